@@ -1,0 +1,135 @@
+/*
+ * lzfse_mi.h -- C ABI of the MI355X-native LZFSE block codec.
+ *
+ * Drop-in boundary for lzfse_rust's slice path (citations relative to the reference tree):
+ *   LzfseEncoder::encode_bytes(&mut self, src:&[u8], dst:&mut Vec<u8>) -> io::Result<u64>
+ *       src/encode/encoder.rs:49-53  -> lzfse_mi_encode
+ *   LzfseDecoder::decode_bytes(&mut self, src:&[u8], dst:&mut Vec<u8>) -> crate::Result<u64>
+ *       src/decode/decoder.rs:61-69  -> lzfse_mi_decode
+ *   decode::probe (sum of n_raw_bytes) src/decode/probe.rs:11-35 -> lzfse_mi_decode_size
+ * Shape follows the in-tree FFI precedent lzfse_sys (lzfse_sys/src/lib.rs:29-56): plain
+ * pointers and sizes, caller-owned buffers, no exceptions, an int status per call.
+ * The Rust-side binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * All compute runs in hand-written HIP kernels for gfx950. There is NO CPU fallback:
+ * lzfse_mi_create fails with LZFSE_MI_NO_DEVICE when no HIP device is usable.
+ */
+#ifndef LZFSE_MI_H
+#define LZFSE_MI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Status codes: 1:1 with crate::Error (src/error/mod.rs:40-61), FseErrorKind
+ * (src/fse/error_kind.rs:9-40) and VnErrorKind (src/vn/error_kind.rs:9-16). */
+enum {
+    LZFSE_MI_OK = 0,
+    LZFSE_MI_IO = 1,                 /* Error::Io: HIP runtime / allocation failure */
+    LZFSE_MI_BAD_BLOCK = 2,          /* Error::BadBlock(magic) */
+    LZFSE_MI_BAD_BIT_STREAM = 3,     /* Error::BadBitStream */
+    LZFSE_MI_BAD_D_VALUE = 4,        /* Error::BadDValue */
+    LZFSE_MI_BAD_READER_STATE = 5,   /* Error::BadReaderState (unused on the slice path) */
+    LZFSE_MI_BUFFER_OVERFLOW = 6,    /* Error::BufferOverflow: dst capacity too small */
+    LZFSE_MI_PAYLOAD_OVERFLOW = 7,   /* Error::PayloadOverflow */
+    LZFSE_MI_PAYLOAD_UNDERFLOW = 8,  /* Error::PayloadUnderflow */
+    LZFSE_MI_UNSUPPORTED = 9,        /* inputs the device path does not take */
+    LZFSE_MI_NO_DEVICE = 10,         /* no usable HIP device: the product never falls back */
+    LZFSE_MI_BAD_ARGUMENT = 11,
+    LZFSE_MI_FSE_BAD_LITERAL_BITS = 16,
+    LZFSE_MI_FSE_BAD_LITERAL_COUNT = 17,
+    LZFSE_MI_FSE_BAD_LITERAL_PAYLOAD = 18,
+    LZFSE_MI_FSE_BAD_LITERAL_STATE = 19,
+    LZFSE_MI_FSE_BAD_LMD_BITS = 20,
+    LZFSE_MI_FSE_BAD_LMD_COUNT = 21,
+    LZFSE_MI_FSE_BAD_LMD_PAYLOAD = 22,
+    LZFSE_MI_FSE_BAD_LMD_STATE = 23,
+    LZFSE_MI_FSE_BAD_PAYLOAD_COUNT = 24,
+    LZFSE_MI_FSE_BAD_RAW_BYTE_COUNT = 25,
+    LZFSE_MI_FSE_BAD_READER_STATE = 26,
+    LZFSE_MI_FSE_BAD_WEIGHT_PAYLOAD = 27,
+    LZFSE_MI_FSE_BAD_WEIGHT_PAYLOAD_COUNT = 28,
+    LZFSE_MI_FSE_WEIGHT_PAYLOAD_OVERFLOW = 29,
+    LZFSE_MI_FSE_WEIGHT_PAYLOAD_UNDERFLOW = 30,
+    LZFSE_MI_VN_BAD_PAYLOAD_COUNT = 48,
+    LZFSE_MI_VN_BAD_PAYLOAD = 49,
+    LZFSE_MI_VN_BAD_OPCODE = 50
+};
+
+/* One context = one HIP device + one HIP stream + reusable device scratch. Like
+ * LzfseEncoder/LzfseDecoder (`&mut self`, encoder.rs:14-18, decoder.rs:17-21) a context is
+ * not thread-safe; distinct contexts are independent. Results never depend on prior calls. */
+typedef struct lzfse_mi_ctx lzfse_mi_ctx;
+
+int lzfse_mi_create(int device, lzfse_mi_ctx **out);
+void lzfse_mi_destroy(lzfse_mi_ctx *ctx);
+const char *lzfse_mi_status_string(int status);
+const char *lzfse_mi_version(void);
+
+/* Use an existing HIP stream (hipStream_t passed as void*, e.g. torch's current stream).
+ * NULL restores the context's own stream. */
+int lzfse_mi_set_stream(lzfse_mi_ctx *ctx, void *hip_stream);
+
+/* Upper bound of the encoded size of an n-byte input (fse/constants.rs:54-69: every full
+ * bvx2 block carries >= 39 996 raw bytes and costs <= 54 bits per LMD + 10 bits per literal). */
+size_t lzfse_mi_encode_bound(size_t n);
+
+/* ---- host-pointer entry points: exactly what the Rust shim binds ---------------------- */
+
+/* encode_bytes: writes the complete stream (blocks + bvx$) for src[0..n) at dst, never more
+ * than cap bytes; *out_len = bytes written (the u64 the Rust method returns). */
+int lzfse_mi_encode(lzfse_mi_ctx *ctx, const uint8_t *src, size_t n, uint8_t *dst, size_t cap,
+                    size_t *out_len);
+
+/* decode_bytes: src[0..n) must be one complete stream ending exactly at bvx$ + 4 bytes
+ * (decoder.rs:90-96). *out_len = raw bytes written. LZFSE_MI_BUFFER_OVERFLOW if cap is short;
+ * size dst with lzfse_mi_decode_size. */
+int lzfse_mi_decode(lzfse_mi_ctx *ctx, const uint8_t *src, size_t n, uint8_t *dst, size_t cap,
+                    size_t *out_len);
+
+/* Header walk on the host: sum of n_raw_bytes of all blocks. */
+int lzfse_mi_decode_size(const uint8_t *src, size_t n, uint64_t *raw_len);
+
+/* Many independent streams per call (the unit of GPU parallelism). The
+ * return value reports call-level failures only; statuses[i] is per stream. */
+int lzfse_mi_encode_batch(lzfse_mi_ctx *ctx, size_t count, const uint8_t *const *srcs,
+                          const size_t *lens, uint8_t *const *dsts, const size_t *caps,
+                          size_t *out_lens, int *statuses);
+int lzfse_mi_decode_batch(lzfse_mi_ctx *ctx, size_t count, const uint8_t *const *srcs,
+                          const size_t *lens, uint8_t *const *dsts, const size_t *caps,
+                          size_t *out_lens, int *statuses);
+
+/* ---- device-resident entry points (inputs and outputs already in HBM) ----------------- */
+/* Stream i reads d_src[src_off[i] .. src_off[i] + src_len[i]) and writes at
+ * d_dst[dst_off[i] ..], at most dst_cap[i] bytes. Offset/length arrays are HOST arrays.
+ * out_lens / statuses are HOST arrays filled when the call returns (the call synchronises
+ * the context's stream once at its end). */
+int lzfse_mi_decode_batch_device(lzfse_mi_ctx *ctx, size_t count, const void *d_src,
+                                 const uint64_t *src_off, const uint64_t *src_len, void *d_dst,
+                                 const uint64_t *dst_off, const uint64_t *dst_cap,
+                                 uint64_t *out_lens, int *statuses);
+int lzfse_mi_encode_batch_device(lzfse_mi_ctx *ctx, size_t count, const void *d_src,
+                                 const uint64_t *src_off, const uint64_t *src_len, void *d_dst,
+                                 const uint64_t *dst_off, const uint64_t *dst_cap,
+                                 uint64_t *out_lens, int *statuses);
+
+/* ---- measurement ---------------------------------------------------------------------- */
+/* Per-kernel device time of the LAST batch call on this context, measured with HIP events
+ * recorded on the stream the kernels were launched on. names[i] points at static strings. */
+#define LZFSE_MI_MAX_STAGES 24
+typedef struct lzfse_mi_timings {
+    int n_stages;
+    const char *names[LZFSE_MI_MAX_STAGES];
+    float ms[LZFSE_MI_MAX_STAGES];
+    uint64_t launches[LZFSE_MI_MAX_STAGES];
+} lzfse_mi_timings;
+int lzfse_mi_enable_timing(lzfse_mi_ctx *ctx, int enable);
+int lzfse_mi_get_timings(lzfse_mi_ctx *ctx, lzfse_mi_timings *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

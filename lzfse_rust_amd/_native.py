@@ -1,0 +1,67 @@
+"""ctypes binding of include/lzfse_mi.h. Loading fails loudly when the HIP library is missing."""
+import ctypes as C
+import os
+
+from . import build as _build
+
+MAX_STAGES = 24
+
+
+class Timings(C.Structure):
+    _fields_ = [("n_stages", C.c_int), ("names", C.c_char_p * MAX_STAGES), ("ms", C.c_float * MAX_STAGES),
+                ("launches", C.c_uint64 * MAX_STAGES)]
+
+
+_lib = None
+
+_SYMBOLS = [
+    "lzfse_mi_create", "lzfse_mi_destroy", "lzfse_mi_status_string", "lzfse_mi_version", "lzfse_mi_set_stream",
+    "lzfse_mi_encode_bound", "lzfse_mi_encode", "lzfse_mi_decode", "lzfse_mi_decode_size",
+    "lzfse_mi_encode_batch", "lzfse_mi_decode_batch", "lzfse_mi_decode_batch_device",
+    "lzfse_mi_encode_batch_device", "lzfse_mi_enable_timing", "lzfse_mi_get_timings",
+]
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`. "
+                           "There is no CPU fallback for the MI355X codec.")
+    L = C.CDLL(path)
+    for s in _SYMBOLS:
+        getattr(L, s)  # raises AttributeError if the ABI is incomplete
+    vp, sz, u64p, ip = C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_int)
+    L.lzfse_mi_create.restype = C.c_int
+    L.lzfse_mi_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.lzfse_mi_destroy.restype = None
+    L.lzfse_mi_destroy.argtypes = [vp]
+    L.lzfse_mi_status_string.restype = C.c_char_p
+    L.lzfse_mi_status_string.argtypes = [C.c_int]
+    L.lzfse_mi_version.restype = C.c_char_p
+    L.lzfse_mi_set_stream.restype = C.c_int
+    L.lzfse_mi_set_stream.argtypes = [vp, vp]
+    L.lzfse_mi_encode_bound.restype = sz
+    L.lzfse_mi_encode_bound.argtypes = [sz]
+    for name in ("lzfse_mi_encode", "lzfse_mi_decode"):
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
+    L.lzfse_mi_decode_size.restype = C.c_int
+    L.lzfse_mi_decode_size.argtypes = [vp, sz, u64p]
+    for name in ("lzfse_mi_encode_batch", "lzfse_mi_decode_batch"):
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = [vp, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), ip]
+    for name in ("lzfse_mi_encode_batch_device", "lzfse_mi_decode_batch_device"):
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = [vp, sz, vp, u64p, u64p, vp, u64p, u64p, u64p, ip]
+    L.lzfse_mi_enable_timing.restype = C.c_int
+    L.lzfse_mi_enable_timing.argtypes = [vp, C.c_int]
+    L.lzfse_mi_get_timings.restype = C.c_int
+    L.lzfse_mi_get_timings.argtypes = [vp, C.POINTER(Timings)]
+    _lib = L
+    return L

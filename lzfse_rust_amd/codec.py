@@ -1,0 +1,159 @@
+"""Host-side mirror of lzfse_rust's slice API over the MI355X C ABI.
+
+    LzfseEncoder.encode_bytes(src, dst) -> int     src/encode/encoder.rs:49-53
+    LzfseDecoder.decode_bytes(src, dst) -> int     src/decode/decoder.rs:61-69
+    encode_bytes / decode_bytes (free functions)   src/encode/mod.rs:58-60, src/decode/mod.rs:49-51
+
+Same names, argument meaning and error behaviour: `dst` (a bytearray, the Vec<u8>) is appended
+to, never cleared, and the number of appended bytes is returned; decode errors raise LzfseError
+carrying the status code that maps 1:1 on crate::Error. All compute runs on the GPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native
+
+OK = 0
+
+
+class LzfseError(Exception):
+    """crate::Error (src/error/mod.rs:40-61) / io::Error for the encoder."""
+
+    def __init__(self, status):
+        self.status = int(status)
+        msg = _native.lib().lzfse_mi_status_string(self.status).decode()
+        super().__init__(f"lzfse status {self.status}: {msg}")
+
+
+def _check(st):
+    if st != OK:
+        raise LzfseError(st)
+
+
+class Context:
+    """One HIP device + stream + scratch (lzfse_mi_ctx)."""
+
+    def __init__(self, device=0):
+        self._lib = _native.lib()
+        h = C.c_void_p()
+        _check(self._lib.lzfse_mi_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lzfse_mi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- stream / timing plumbing --
+    def set_stream(self, hip_stream_ptr):
+        _check(self._lib.lzfse_mi_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    def enable_timing(self, on=True):
+        _check(self._lib.lzfse_mi_enable_timing(self._h, 1 if on else 0))
+
+    def timings(self):
+        t = _native.Timings()
+        _check(self._lib.lzfse_mi_get_timings(self._h, C.byref(t)))
+        return {t.names[i].decode(): (float(t.ms[i]), int(t.launches[i])) for i in range(t.n_stages)}
+
+    # -- host-pointer batch --
+    def _host_batch(self, fn, srcs, caps):
+        n = len(srcs)
+        arrs = [np.frombuffer(bytes(s) if not isinstance(s, np.ndarray) else s, dtype=np.uint8) for s in srcs]
+        outs = [np.empty(max(int(c), 1), dtype=np.uint8) for c in caps]
+        sp = (C.c_void_p * n)(*[a.ctypes.data if a.size else None for a in arrs])
+        sl = (C.c_size_t * n)(*[a.size for a in arrs])
+        dp = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        dc = (C.c_size_t * n)(*[int(c) for c in caps])
+        ol = (C.c_size_t * n)()
+        st = (C.c_int * n)()
+        _check(fn(self._h, n, sp, sl, dp, dc, ol, st))
+        return [outs[i][: ol[i]] for i in range(n)], list(st)
+
+    def encode_batch(self, srcs):
+        caps = [self._lib.lzfse_mi_encode_bound(len(s)) for s in srcs]
+        return self._host_batch(self._lib.lzfse_mi_encode_batch, srcs, caps)
+
+    def decode_batch(self, srcs, caps=None):
+        if caps is None:
+            caps = [decode_size(s) for s in srcs]
+        return self._host_batch(self._lib.lzfse_mi_decode_batch, srcs, caps)
+
+    # -- device-resident batch: raw device pointers (e.g. torch tensor.data_ptr()) --
+    def _device_batch(self, fn, d_src, src_off, src_len, d_dst, dst_off, dst_cap):
+        n = len(src_off)
+        so = np.ascontiguousarray(src_off, dtype=np.uint64)
+        sl = np.ascontiguousarray(src_len, dtype=np.uint64)
+        do = np.ascontiguousarray(dst_off, dtype=np.uint64)
+        dc = np.ascontiguousarray(dst_cap, dtype=np.uint64)
+        ol = np.zeros(n, dtype=np.uint64)
+        st = np.zeros(n, dtype=np.int32)
+        u64p, ip = C.POINTER(C.c_uint64), C.POINTER(C.c_int)
+        _check(fn(self._h, n, C.c_void_p(d_src), so.ctypes.data_as(u64p), sl.ctypes.data_as(u64p),
+                  C.c_void_p(d_dst), do.ctypes.data_as(u64p), dc.ctypes.data_as(u64p), ol.ctypes.data_as(u64p),
+                  st.ctypes.data_as(ip)))
+        return ol, st
+
+    def decode_batch_device(self, d_src, src_off, src_len, d_dst, dst_off, dst_cap):
+        return self._device_batch(self._lib.lzfse_mi_decode_batch_device, d_src, src_off, src_len, d_dst, dst_off,
+                                  dst_cap)
+
+    def encode_batch_device(self, d_src, src_off, src_len, d_dst, dst_off, dst_cap):
+        return self._device_batch(self._lib.lzfse_mi_encode_batch_device, d_src, src_off, src_len, d_dst, dst_off,
+                                  dst_cap)
+
+
+def encode_bound(n):
+    return _native.lib().lzfse_mi_encode_bound(int(n))
+
+
+def decode_size(src):
+    """decode::probe: sum of n_raw_bytes over the block headers (src/decode/probe.rs:11-35)."""
+    a = np.frombuffer(bytes(src) if not isinstance(src, np.ndarray) else src, dtype=np.uint8)
+    v = C.c_uint64(0)
+    _check(_native.lib().lzfse_mi_decode_size(a.ctypes.data if a.size else None, a.size, C.byref(v)))
+    return v.value
+
+
+class LzfseEncoder:
+    """src/encode/encoder.rs:14-54."""
+
+    def __init__(self, device=0, context=None):
+        self._ctx = context or Context(device)
+
+    def encode_bytes(self, src, dst):
+        """Appends the LZFSE stream of `src` to bytearray `dst`; returns bytes appended."""
+        outs, st = self._ctx.encode_batch([src])
+        _check(st[0])
+        dst += outs[0].tobytes()
+        return len(outs[0])
+
+
+class LzfseDecoder:
+    """src/decode/decoder.rs:17-99."""
+
+    def __init__(self, device=0, context=None):
+        self._ctx = context or Context(device)
+
+    def decode_bytes(self, src, dst):
+        """Appends the decoded bytes of stream `src` to bytearray `dst`; returns bytes appended."""
+        outs, st = self._ctx.decode_batch([src])
+        _check(st[0])
+        dst += outs[0].tobytes()
+        return len(outs[0])
+
+
+def encode_bytes(src, dst):
+    return LzfseEncoder().encode_bytes(src, dst)
+
+
+def decode_bytes(src, dst):
+    return LzfseDecoder().decode_bytes(src, dst)

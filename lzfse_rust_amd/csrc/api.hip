@@ -1,0 +1,427 @@
+// C ABI of the MI355X LZFSE codec (include/lzfse_mi.h): context, device scratch, batching.
+// Host side of LzfseEncoder::encode_bytes (encode/encoder.rs:49-53) and
+// LzfseDecoder::decode_bytes (decode/decoder.rs:61-99). No CPU codec lives here: every
+// byte of bvx2 entropy coding, match finding and LZ copy is produced by the HIP kernels
+// in decode.hip / encode.hip.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "common.h"
+#include "internal.h"
+
+using namespace lzmi;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    // grow-only device buffer; contents are NOT preserved
+    bool ensure(size_t n) {
+        if (n <= cap) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        size_t nc = n + n / 4 + 4096;
+        if (hipMalloc(&p, nc) != hipSuccess) { cap = 0; p = nullptr; return false; }
+        cap = nc;
+        return true;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct HostBuf {  // pinned staging
+    void *p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t n) {
+        if (n <= cap) return true;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        size_t nc = n + n / 4 + 4096;
+        if (hipHostMalloc(&p, nc, hipHostMallocDefault) != hipSuccess) { cap = 0; p = nullptr; return false; }
+        cap = nc;
+        return true;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct lzfse_mi_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // batch descriptors / results
+    DevBuf d_streams, d_walk, d_plan, d_blocks, d_bres, d_sres;
+    // decode scratch
+    DevBuf d_lmds, d_lits;
+    // encode scratch (encode.hip)
+    EncScratch enc;
+    // host-pointer API staging
+    DevBuf d_in, d_out;
+    HostBuf h_in, h_out;
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    struct Span { const char *name; hipEvent_t a, b; };
+    std::vector<Span> spans;
+    lzfse_mi_timings last{};
+
+    hipEvent_t get_event() {
+        if (ev_used == ev_pool.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            ev_pool.push_back(e);
+        }
+        return ev_pool[ev_used++];
+    }
+};
+
+namespace lzmi {
+// RAII helper: brackets a kernel (or group) with events when timing is enabled
+StageTimer::StageTimer(lzfse_mi_ctx *c, const char *name) : ctx(c) {
+    if (!ctx->timing) return;
+    hipEvent_t a = ctx->get_event(), b = ctx->get_event();
+    if (!a || !b) return;
+    (void)hipEventRecord(a, ctx->stream);
+    ctx->spans.push_back({name, a, b});
+    idx = (int)ctx->spans.size() - 1;
+}
+StageTimer::~StageTimer() {
+    if (idx >= 0) (void)hipEventRecord(ctx->spans[idx].b, ctx->stream);
+}
+hipStream_t ctx_stream(lzfse_mi_ctx *c) { return c->stream; }
+EncScratch &ctx_enc(lzfse_mi_ctx *c) { return c->enc; }
+}  // namespace lzmi
+
+static void timing_begin(lzfse_mi_ctx *c) {
+    c->ev_used = 0;
+    c->spans.clear();
+}
+
+static void timing_end(lzfse_mi_ctx *c) {
+    lzfse_mi_timings &t = c->last;
+    memset(&t, 0, sizeof t);
+    if (!c->timing) return;
+    for (auto &sp : c->spans) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) != hipSuccess) continue;
+        int k = -1;
+        for (int i = 0; i < t.n_stages; i++)
+            if (t.names[i] == sp.name) k = i;
+        if (k < 0) {
+            if (t.n_stages == LZFSE_MI_MAX_STAGES) continue;
+            k = t.n_stages++;
+            t.names[k] = sp.name;
+        }
+        t.ms[k] += ms;
+        t.launches[k] += 1;
+    }
+}
+
+#define HIP_TRY(x) do { if ((x) != hipSuccess) { return LZFSE_MI_IO; } } while (0)
+
+extern "C" {
+
+const char *lzfse_mi_version(void) { return "lzfse-mi355x 0.1.0 (gfx950)"; }
+
+const char *lzfse_mi_status_string(int s) {
+    switch (s) {
+    case LZFSE_MI_OK: return "ok";
+    case LZFSE_MI_IO: return "io / HIP runtime error";
+    case LZFSE_MI_BAD_BLOCK: return "bad block";
+    case LZFSE_MI_BAD_BIT_STREAM: return "bad bitstream";
+    case LZFSE_MI_BAD_D_VALUE: return "bad D value";
+    case LZFSE_MI_BAD_READER_STATE: return "bad reader state";
+    case LZFSE_MI_BUFFER_OVERFLOW: return "buffer overflow";
+    case LZFSE_MI_PAYLOAD_OVERFLOW: return "bad payload overflow";
+    case LZFSE_MI_PAYLOAD_UNDERFLOW: return "bad payload underflow";
+    case LZFSE_MI_UNSUPPORTED: return "unsupported input";
+    case LZFSE_MI_NO_DEVICE: return "no usable HIP device";
+    case LZFSE_MI_BAD_ARGUMENT: return "bad argument";
+    case LZFSE_MI_FSE_BAD_LITERAL_BITS: return "FSE: bad literal bits";
+    case LZFSE_MI_FSE_BAD_LITERAL_COUNT: return "FSE: bad literal count";
+    case LZFSE_MI_FSE_BAD_LITERAL_PAYLOAD: return "FSE: bad literal payload";
+    case LZFSE_MI_FSE_BAD_LITERAL_STATE: return "FSE: bad literal state";
+    case LZFSE_MI_FSE_BAD_LMD_BITS: return "FSE: bad LMD bits";
+    case LZFSE_MI_FSE_BAD_LMD_COUNT: return "FSE: bad LMD count";
+    case LZFSE_MI_FSE_BAD_LMD_PAYLOAD: return "FSE: bad LMD payload";
+    case LZFSE_MI_FSE_BAD_LMD_STATE: return "FSE: bad LMD state";
+    case LZFSE_MI_FSE_BAD_PAYLOAD_COUNT: return "FSE: bad payload count";
+    case LZFSE_MI_FSE_BAD_RAW_BYTE_COUNT: return "FSE: bad raw byte count";
+    case LZFSE_MI_FSE_BAD_READER_STATE: return "FSE: bad reader state";
+    case LZFSE_MI_FSE_BAD_WEIGHT_PAYLOAD: return "FSE: bad weight payload";
+    case LZFSE_MI_FSE_BAD_WEIGHT_PAYLOAD_COUNT: return "FSE: bad weight payload count";
+    case LZFSE_MI_FSE_WEIGHT_PAYLOAD_OVERFLOW: return "FSE: weight payload overflow";
+    case LZFSE_MI_FSE_WEIGHT_PAYLOAD_UNDERFLOW: return "FSE: weight payload underflow";
+    case LZFSE_MI_VN_BAD_PAYLOAD_COUNT: return "VN: bad payload count";
+    case LZFSE_MI_VN_BAD_PAYLOAD: return "VN: bad payload";
+    case LZFSE_MI_VN_BAD_OPCODE: return "VN: bad opcode";
+    default: return "unknown status";
+    }
+}
+
+int lzfse_mi_create(int device, lzfse_mi_ctx **out) {
+    if (!out) return LZFSE_MI_BAD_ARGUMENT;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return LZFSE_MI_NO_DEVICE;
+    if (device < 0 || device >= n) return LZFSE_MI_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return LZFSE_MI_NO_DEVICE;
+    lzfse_mi_ctx *c = new (std::nothrow) lzfse_mi_ctx();
+    if (!c) return LZFSE_MI_IO;
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return LZFSE_MI_NO_DEVICE;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return LZFSE_MI_OK;
+}
+
+void lzfse_mi_destroy(lzfse_mi_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf *b : {&c->d_streams, &c->d_walk, &c->d_plan, &c->d_blocks, &c->d_bres, &c->d_sres,
+                      &c->d_lmds, &c->d_lits, &c->d_in, &c->d_out})
+        b->release();
+    enc_scratch_release(c->enc);
+    c->h_in.release();
+    c->h_out.release();
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int lzfse_mi_set_stream(lzfse_mi_ctx *c, void *hip_stream) {
+    if (!c) return LZFSE_MI_BAD_ARGUMENT;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return LZFSE_MI_OK;
+}
+
+size_t lzfse_mi_encode_bound(size_t n) { return n + n / 2 + n / 4 + 4096; }
+
+int lzfse_mi_enable_timing(lzfse_mi_ctx *c, int enable) {
+    if (!c) return LZFSE_MI_BAD_ARGUMENT;
+    c->timing = enable != 0;
+    return LZFSE_MI_OK;
+}
+
+int lzfse_mi_get_timings(lzfse_mi_ctx *c, lzfse_mi_timings *out) {
+    if (!c || !out) return LZFSE_MI_BAD_ARGUMENT;
+    *out = c->last;
+    return LZFSE_MI_OK;
+}
+
+// decode/probe.rs:11-35 on the host (pure header arithmetic, no payload is touched)
+int lzfse_mi_decode_size(const uint8_t *src, size_t n, uint64_t *raw_len) {
+    if ((!src && n) || !raw_len) return LZFSE_MI_BAD_ARGUMENT;
+    size_t pos = 0;
+    uint64_t total = 0;
+    for (;;) {
+        if (n - pos < 4) return LZFSE_MI_PAYLOAD_UNDERFLOW;
+        uint32_t magic = ld_u32(src + pos);
+        size_t avail = n - pos;
+        uint64_t skip;
+        uint32_t n_raw;
+        if (magic == MAGIC_EOS) break;
+        if (magic == MAGIC_VX2 || magic == MAGIC_VX1) {
+            bool v1 = magic == MAGIC_VX1;
+            if (avail < (v1 ? V1_HEADER_SIZE : V2_HEADER_SIZE)) return LZFSE_MI_PAYLOAD_UNDERFLOW;
+            FseHeader h;
+            int e = v1 ? fse_load_v1(src + pos, h) : fse_load_v2(src + pos, h);
+            if (e) return e;
+            skip = (uint64_t)h.hdr_size + h.lit_payload + h.lmd_payload;
+            n_raw = h.n_raw;
+        } else if (magic == MAGIC_VXN) {
+            if (avail < 12) return LZFSE_MI_PAYLOAD_UNDERFLOW;
+            n_raw = ld_u32(src + pos + 4);
+            skip = 12ull + ld_u32(src + pos + 8);
+        } else if (magic == MAGIC_RAW) {
+            if (avail < 8) return LZFSE_MI_PAYLOAD_UNDERFLOW;
+            n_raw = ld_u32(src + pos + 4);
+            skip = 8ull + n_raw;
+        } else {
+            return LZFSE_MI_BAD_BLOCK;
+        }
+        if (skip >= avail) return LZFSE_MI_PAYLOAD_UNDERFLOW;
+        pos += (size_t)skip;
+        total += n_raw;
+    }
+    if (n - pos != 4) return LZFSE_MI_PAYLOAD_OVERFLOW;
+    *raw_len = total;
+    return LZFSE_MI_OK;
+}
+
+// ---------------------------------------------------------------------------- decode (device)
+
+int lzfse_mi_decode_batch_device(lzfse_mi_ctx *c, size_t count, const void *d_src, const uint64_t *src_off,
+                                 const uint64_t *src_len, void *d_dst, const uint64_t *dst_off,
+                                 const uint64_t *dst_cap, uint64_t *out_lens, int *statuses) {
+    if (!c || (count && (!src_off || !src_len || !dst_off || !dst_cap || !out_lens || !statuses)))
+        return LZFSE_MI_BAD_ARGUMENT;
+    if (count == 0) return LZFSE_MI_OK;
+    if (count > 0x7FFFFFFFu) return LZFSE_MI_BAD_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device));
+    timing_begin(c);
+    hipStream_t st = c->stream;
+    const uint32_t ns = (uint32_t)count;
+    std::vector<StreamIn> h_streams(ns);
+    uint64_t src_total = 0;
+    for (uint32_t i = 0; i < ns; i++) {
+        h_streams[i] = {src_off[i], src_len[i], dst_off[i], dst_cap[i]};
+        src_total = std::max<uint64_t>(src_total, src_off[i] + src_len[i]);
+    }
+    if (!c->d_streams.ensure(ns * sizeof(StreamIn)) || !c->d_walk.ensure(ns * sizeof(StreamWalk)) ||
+        !c->d_plan.ensure(ns * sizeof(StreamPlan)) || !c->d_sres.ensure(ns * sizeof(StreamResult)))
+        return LZFSE_MI_IO;
+    HIP_TRY(hipMemcpyAsync(c->d_streams.p, h_streams.data(), ns * sizeof(StreamIn), hipMemcpyHostToDevice, st));
+    // pass 1: count
+    {
+        StageTimer t(c, "dec_walk");
+        launch_dec_walk(false, (const uint8_t *)d_src, (const StreamIn *)c->d_streams.p, ns,
+                        (StreamWalk *)c->d_walk.p, nullptr, nullptr, st);
+    }
+    std::vector<StreamWalk> h_walk(ns);
+    HIP_TRY(hipMemcpyAsync(h_walk.data(), c->d_walk.p, ns * sizeof(StreamWalk), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::vector<StreamPlan> h_plan(ns);
+    uint64_t nb = 0, nl = 0, nu = 0;
+    for (uint32_t i = 0; i < ns; i++) {
+        StreamPlan &p = h_plan[i];
+        p.blk_base = nb; p.lmd_base = nl; p.lit_base = nu; p.n_blocks = h_walk[i].n_blocks; p.skip = 0;
+        statuses[i] = LZFSE_MI_OK;
+        out_lens[i] = 0;
+        if (h_walk[i].status) { statuses[i] = h_walk[i].status; p.skip = 1; p.n_blocks = 0; continue; }
+        if (h_walk[i].raw_total > dst_cap[i]) { statuses[i] = LZFSE_MI_BUFFER_OVERFLOW; p.skip = 1; p.n_blocks = 0; continue; }
+        nb += h_walk[i].n_blocks; nl += h_walk[i].n_lmds; nu += h_walk[i].n_lits;
+    }
+    if (nb > 0x7FFFFFFFull) return LZFSE_MI_UNSUPPORTED;
+    if (!c->d_blocks.ensure((nb + 1) * sizeof(BlockDesc)) || !c->d_bres.ensure((nb + 1) * sizeof(BlockResult)) ||
+        !c->d_lmds.ensure((nl + 64) * sizeof(LmdRec)) || !c->d_lits.ensure(nu + 256))
+        return LZFSE_MI_IO;
+    HIP_TRY(hipMemcpyAsync(c->d_plan.p, h_plan.data(), ns * sizeof(StreamPlan), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(c->d_bres.p, 0, (nb + 1) * sizeof(BlockResult), st));
+    HIP_TRY(hipMemsetAsync(c->d_sres.p, 0, ns * sizeof(StreamResult), st));
+    {
+        StageTimer t(c, "dec_walk");
+        launch_dec_walk(true, (const uint8_t *)d_src, (const StreamIn *)c->d_streams.p, ns, nullptr,
+                        (const StreamPlan *)c->d_plan.p, (BlockDesc *)c->d_blocks.p, st);
+    }
+    {
+        StageTimer t(c, "dec_fse");
+        launch_dec_fse((const uint8_t *)d_src, src_total, (const BlockDesc *)c->d_blocks.p, (uint32_t)nb,
+                       (uint8_t *)c->d_lits.p, (LmdRec *)c->d_lmds.p, (BlockResult *)c->d_bres.p, st);
+    }
+    {
+        StageTimer t(c, "dec_lz");
+        int variant = ns >= 512 ? 0 : 1;
+        if (const char *ev = getenv("LZFSE_MI_LZ_VARIANT")) variant = atoi(ev);
+        launch_dec_lz(variant, (const uint8_t *)d_src, (const StreamIn *)c->d_streams.p,
+                      (const StreamPlan *)c->d_plan.p, ns, (const BlockDesc *)c->d_blocks.p,
+                      (const BlockResult *)c->d_bres.p, (const LmdRec *)c->d_lmds.p, (const uint8_t *)c->d_lits.p,
+                      (uint8_t *)d_dst, (StreamResult *)c->d_sres.p, st);
+    }
+    std::vector<StreamResult> h_sres(ns);
+    HIP_TRY(hipMemcpyAsync(h_sres.data(), c->d_sres.p, ns * sizeof(StreamResult), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (hipGetLastError() != hipSuccess) return LZFSE_MI_IO;
+    for (uint32_t i = 0; i < ns; i++) {
+        if (h_plan[i].skip) continue;
+        statuses[i] = h_sres[i].status;
+        out_lens[i] = h_sres[i].status ? 0 : h_sres[i].out_len;
+    }
+    timing_end(c);
+    return LZFSE_MI_OK;
+}
+
+int lzfse_mi_encode_batch_device(lzfse_mi_ctx *c, size_t count, const void *d_src, const uint64_t *src_off,
+                                 const uint64_t *src_len, void *d_dst, const uint64_t *dst_off,
+                                 const uint64_t *dst_cap, uint64_t *out_lens, int *statuses) {
+    if (!c || (count && (!src_off || !src_len || !dst_off || !dst_cap || !out_lens || !statuses)))
+        return LZFSE_MI_BAD_ARGUMENT;
+    if (count == 0) return LZFSE_MI_OK;
+    if (count > 0x7FFFFFFFu) return LZFSE_MI_BAD_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device));
+    timing_begin(c);
+    int r = enc_batch_device(c, (uint32_t)count, (const uint8_t *)d_src, src_off, src_len, (uint8_t *)d_dst,
+                             dst_off, dst_cap, out_lens, statuses);
+    timing_end(c);
+    return r;
+}
+
+// ---------------------------------------------------------------------------- host-pointer API
+
+typedef int (*batch_dev_fn)(lzfse_mi_ctx *, size_t, const void *, const uint64_t *, const uint64_t *, void *,
+                            const uint64_t *, const uint64_t *, uint64_t *, int *);
+
+static int host_batch(lzfse_mi_ctx *c, batch_dev_fn fn, size_t count, const uint8_t *const *srcs,
+                      const size_t *lens, uint8_t *const *dsts, const size_t *caps, size_t *out_lens,
+                      int *statuses) {
+    if (!c || (count && (!srcs || !lens || !dsts || !caps || !out_lens || !statuses))) return LZFSE_MI_BAD_ARGUMENT;
+    if (count == 0) return LZFSE_MI_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<uint64_t> so(count), sl(count), dof(count), dc(count), ol(count);
+    uint64_t in_total = 0, out_total = 0;
+    for (size_t i = 0; i < count; i++) {
+        so[i] = in_total; sl[i] = lens[i];
+        in_total += (lens[i] + 255) & ~(uint64_t)255;
+        dof[i] = out_total; dc[i] = caps[i];
+        out_total += (caps[i] + 255) & ~(uint64_t)255;
+    }
+    if (!c->d_in.ensure(in_total + 256) || !c->d_out.ensure(out_total + 256) || !c->h_in.ensure(in_total + 256) ||
+        !c->h_out.ensure(out_total + 256))
+        return LZFSE_MI_IO;
+    for (size_t i = 0; i < count; i++)
+        if (lens[i]) memcpy((uint8_t *)c->h_in.p + so[i], srcs[i], lens[i]);
+    HIP_TRY(hipMemcpyAsync(c->d_in.p, c->h_in.p, in_total, hipMemcpyHostToDevice, c->stream));
+    int r = fn(c, count, c->d_in.p, so.data(), sl.data(), c->d_out.p, dof.data(), dc.data(), ol.data(), statuses);
+    if (r) return r;
+    // copy back only what was produced
+    uint64_t hi = 0;
+    for (size_t i = 0; i < count; i++)
+        if (statuses[i] == 0 && ol[i]) hi = std::max(hi, dof[i] + ol[i]);
+    if (hi) {
+        HIP_TRY(hipMemcpyAsync(c->h_out.p, c->d_out.p, hi, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    for (size_t i = 0; i < count; i++) {
+        out_lens[i] = statuses[i] == 0 ? (size_t)ol[i] : 0;
+        if (statuses[i] == 0 && ol[i]) memcpy(dsts[i], (uint8_t *)c->h_out.p + dof[i], ol[i]);
+    }
+    return LZFSE_MI_OK;
+}
+
+int lzfse_mi_decode_batch(lzfse_mi_ctx *c, size_t count, const uint8_t *const *srcs, const size_t *lens,
+                          uint8_t *const *dsts, const size_t *caps, size_t *out_lens, int *statuses) {
+    return host_batch(c, lzfse_mi_decode_batch_device, count, srcs, lens, dsts, caps, out_lens, statuses);
+}
+
+int lzfse_mi_encode_batch(lzfse_mi_ctx *c, size_t count, const uint8_t *const *srcs, const size_t *lens,
+                          uint8_t *const *dsts, const size_t *caps, size_t *out_lens, int *statuses) {
+    return host_batch(c, lzfse_mi_encode_batch_device, count, srcs, lens, dsts, caps, out_lens, statuses);
+}
+
+int lzfse_mi_decode(lzfse_mi_ctx *c, const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *out_len) {
+    if (!out_len) return LZFSE_MI_BAD_ARGUMENT;
+    int st = 0;
+    int r = lzfse_mi_decode_batch(c, 1, &src, &n, &dst, &cap, out_len, &st);
+    return r ? r : st;
+}
+
+int lzfse_mi_encode(lzfse_mi_ctx *c, const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *out_len) {
+    if (!out_len) return LZFSE_MI_BAD_ARGUMENT;
+    int st = 0;
+    int r = lzfse_mi_encode_batch(c, 1, &src, &n, &dst, &cap, out_len, &st);
+    return r ? r : st;
+}
+
+}  // extern "C"

@@ -1,0 +1,757 @@
+// Decode side of the MI355X LZFSE codec: hand-written HIP kernels for gfx950 (wave64).
+//
+//   dec_walk_kernel   header walk per stream            decoder.rs:61-99, probe.rs:11-35
+//   dec_fse_kernel    weights -> tables (LDS) -> FSE     fse_core.rs:49-141, weights.rs:83-105,
+//                     decode of literals and LMDs        decoder.rs:244-335, literals.rs:49-91
+//   dec_lz_kernel     literal / match copy (LZ77)        lz/writer.rs:97-186, lz/object.rs:27-74
+//                     + bvx- and bvxn blocks             raw/block.rs:46-93, vn/vn_core.rs:40-287
+//
+// Parallelism: FSE is serial per bit stream, so the entropy stage runs one workgroup (two
+// waves: LMD stream, literal stream) per bvx2 block with its 7 KiB of tables in LDS and
+// uses lanes 0..2 / 0..3 of a wave for the interleaved L,M,D / four literal states
+// (one LDS table fetch + a DPP prefix sum over bit counts per step). The LZ stage runs one
+// workgroup per stream, stages a tile of output in LDS, resolves near matches there and
+// writes the tile back with coalesced 16-byte stores.
+#include "common.h"
+
+namespace lzmi {
+
+// ------------------------------------------------------------------------------------ utils
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// value of `v` in the lane `delta` below (0 for lanes < delta); DPP row_shr within rows of
+// 16 lanes is enough for the 3- and 4-lane prefix sums used here.
+template <int DELTA>
+__device__ __forceinline__ uint32_t dpp_shr(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + DELTA, 0xF, 0xF, true);
+}
+
+__device__ __forceinline__ uint32_t read_lane(uint32_t v, int lane) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+
+// wave-level inclusive scan (shuffle based; used outside the hot loops)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    int l = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d);
+        if (l >= d) v += o;
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------ headers
+
+// ------------------------------------------------------------------------------------ walk
+
+// One thread per stream. EMIT = false: count blocks / LMDs / literals and validate headers.
+// EMIT = true: write BlockDesc records at the bases the host assigned from the counts.
+template <bool EMIT>
+__global__ void dec_walk_kernel(const uint8_t *__restrict__ src, const StreamIn *__restrict__ streams,
+                                uint32_t n_streams, StreamWalk *__restrict__ walk,
+                                const StreamPlan *__restrict__ plan, BlockDesc *__restrict__ blocks) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_streams) return;
+    if (EMIT && plan[s].skip) return;
+    const StreamIn in = streams[s];
+    const uint8_t *base = src + in.src_off;
+    uint64_t n = in.src_len, pos = 0;
+    StreamWalk w;
+    w.n_lmds = 0; w.n_lits = 0; w.raw_total = 0; w.n_blocks = 0; w.status = 0; w.err_block = 0; w.pad = 0;
+    uint64_t blk_i = 0, lmd_i = 0, lit_i = 0;
+    if (EMIT) { blk_i = plan[s].blk_base; lmd_i = plan[s].lmd_base; lit_i = plan[s].lit_base; }
+    uint32_t max_blocks = EMIT ? plan[s].n_blocks : 0xFFFFFFFFu;
+    for (;;) {
+        if (n - pos < 4) { w.status = LZFSE_MI_PAYLOAD_UNDERFLOW; break; }
+        uint32_t magic = ld_u32(base + pos);
+        uint64_t avail = n - pos;
+        if (magic == MAGIC_EOS) {
+            if (avail != 4) w.status = LZFSE_MI_PAYLOAD_OVERFLOW;  // decoder.rs:93-95
+            break;
+        }
+        BlockDesc d;
+        d.src_pos = in.src_off + pos; d.src_end = in.src_off + n; d.dst_rel = w.raw_total;
+        d.lmd_base = lmd_i; d.lit_base = lit_i; d.stream = s;
+        d.n_lmd = 0; d.n_lit = 0; d.n_raw = 0; d.payload = 0;
+        uint64_t skip;
+        int st = 0;
+        if (magic == MAGIC_VX2 || magic == MAGIC_VX1) {
+            FseHeader h;
+            bool v1 = magic == MAGIC_VX1;
+            if (avail < (v1 ? V1_HEADER_SIZE : V2_HEADER_SIZE)) st = LZFSE_MI_PAYLOAD_UNDERFLOW;
+            else st = v1 ? fse_load_v1(base + pos, h) : fse_load_v2(base + pos, h);
+            if (!st) {
+                skip = (uint64_t)h.hdr_size + h.lit_payload + h.lmd_payload;
+                if (skip > avail) st = LZFSE_MI_PAYLOAD_UNDERFLOW;  // decode/take.rs:10-19
+                d.kind = v1 ? KIND_VX1 : KIND_VX2;
+                d.n_lmd = h.lmd_num; d.n_lit = h.lit_num; d.n_raw = h.n_raw;
+            }
+        } else if (magic == MAGIC_VXN) {
+            if (avail < 12) st = LZFSE_MI_PAYLOAD_UNDERFLOW;
+            else {
+                d.kind = KIND_VXN;
+                d.n_raw = ld_u32(base + pos + 4);
+                d.payload = ld_u32(base + pos + 8);
+                skip = 12ull + d.payload;
+                if (skip > avail) st = LZFSE_MI_PAYLOAD_UNDERFLOW;
+            }
+        } else if (magic == MAGIC_RAW) {
+            if (avail < 8) st = LZFSE_MI_PAYLOAD_UNDERFLOW;
+            else {
+                d.kind = KIND_RAW;
+                d.n_raw = ld_u32(base + pos + 4);
+                skip = 8ull + d.n_raw;
+                if (skip > avail) st = LZFSE_MI_PAYLOAD_UNDERFLOW;  // raw/block.rs:70-92
+            }
+        } else {
+            st = LZFSE_MI_BAD_BLOCK;
+        }
+        if (st) { w.status = st; w.err_block = w.n_blocks; break; }
+        if (EMIT) {
+            if (w.n_blocks >= max_blocks) break;  // cannot happen: same walk as the count pass
+            blocks[blk_i + w.n_blocks] = d;
+        }
+        w.n_blocks++;
+        w.n_lmds += d.n_lmd; lmd_i += d.n_lmd;
+        w.n_lits += d.n_lit; lit_i += d.n_lit;
+        w.raw_total += d.n_raw;
+        pos += skip;
+    }
+    if (!EMIT) walk[s] = w;
+}
+
+// ------------------------------------------------------------------------------------ FSE stage
+
+// Backward bit reader (bits/bit_reader.rs:11-72) for one wave. The payload is streamed through
+// a 512-byte LDS ring (two 256-byte halves) that all 64 lanes refill with coalesced dword loads
+// ahead of the cursor; the 64-bit window itself lives in registers.
+struct BitWindow {
+    uint64_t acc;
+    int32_t avail;   // accum_bits
+    int64_t pos;     // idx relative to the reader base (the 8 pad bytes)
+    // ring state
+    const uint8_t *gbase;     // address of reader base in global memory
+    const uint8_t *glo, *ghi; // readable range of the source buffer
+    uint32_t *ring;           // 128 dwords in LDS
+    int64_t cb;               // absolute dword index (address / 4) of the lowest dword held
+    uint32_t pend;            // prefetched dword for the half below cb
+    int has_pend;
+};
+
+__device__ __forceinline__ uint32_t bw_gload(const BitWindow &w, int64_t dw) {
+    const uint8_t *a = (const uint8_t *)(uintptr_t)((uint64_t)dw << 2);
+    return (a >= w.glo && a + 4 <= w.ghi) ? *(const uint32_t *)a : 0u;
+}
+
+__device__ __forceinline__ uint64_t bw_window(const BitWindow &w) {
+    if (w.pos < 0) return 0;  // bit_src.rs:36-45
+    uint64_t a = (uint64_t)(uintptr_t)w.gbase + (uint64_t)w.pos;
+    int64_t dw = (int64_t)(a >> 2);
+    uint32_t sh = (uint32_t)(a & 3) * 8;
+    uint32_t d0 = w.ring[(dw) & 127], d1 = w.ring[(dw + 1) & 127], d2 = w.ring[(dw + 2) & 127];
+    uint64_t lo = (uint64_t)d0 | ((uint64_t)d1 << 32);
+    return sh ? ((lo >> sh) | ((uint64_t)d2 << (64 - sh))) : lo;
+}
+
+// init: pos = len - 8 (bit_reader.rs:20-30). Returns BadBitStream per the reference check.
+__device__ inline int bw_init(BitWindow &w, const uint8_t *gbase, uint32_t len, uint32_t off,
+                              const uint8_t *glo, const uint8_t *ghi, uint32_t *ring) {
+    w.gbase = gbase; w.glo = glo; w.ghi = ghi; w.ring = ring;
+    w.pos = (int64_t)len - 8;
+    uint64_t a = (uint64_t)(uintptr_t)gbase + (uint64_t)w.pos;
+    int64_t dw = (int64_t)(a >> 2);
+    w.cb = dw & ~63ll;
+    int l = lane_id();
+    // hold [cb, cb+128); the window needs dw .. dw+2 < cb + 66
+    ring[(w.cb + l) & 127] = bw_gload(w, w.cb + l);
+    ring[(w.cb + 64 + l) & 127] = bw_gload(w, w.cb + 64 + l);
+    w.pend = bw_gload(w, w.cb - 64 + l);
+    w.has_pend = 1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    w.acc = bw_window(w);
+    w.avail = 64 - (int32_t)off;
+    if (off != 0 && (w.acc >> w.avail) != 0) return LZFSE_MI_BAD_BIT_STREAM;
+    return 0;
+}
+
+// flush (bit_reader.rs:39-51) + ring maintenance
+__device__ __forceinline__ void bw_flush(BitWindow &w) {
+    int32_t nbytes = (64 - w.avail) >> 3;
+    w.pos -= nbytes;
+    w.avail += nbytes * 8;
+    uint64_t a = (uint64_t)(uintptr_t)w.gbase + (uint64_t)(w.pos < 0 ? 0 : w.pos);
+    int64_t dw = (int64_t)(a >> 2);
+    if (dw < w.cb + 32) {
+        // cursor is in the lower quarter: drop the upper half, install the prefetched half
+        // [cb-64, cb) and start prefetching the one below it.
+        int l = lane_id();
+        w.ring[(w.cb - 64 + l) & 127] = w.pend;
+        w.cb -= 64;
+        w.pend = bw_gload(w, w.cb - 64 + l);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    w.acc = bw_window(w);
+}
+
+// finalize (bit_reader.rs:64-71)
+__device__ __forceinline__ int bw_finalize(BitWindow &w) {
+    int32_t nbytes = (64 - w.avail) >> 3;
+    int64_t pos = w.pos - nbytes;
+    int32_t avail = w.avail + nbytes * 8;
+    return ((int64_t)avail + pos * 8 < 64) ? LZFSE_MI_PAYLOAD_UNDERFLOW : 0;
+}
+
+constexpr int FSE_THREADS = 128;
+
+// LDS table entry formats
+//   U: k | symbol << 8 | (delta & 0xFFFF) << 16                       (decoder.rs:222-238)
+//   V: .x = k | v_bits << 8 | (delta & 0xFFFF) << 16, .y = v_base     (decoder.rs:205-220)
+__global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
+    const uint8_t *__restrict__ src, uint64_t src_total, const BlockDesc *__restrict__ blocks,
+    uint32_t n_blocks, uint8_t *__restrict__ lit_out, LmdRec *__restrict__ lmd_out,
+    BlockResult *__restrict__ results) {
+    __shared__ uint32_t u_tab[U_STATES];
+    __shared__ uint2 v_tab[L_STATES + M_STATES + D_STATES];
+    __shared__ uint32_t stage[168];   // up to 662 header+weight bytes (v2), dword aligned
+    __shared__ uint16_t wts[N_WEIGHTS];
+    __shared__ uint16_t cum[N_WEIGHTS];
+    __shared__ uint32_t ring[2][128];
+    __shared__ int sh_status[2];
+    __shared__ uint32_t sh_sums[2];
+
+    const uint32_t b = blockIdx.x;
+    if (b >= n_blocks) return;
+    const BlockDesc d = blocks[b];
+    if (d.kind != KIND_VX2 && d.kind != KIND_VX1) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint8_t *p = src + d.src_pos;
+    const uint8_t *glo = src, *ghi = src + ((src_total + 3) & ~3ull);
+
+    FseHeader h;
+    int st = d.kind == KIND_VX1 ? fse_load_v1(p, h) : fse_load_v2(p, h);  // validated by the walk
+    if (st) { if (tid == 0) { results[b].status = st; } return; }
+    if (tid < 2) sh_status[tid] = 0;
+
+    // ---- weights (weights.rs:66-105) ----
+    if (d.kind == KIND_VX2) {
+        uint32_t nw = h.n_weight;
+        for (uint32_t i = tid; i < 168; i += FSE_THREADS) {
+            uint32_t v = 0;
+            for (int k = 0; k < 4; k++) {
+                uint32_t bi = i * 4 + k;
+                if (bi < nw) v |= (uint32_t)p[V2_HEADER_SIZE + bi] << (8 * k);
+            }
+            stage[i] = v;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            // weight_encoder.rs:10-20; zero-padded source makes the refill cadence irrelevant:
+            // total bits T decides under/overflow exactly as accum_bits/i do in the reference.
+            uint64_t accum = 0;
+            int32_t bits = 0;
+            uint32_t wi = 0, total_bits = 0;
+            for (uint32_t k = 0; k < N_WEIGHTS; k++) {
+                if (bits <= 32) {
+                    uint32_t v = wi < 168 ? stage[wi] : 0u;
+                    wi++;
+                    accum |= (uint64_t)v << bits;
+                    bits += 32;
+                }
+                uint32_t a = (uint32_t)accum;
+                uint32_t cto = (~a) ? __builtin_ctz(~a) : 32u;  // trailing ones
+                uint32_t nb, wv;
+                if (cto == 0) { nb = 2; wv = (a >> 1) & 1; }
+                else if (cto == 1) { nb = 3; wv = 2 + ((a >> 2) & 1); }
+                else if (cto == 2) { nb = 5; wv = 4 + ((a >> 3) & 3); }
+                else if (cto == 3) { nb = 8; wv = 8 + ((a >> 4) & 0xF); }
+                else { nb = 14; wv = 24 + ((a >> 4) & 0x3FF); }
+                wts[k] = (uint16_t)wv;
+                accum >>= nb;
+                bits -= (int32_t)nb;
+                total_bits += nb;
+            }
+            int e = 0;
+            if (total_bits > 8 * nw) e = LZFSE_MI_FSE_WEIGHT_PAYLOAD_UNDERFLOW;
+            else if (nw > (total_bits + 7) / 8) e = LZFSE_MI_FSE_WEIGHT_PAYLOAD_OVERFLOW;
+            sh_status[0] = e;
+        }
+    } else {
+        for (uint32_t i = tid; i < N_WEIGHTS; i += FSE_THREADS) wts[i] = ld_u16(p + V1_HEADER_SIZE + 2 * i);
+    }
+    __syncthreads();
+    // ---- cumulative weights + totals check (weights.rs:189-200) ----
+    if (wave == 0) {
+        // lane handles 4 U symbols; lanes also cover L (20), M (20), D (64) tables
+        uint32_t w0 = wts[104 + 4 * lane], w1 = wts[105 + 4 * lane], w2 = wts[106 + 4 * lane], w3 = wts[107 + 4 * lane];
+        uint32_t s4 = w0 + w1 + w2 + w3;
+        uint32_t inc = wave_incl_scan(s4);
+        uint32_t ex = inc - s4;
+        cum[104 + 4 * lane] = (uint16_t)ex;
+        cum[105 + 4 * lane] = (uint16_t)(ex + w0);
+        cum[106 + 4 * lane] = (uint16_t)(ex + w0 + w1);
+        cum[107 + 4 * lane] = (uint16_t)(ex + w0 + w1 + w2);
+        uint32_t tot_u = read_lane(inc, 63);
+        uint32_t wd = wts[40 + lane];
+        uint32_t incd = wave_incl_scan(wd);
+        cum[40 + lane] = (uint16_t)(incd - wd);
+        uint32_t tot_d = read_lane(incd, 63);
+        uint32_t wl = lane < 20 ? wts[lane] : 0u, wm = lane < 20 ? wts[20 + lane] : 0u;
+        uint32_t incl = wave_incl_scan(wl), incm = wave_incl_scan(wm);
+        if (lane < 20) { cum[lane] = (uint16_t)(incl - wl); cum[20 + lane] = (uint16_t)(incm - wm); }
+        uint32_t tot_l = read_lane(incl, 63), tot_m = read_lane(incm, 63);
+        if (lane == 0 && sh_status[0] == 0 &&
+            (tot_l > L_STATES || tot_m > M_STATES || tot_d > D_STATES || tot_u > U_STATES))
+            sh_status[0] = LZFSE_MI_FSE_BAD_WEIGHT_PAYLOAD;
+    }
+    __syncthreads();
+    if (sh_status[0]) { if (tid == 0) results[b].status = sh_status[0]; return; }
+
+    // ---- decode tables (decoder.rs:244-335): per state, binary search the owning symbol ----
+    for (uint32_t t = tid; t < U_STATES; t += FSE_THREADS) {
+        uint32_t lo = 0, hi = 255;  // last i with cum[i] <= t
+        while (lo < hi) {
+            uint32_t mid = (lo + hi + 1) >> 1;
+            if (cum[104 + mid] <= t) lo = mid; else hi = mid - 1;
+        }
+        uint32_t w = wts[104 + lo], j = t - cum[104 + lo];
+        uint32_t e;
+        if (j < w) {
+            uint32_t k = __builtin_clz(w) - 21;  // clz(w) - clz(1024)
+            uint32_t x = (2048u >> k) - w;
+            int32_t delta; uint32_t kk;
+            if (j < x) { kk = k; delta = (int32_t)((w + j) << k) - 1024; }
+            else { kk = k - 1; delta = (int32_t)((j - x) << (k - 1)); }
+            e = kk | (lo << 8) | ((uint32_t)(delta & 0xFFFF) << 16);
+        } else {
+            e = 0u | (0u << 8) | (t << 16);  // latch: k = 0, symbol 0, delta = own index
+        }
+        u_tab[t] = e;
+    }
+    for (uint32_t t = tid; t < L_STATES + M_STATES + D_STATES; t += FSE_THREADS) {
+        uint32_t which = t < 64 ? 0u : (t < 128 ? 1u : 2u);
+        uint32_t tb = which == 0 ? 0u : (which == 1 ? 64u : 128u);
+        uint32_t wb = which == 0 ? 0u : (which == 1 ? 20u : 40u);
+        uint32_t nsym = which == 2 ? 64u : 20u;
+        uint32_t nst = which == 2 ? 256u : 64u;
+        uint32_t clzn = which == 2 ? 23u : 25u;
+        uint32_t ts = t - tb;
+        uint32_t lo = 0, hi = nsym - 1;
+        while (lo < hi) {
+            uint32_t mid = (lo + hi + 1) >> 1;
+            if (cum[wb + mid] <= ts) lo = mid; else hi = mid - 1;
+        }
+        uint32_t w = wts[wb + lo], j = ts - cum[wb + lo];
+        uint2 e;
+        if (j < w) {
+            uint32_t k = __builtin_clz(w) - clzn;
+            uint32_t x = ((2 * nst) >> k) - w;
+            int32_t delta; uint32_t kk;
+            if (j < x) { kk = k; delta = (int32_t)((w + j) << k) - (int32_t)nst; }
+            else { kk = k - 1; delta = (int32_t)((j - x) << (k - 1)); }
+            uint32_t vb = which == 0 ? l_extra_bits(lo) : which == 1 ? m_extra_bits(lo) : d_extra_bits(lo);
+            uint32_t vv = which == 0 ? l_base_value(lo) : which == 1 ? m_base_value(lo) : d_base_value(lo);
+            e.x = kk | (vb << 8) | ((uint32_t)(delta & 0xFFFF) << 16);
+            e.y = vv;
+        } else {
+            e.x = (ts << 16);
+            e.y = 0;
+        }
+        v_tab[t] = e;
+    }
+    __syncthreads();
+
+    // ---- the two bit streams ----
+    const uint32_t lit_off = h.hdr_size - 8;  // fse_core.rs:30-33,59: 8 bytes lent as reader pad
+    const uint32_t lmd_off = h.hdr_size + h.lit_payload;
+    if (wave == 1) {
+        // literals.rs:49-91: four interleaved states in lanes 0..3, shared cursor
+        BitWindow w;
+        int e = bw_init(w, p + lit_off, h.lit_payload + 8, h.lit_bits, glo, ghi, ring[1]);
+        const int q4 = lane & 3;
+        uint32_t state = q4 == 0 ? h.lit_state[0] : q4 == 1 ? h.lit_state[1] : q4 == 2 ? h.lit_state[2] : h.lit_state[3];
+        uint32_t rec = 0;
+        uint8_t *out = lit_out + d.lit_base;
+        const uint32_t n_groups = e ? 0u : h.lit_num >> 2;
+        for (uint32_t g = 0; g < n_groups; g++) {
+            uint32_t ent = u_tab[state];
+            uint32_t k = ent & 0xFF;
+            uint32_t sym = (ent >> 8) & 0xFF;
+            int32_t delta = (int32_t)(int16_t)(ent >> 16);
+            uint32_t pre = k;
+            pre += dpp_shr<1>(pre);
+            pre += dpp_shr<2>(pre);  // inclusive prefix over lanes 0..3
+            uint32_t bits = (uint32_t)(w.acc >> ((w.avail - (int32_t)pre) & 63)) & mask32(k);
+            state = (uint32_t)((int32_t)bits + delta) & 1023u;
+            uint32_t total = read_lane(pre, 3);
+            uint32_t word = sym << (8 * (lane & 3));
+            word |= dpp_shr<1>(word);
+            word |= dpp_shr<2>(word);  // lane 3 holds the four symbols
+            word = read_lane(word, 3);
+            if (lane == (int)(g & 63)) rec = word;
+            if ((g & 63) == 63) ((uint32_t *)out)[(g & ~63u) + lane] = rec;
+            w.avail -= (int32_t)total;
+            bw_flush(w);
+        }
+        if (n_groups & 63) {
+            if (lane < (int)(n_groups & 63)) ((uint32_t *)out)[(n_groups & ~63u) + lane] = rec;
+        }
+        if (!e) e = bw_finalize(w);
+        uint32_t s0 = read_lane(state, 0) | read_lane(state, 1) | read_lane(state, 2) | read_lane(state, 3);
+        if (!e && s0 != 0) e = LZFSE_MI_FSE_BAD_LMD_PAYLOAD;  // literals.rs:78-88
+        if (lane == 0) sh_status[1] = e;
+    } else {
+        // fse_core.rs:91-141 (entropy part): L, M, D in lanes 0, 1, 2
+        BitWindow w;
+        int e = bw_init(w, p + lmd_off, h.lmd_payload, h.lmd_bits, glo, ghi, ring[0]);
+        const int li = lane < 2 ? lane : 2;
+        uint32_t state = li == 0 ? h.lmd_state[0] : li == 1 ? h.lmd_state[1] : h.lmd_state[2];
+        const uint32_t tbase = li == 0 ? 0u : (li == 1 ? 64u : 128u);
+        const uint32_t smask = li == 2 ? 255u : 63u;
+        uint2 rec = make_uint2(0, 0);
+        LmdRec *out = lmd_out + d.lmd_base;
+        uint32_t sum_l = 0, sum_m = 0, prev_d = 0;
+        const uint32_t n = e ? 0u : h.lmd_num;
+        for (uint32_t i = 0; i < n; i++) {
+            uint2 ent = v_tab[tbase + state];
+            uint32_t k = ent.x & 0xFF, vb = (ent.x >> 8) & 0xFF;
+            int32_t delta = (int32_t)(int16_t)(ent.x >> 16);
+            uint32_t nb = k + vb;
+            uint32_t pre = nb;
+            pre += dpp_shr<1>(pre);
+            pre += dpp_shr<2>(pre);
+            uint64_t x = w.acc >> ((w.avail - (int32_t)pre) & 63);
+            uint32_t extra = (uint32_t)x & mask32(vb);
+            uint32_t sb = (uint32_t)(x >> vb) & mask32(k);
+            state = (uint32_t)((int32_t)sb + delta) & smask;
+            uint32_t val = ent.y + extra;
+            uint32_t total = read_lane(pre, 2);
+            uint32_t l = read_lane(val, 0), m = read_lane(val, 1), dd = read_lane(val, 2);
+            if (dd != 0) prev_d = dd;  // lmd_type.rs:153-160
+            sum_l += l;
+            sum_m += m;
+            if (sum_l > LITERALS_PER_BLOCK && !e) e = LZFSE_MI_FSE_BAD_LMD_PAYLOAD;  // fse_core.rs:119-128
+            if (lane == (int)(i & 63)) rec = make_uint2(l | (m << 16), prev_d);
+            if ((i & 63) == 63) out[(i & ~63u) + lane] = rec;
+            w.avail -= (int32_t)total;
+            bw_flush(w);
+        }
+        if (n & 63) {
+            if (lane < (int)(n & 63)) out[(n & ~63u) + lane] = rec;
+        }
+        if (!e) e = bw_finalize(w);
+        uint32_t s0 = read_lane(state, 0) | read_lane(state, 1) | read_lane(state, 2);
+        if (!e && !(sum_l <= h.lit_num && sum_l + sum_m == h.n_raw && s0 == 0))
+            e = LZFSE_MI_FSE_BAD_LMD_PAYLOAD;  // fse_core.rs:132-140
+        if (lane == 0) { sh_status[0] = e; sh_sums[0] = sum_l; sh_sums[1] = sum_m; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        BlockResult r;
+        // literals are loaded before the LMD stream is touched (decoder.rs:127-141)
+        r.status = sh_status[1] ? sh_status[1] : sh_status[0];
+        r.sum_l = sh_sums[0]; r.sum_m = sh_sums[1]; r.pad = 0;
+        results[b] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------ LZ stage
+
+template <int NT>
+__device__ __forceinline__ void block_excl_scan2(uint32_t a, uint32_t b, uint32_t &ea, uint32_t &eb,
+                                                 uint32_t &ta, uint32_t &tb, uint32_t *sh /* 2 * NT/64 + 2 */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NW = NT / 64;
+    uint32_t ia = wave_incl_scan(a), ib = wave_incl_scan(b);
+    if (lane == 63) { sh[wave] = ia; sh[NW + wave] = ib; }
+    __syncthreads();
+    uint32_t oa = 0, ob = 0, sa = 0, sb = 0;
+    for (int w = 0; w < NW; w++) {
+        uint32_t va = sh[w], vb = sh[NW + w];
+        if (w < wave) { oa += va; ob += vb; }
+        sa += va; sb += vb;
+    }
+    ea = oa + ia - a; eb = ob + ib - b; ta = sa; tb = sb;
+    __syncthreads();
+}
+
+// LZVN block decode by one lane (vn/vn_core.rs:134-283); bvxn only occurs in tiny or foreign
+// streams so latency, not throughput, is what matters here.
+__device__ int vn_decode_serial(const uint8_t *p, uint64_t avail, uint32_t n_raw, uint32_t n_payload,
+                                uint8_t *dst, uint64_t &out_pos, uint64_t cap) {
+    uint64_t q = 12;
+    uint32_t match_distance = 0;
+    const uint64_t mark = out_pos;
+    if (avail - q < 8) return LZFSE_MI_PAYLOAD_UNDERFLOW;
+    for (;;) {
+        uint64_t rem = avail - q;
+        const uint8_t *s = p + q;
+        uint32_t opu = ld_u32(s);
+        uint32_t b = opu & 0xFF, hi = b >> 4, lo4 = b & 15, low3 = b & 7;
+        uint32_t l = 0, m = 0, op_len = 0;
+        int kind;  // 0 literal, 1 match(prev d), 2 lmd, 3 nop, 4 eos, 5 udef
+        if (hi == 0xE) { kind = 0; if (lo4 == 0) { l = ((opu >> 8) & 0xFF) + 16; op_len = 2; } else { l = lo4; op_len = 1; } }
+        else if (hi == 0xF) { kind = 1; if (lo4 == 0) { m = ((opu >> 8) & 0xFF) + 16; op_len = 2; } else { m = lo4; op_len = 1; } }
+        else if (hi == 0x7 || hi == 0xD) kind = 5;
+        else if (hi == 0xA || hi == 0xB) {
+            kind = 2; op_len = 3;
+            m = (((opu & 7) << 2) | ((opu >> 8) & 3)) + 3; l = (opu >> 3) & 3;
+            match_distance = (opu >> 10) & 0x3FFF;
+        } else if (low3 == 7) {
+            kind = 2; op_len = 3; m = ((opu >> 3) & 7) + 3; l = (opu >> 6) & 3;
+            match_distance = (opu >> 8) & 0xFFFF;
+        } else if (low3 == 6) {
+            if (b == 0x06) kind = 4;
+            else if (b == 0x0E || b == 0x16) kind = 3;
+            else if (b < 0x40) kind = 5;
+            else { kind = 2; op_len = 1; m = ((opu >> 3) & 7) + 3; l = (opu >> 6) & 3; }
+        } else {
+            kind = 2; op_len = 2; m = ((opu >> 3) & 7) + 3; l = (opu >> 6) & 3;
+            match_distance = ((opu & 7) << 8) | ((opu >> 8) & 0xFF);
+        }
+        if (kind == 5) return LZFSE_MI_VN_BAD_OPCODE;
+        if (kind == 4) {
+            if (ld_u64(s) != 0x06ull) return LZFSE_MI_VN_BAD_PAYLOAD;
+            q += 8;
+            uint64_t consumed = q - 12, produced = out_pos - mark;
+            if (consumed > n_payload) return LZFSE_MI_PAYLOAD_UNDERFLOW;
+            if (produced > n_raw) return LZFSE_MI_VN_BAD_PAYLOAD;
+            if (consumed != n_payload) return LZFSE_MI_PAYLOAD_OVERFLOW;
+            if (produced != n_raw) return LZFSE_MI_VN_BAD_PAYLOAD;
+            return 0;
+        }
+        if (kind == 3) { if (rem - 1 < 8) return LZFSE_MI_PAYLOAD_UNDERFLOW; q += 1; continue; }
+        if (kind == 1) { if (rem - op_len < 8) return LZFSE_MI_PAYLOAD_UNDERFLOW; }
+        else { if (rem - op_len < (uint64_t)l + 8) return LZFSE_MI_PAYLOAD_UNDERFLOW; }
+        if (out_pos + l + m > cap) return LZFSE_MI_BUFFER_OVERFLOW;
+        for (uint32_t t = 0; t < l; t++) dst[out_pos + t] = s[op_len + t];
+        out_pos += l;
+        if (m) {
+            if (match_distance == 0 || match_distance > out_pos) return LZFSE_MI_BAD_D_VALUE;
+            for (uint32_t t = 0; t < m; t++) {
+                dst[out_pos + t] = dst[out_pos + t - match_distance];
+            }
+            out_pos += m;
+        }
+        q += op_len + l;
+    }
+}
+
+constexpr uint32_t SHORT_COPY = 24;  // copies up to this many bytes are done by the owning lane
+
+template <int NT, int TILE>
+__global__ __launch_bounds__(NT) void dec_lz_kernel(
+    const uint8_t *__restrict__ src, const StreamIn *__restrict__ streams, const StreamPlan *__restrict__ plan,
+    const BlockDesc *__restrict__ blocks, const BlockResult *__restrict__ bres,
+    const LmdRec *__restrict__ lmds, const uint8_t *__restrict__ lits, uint8_t *dst_all,
+    StreamResult *__restrict__ sres) {
+    constexpr int NW = NT / 64;
+    __shared__ __attribute__((aligned(16))) uint8_t tile[TILE + 32];
+    __shared__ uint32_t s_off[NT];   // tile-relative output offset of the LMD (literals first)
+    __shared__ uint32_t s_lm[NT];    // l | m << 16
+    __shared__ uint32_t s_d[NT];
+    __shared__ uint32_t s_lit[NT];   // literal offset inside the block's literal buffer
+    __shared__ uint32_t s_dep[NT];   // ordered list of LMD slots whose match reads the tile
+    __shared__ uint32_t s_long[2 * NT];
+    __shared__ uint32_t s_scan[2 * NW + 2];
+    __shared__ uint32_t s_cnt[4];
+    __shared__ int s_status;
+
+    const uint32_t s = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const StreamPlan pl = plan[s];
+    if (pl.skip) return;
+    const StreamIn in = streams[s];
+    uint8_t *dst = dst_all + in.dst_off;
+    uint64_t out_pos = 0;  // bytes produced so far in this stream
+    int status = 0;
+    if (tid == 0) s_status = 0;
+    __syncthreads();
+
+    for (uint32_t bi = 0; bi < pl.n_blocks && !status; bi++) {
+        const BlockDesc d = blocks[pl.blk_base + bi];
+        if (d.kind == KIND_RAW) {
+            // raw/block.rs:70-92
+            if (out_pos + d.n_raw > in.dst_cap) { status = LZFSE_MI_BUFFER_OVERFLOW; break; }
+            const uint8_t *p = src + d.src_pos + 8;
+            for (uint32_t i = tid; i < d.n_raw; i += NT) dst[out_pos + i] = p[i];
+            out_pos += d.n_raw;
+            __syncthreads();
+            continue;
+        }
+        if (d.kind == KIND_VXN) {
+            __syncthreads();
+            if (tid == 0) {
+                uint64_t op = out_pos;
+                int e = vn_decode_serial(src + d.src_pos, d.src_end - d.src_pos, d.n_raw, d.payload, dst, op, in.dst_cap);
+                s_status = e;
+                s_cnt[0] = (uint32_t)(op - out_pos);
+            }
+            __syncthreads();
+            status = s_status;
+            out_pos += s_cnt[0];
+            __syncthreads();
+            continue;
+        }
+        const BlockResult br = bres[pl.blk_base + bi];
+        if (br.status) { status = br.status; break; }
+        if (out_pos + d.n_raw > in.dst_cap) { status = LZFSE_MI_BUFFER_OVERFLOW; break; }
+        const LmdRec *bl = lmds + d.lmd_base;
+        const uint8_t *blit = lits + d.lit_base;
+        uint32_t lit_run = 0;
+        for (uint32_t g0 = 0; g0 < d.n_lmd && !status;) {
+            const uint32_t idx = g0 + tid;
+            const bool valid = idx < d.n_lmd;
+            LmdRec r = valid ? bl[idx] : make_uint2(0, 0);
+            uint32_t l = r.x & 0xFFFF, m = r.x >> 16, dd = r.y;
+            uint32_t span = l + m;
+            uint32_t ex_l, ex_s, tot_l, tot_s;
+            block_excl_scan2<NT>(l, span, ex_l, ex_s, tot_l, tot_s, s_scan);
+            // participants: the longest prefix of LMDs whose output fits the tile
+            const bool part = valid && (ex_s + span <= (uint32_t)TILE);
+            if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; s_cnt[2] = 0; s_cnt[3] = 0; }
+            __syncthreads();
+            unsigned long long pb = __ballot(part);
+            if (lane == 0 && pb) atomicAdd(&s_cnt[0], (uint32_t)__popcll(pb));
+            __syncthreads();
+            const uint32_t cnt = s_cnt[0];
+            // tile length = exclusive sum at slot cnt (or total if everyone participates)
+            if (tid == (int)cnt - 1) s_cnt[1] = ex_s + span;
+            __syncthreads();
+            const uint32_t tile_len = s_cnt[1];
+            const uint64_t tile_base = out_pos;                       // stream-relative
+            const uint32_t pad = (uint32_t)((uintptr_t)(dst + tile_base) & 15);  // LDS/global co-alignment
+            uint8_t *t = tile + pad;
+
+            // ---- classify + short copies by the owning lane ----
+            const uint64_t p_match = tile_base + ex_s + l;  // stream-relative position of the match
+            bool bad_d = part && m != 0 && (dd == 0 || (uint64_t)dd > p_match);  // lz/writer.rs:156-178
+            bool dep = false, far_long = false, lit_long = false;
+            if (part && !bad_d) {
+                s_off[tid] = ex_s; s_lm[tid] = r.x; s_d[tid] = dd; s_lit[tid] = lit_run + ex_l;
+                if (l) {
+                    if (l <= SHORT_COPY) {
+                        const uint8_t *ls = blit + lit_run + ex_l;
+                        for (uint32_t k = 0; k < l; k++) t[ex_s + k] = ls[k];
+                    } else lit_long = true;
+                }
+                if (m) {
+                    // source [p - d, p - d + min(m, d)) ; far when it ends at or before the tile
+                    uint32_t slen = m < dd ? m : dd;
+                    if (dd >= m && p_match - dd + slen <= tile_base) {
+                        if (m <= SHORT_COPY) {
+                            const uint8_t *ms = dst + (p_match - dd);
+                            for (uint32_t k = 0; k < m; k++) t[ex_s + l + k] = ms[k];
+                        } else far_long = true;
+                    } else dep = true;
+                }
+            }
+            // ordered compaction of dependent matches and of long copies
+            unsigned long long bb = __ballot(bad_d);
+            if (bb && lane == 0) atomicOr((int *)&s_status, LZFSE_MI_BAD_D_VALUE);
+            uint32_t nl = (lit_long ? 1u : 0u) + (far_long ? 1u : 0u);
+            uint32_t ex_dep, ex_long, tot_dep, tot_long;
+            block_excl_scan2<NT>(dep ? 1u : 0u, nl, ex_dep, ex_long, tot_dep, tot_long, s_scan);
+            if (dep) s_dep[ex_dep] = tid;
+            if (lit_long) s_long[ex_long++] = tid * 2;
+            if (far_long) s_long[ex_long] = tid * 2 + 1;
+            __syncthreads();
+            if (s_status) { status = s_status; break; }
+            // ---- long copies: one wave per segment, 64 bytes per step ----
+            for (uint32_t q = wave; q < tot_long; q += NW) {
+                uint32_t e = s_long[q], slot = e >> 1;
+                uint32_t o = s_off[slot], lm = s_lm[slot];
+                uint32_t ll = lm & 0xFFFF, mm = lm >> 16;
+                if (e & 1) {
+                    const uint8_t *ms = dst + (tile_base + o + ll - s_d[slot]);
+                    for (uint32_t k = lane; k < mm; k += 64) t[o + ll + k] = ms[k];
+                } else {
+                    const uint8_t *ls = blit + s_lit[slot];
+                    for (uint32_t k = lane; k < ll; k += 64) t[o + k] = ls[k];
+                }
+            }
+            __syncthreads();
+            // ---- dependent matches: in order, one wave, LDS-resident (lz/object.rs:27-74 semantics:
+            //      out[p + k] = out[p + k - d], overlap allowed) ----
+            if (wave == 0) {
+                for (uint32_t q = 0; q < tot_dep; q++) {
+                    uint32_t slot = s_dep[q];
+                    uint32_t o = s_off[slot], lm = s_lm[slot], ddq = s_d[slot];
+                    uint32_t ll = lm & 0xFFFF, mm = lm >> 16;
+                    uint32_t mo = o + ll;                      // tile offset of the match
+                    int64_t so = (int64_t)mo - (int64_t)ddq;   // tile offset of the source (may be < 0)
+                    for (uint32_t c = 0; c < mm; c += 64) {
+                        uint32_t k = c + lane;
+                        if (k < mm) {
+                            uint32_t kk = ddq < 64 ? k % ddq : k;
+                            int64_t sp = so + kk;
+                            uint8_t v = sp >= 0 ? t[sp] : dst[(int64_t)tile_base + sp];
+                            t[mo + k] = v;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- write the tile back: head bytes, 16-byte body, tail bytes ----
+            {
+                uint8_t *g = dst + tile_base;
+                uint32_t head = pad ? (16 - pad) : 0;
+                if (head > tile_len) head = tile_len;
+                uint32_t body = (tile_len - head) & ~15u;
+                if (tid < (int)head) g[tid] = t[tid];
+                const uint4 *ts = (const uint4 *)(t + head);
+                uint4 *gd = (uint4 *)(g + head);
+                for (uint32_t k = tid; k < body / 16; k += NT) gd[k] = ts[k];
+                uint32_t tail0 = head + body;
+                if (tail0 + tid < tile_len && tid < 16) g[tail0 + tid] = t[tail0 + tid];
+            }
+            out_pos += tile_len;
+            // lit_run advances by the literals of the participants only
+            if (tid == (int)cnt - 1) s_cnt[2] = ex_l + l;
+            __syncthreads();
+            lit_run += s_cnt[2];
+            g0 += cnt;
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        StreamResult r;
+        r.out_len = out_pos; r.status = status; r.pad = 0;
+        sres[s] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------ launchers
+
+void launch_dec_walk(bool emit, const uint8_t *src, const StreamIn *streams, uint32_t n_streams,
+                     StreamWalk *walk, const StreamPlan *plan, BlockDesc *blocks, hipStream_t st) {
+    dim3 grid((n_streams + 63) / 64), block(64);
+    if (emit) hipLaunchKernelGGL(dec_walk_kernel<true>, grid, block, 0, st, src, streams, n_streams, walk, plan, blocks);
+    else hipLaunchKernelGGL(dec_walk_kernel<false>, grid, block, 0, st, src, streams, n_streams, walk, plan, blocks);
+}
+
+void launch_dec_fse(const uint8_t *src, uint64_t src_total, const BlockDesc *blocks, uint32_t n_blocks,
+                    uint8_t *lit_out, LmdRec *lmd_out, BlockResult *results, hipStream_t st) {
+    if (!n_blocks) return;
+    hipLaunchKernelGGL(dec_fse_kernel, dim3(n_blocks), dim3(FSE_THREADS), 0, st, src, src_total, blocks,
+                       n_blocks, lit_out, lmd_out, results);
+}
+
+void launch_dec_lz(int variant, const uint8_t *src, const StreamIn *streams, const StreamPlan *plan,
+                   uint32_t n_streams, const BlockDesc *blocks, const BlockResult *bres, const LmdRec *lmds,
+                   const uint8_t *lits, uint8_t *dst, StreamResult *sres, hipStream_t st) {
+    if (!n_streams) return;
+    if (variant == 0)
+        hipLaunchKernelGGL((dec_lz_kernel<256, 16384>), dim3(n_streams), dim3(256), 0, st, src, streams, plan,
+                           blocks, bres, lmds, lits, dst, sres);
+    else
+        hipLaunchKernelGGL((dec_lz_kernel<1024, 49152>), dim3(n_streams), dim3(1024), 0, st, src, streams, plan,
+                           blocks, bres, lmds, lits, dst, sres);
+}
+
+}  // namespace lzmi

@@ -1,0 +1,38 @@
+// Internal (non-ABI) declarations shared by api.hip, decode.hip and encode.hip.
+#pragma once
+#include "common.h"
+
+struct lzfse_mi_ctx;
+
+namespace lzmi {
+
+// brackets kernel launches with HIP events on the context's stream (lzfse_mi_get_timings)
+struct StageTimer {
+    lzfse_mi_ctx *ctx;
+    int idx = -1;
+    StageTimer(lzfse_mi_ctx *c, const char *name);
+    ~StageTimer();
+};
+hipStream_t ctx_stream(lzfse_mi_ctx *c);
+
+// ---- decode.hip ----
+void launch_dec_walk(bool emit, const uint8_t *src, const StreamIn *streams, uint32_t n_streams,
+                     StreamWalk *walk, const StreamPlan *plan, BlockDesc *blocks, hipStream_t st);
+void launch_dec_fse(const uint8_t *src, uint64_t src_total, const BlockDesc *blocks, uint32_t n_blocks,
+                    uint8_t *lit_out, LmdRec *lmd_out, BlockResult *results, hipStream_t st);
+void launch_dec_lz(int variant, const uint8_t *src, const StreamIn *streams, const StreamPlan *plan,
+                   uint32_t n_streams, const BlockDesc *blocks, const BlockResult *bres, const LmdRec *lmds,
+                   const uint8_t *lits, uint8_t *dst, StreamResult *sres, hipStream_t st);
+
+// ---- encode.hip ----
+struct EncScratch {
+    void *bufs[16] = {};
+    size_t caps[16] = {};
+};
+EncScratch &ctx_enc(lzfse_mi_ctx *c);
+void enc_scratch_release(EncScratch &s);
+int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, const uint64_t *src_off,
+                     const uint64_t *src_len, uint8_t *d_dst, const uint64_t *dst_off, const uint64_t *dst_cap,
+                     uint64_t *out_lens, int *statuses);
+
+}  // namespace lzmi

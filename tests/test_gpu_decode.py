@@ -1,0 +1,104 @@
+"""GPU parity tests (decode): HIP path through the C ABI vs the oracle and the reference's fixtures."""
+import glob
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle_py import rng_gen_vec, seq_masked
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import lzfse_rust_amd as m
+    return m.Context(0)
+
+
+def _fixture_files(golden):
+    fs = []
+    for sub in ("snappy", "special", "mutate"):
+        fs += sorted(glob.glob(os.path.join(golden, sub, "*.lzfse")))
+    return [f for f in fs if not f.endswith("null.vx2.lzfse")]
+
+
+def test_decode_fixtures_batch(ctx, oracle, golden_dir):
+    """test/src/data.rs:33-100: every fixture, SHA-256 of decoded bytes, all block types."""
+    fs = _fixture_files(golden_dir)
+    srcs = [open(f, "rb").read() for f in fs]
+    outs, st = ctx.decode_batch(srcs)
+    for f, s, o, e in zip(fs, srcs, outs, st):
+        assert e == 0, (f, e)
+        assert hashlib.sha256(o.tobytes()).digest() == open(f[:-6] + ".hash", "rb").read(), f
+        assert o.tobytes() == oracle.decode(s), f
+
+
+def test_decode_single_api(ctx, golden_dir):
+    import lzfse_rust_amd as m
+    dec = m.LzfseDecoder(context=ctx)
+    dst = bytearray(b"keep")
+    n = dec.decode_bytes(open(os.path.join(golden_dir, "snappy", "alice29.txt.lzfse"), "rb").read(), dst)
+    assert n == 152089 and dst[:4] == b"keep" and len(dst) == 4 + n
+
+
+def test_decode_oracle_streams(ctx, oracle, snappy_raw):
+    """Streams produced by the oracle encoder (10 000-LMD blocks, unlike Apple's 9 992)."""
+    raws = list(snappy_raw.values())
+    raws.append(seq_masked(3, 0x01010101, 1 << 20))
+    raws.append(rng_gen_vec(7, 300000))
+    raws.append(bytes(500000))
+    raws.append(b"abc" * 100000)
+    raws.append(bytes(range(256)) * 2000)
+    raws += [bytes(n) for n in (0, 1, 20, 21, 4096, 4097)]
+    raws += [rng_gen_vec(n, n) for n in (5, 100, 4096, 4097, 40001)]
+    encs = [oracle.encode(r) for r in raws]
+    outs, st = ctx.decode_batch(encs)
+    for r, o, e in zip(raws, outs, st):
+        assert e == 0
+        assert o.tobytes() == r
+
+
+def test_decode_many_streams_both_lz_variants(ctx, oracle, snappy_raw):
+    encs = [oracle.encode(r) for r in snappy_raw.values()] * 50
+    raws = list(snappy_raw.values()) * 50
+    for variant in ("0", "1"):
+        os.environ["LZFSE_MI_LZ_VARIANT"] = variant
+        try:
+            outs, st = ctx.decode_batch(encs)
+        finally:
+            del os.environ["LZFSE_MI_LZ_VARIANT"]
+        assert all(e == 0 for e in st)
+        for r, o in zip(raws, outs):
+            assert o.tobytes() == r
+
+
+def test_decode_errors_match_oracle(ctx, oracle, golden_dir, snappy_raw):
+    """Every malformed input must give Err on both sides (never crash / hang): mutate_0.rs."""
+    base = bytearray(open(os.path.join(golden_dir, "mutate", "vx2.lzfse"), "rb").read())
+    cases = []
+    rng = np.random.default_rng(11)
+    for i in rng.choice(len(base), size=300, replace=False):
+        m = bytearray(base)
+        m[i] ^= 1 << int(rng.integers(0, 8))
+        cases.append(bytes(m))
+    enc = oracle.encode(snappy_raw["html"])
+    cases += [enc[:-1], enc[:-4], enc[:-5], enc + b"\0", b"abcd" + enc, enc[:100], b"", b"bvx"]
+    e2 = bytearray(enc)
+    n = int.from_bytes(e2[4:8], "little")
+    e2[4:8] = (n + 1).to_bytes(4, "little")
+    cases.append(bytes(e2))
+    outs, st = ctx.decode_batch(cases, caps=[1 << 20] * len(cases))
+    for c, o, e in zip(cases, outs, st):
+        es = oracle.decode_status(c, 1 << 20)
+        assert (e == 0) == (es == 0), (e, es)
+        if e == 0:
+            assert o.tobytes() == oracle.decode(c, cap=1 << 20)
+    assert st[-1] == 22  # BadLmdPayload for n_raw_bytes + 1 (fse/test.rs:434,458)
+
+
+def test_decode_capacity_too_small(ctx, oracle, snappy_raw):
+    enc = oracle.encode(snappy_raw["html"])
+    outs, st = ctx.decode_batch([enc], caps=[1000])
+    assert st[0] == 6
