@@ -1,7 +1,892 @@
-// Encode side (placeholder until the kernels land): reports LZFSE_MI_UNSUPPORTED.
+// Encode side of the MI355X LZFSE codec: hand-written HIP kernels for gfx950 (wave64).
+//
+// The reference's encoder is a serial greedy/lazy parse over a 4-way, 2^14-bucket history
+// table (encode/frontend_bytes.rs:160-268, encode/history.rs:15-118). Its table state before
+// position i is a pure function of src[0..i+3] because every position is inserted exactly once,
+// in order (frontend_bytes.rs:187,336-344). That makes the expensive part position-parallel:
+//
+//   enc_chain_kernel   per 64 Ki-position tile: prev[i] = previous position in the same bucket
+//                      (history.rs:221-224 hash, fse/object.rs:38-43), exact, in-order, with a
+//                      16 384-entry last-seen table in LDS and ballot matching inside a wave
+//   enc_link_kernel    first occurrences of a tile: link to earlier tiles (window 262 139)
+//   enc_cand_kernel    per position: walk <= 4 chain entries newest->oldest with the reference's
+//                      gates (frontend_bytes.rs:214-231), forward LCP (match_kit/match_fast.rs:
+//                      22-49) and un-gated backward LCS (:61-89), both capped
+//   enc_walk_kernel    the true serial recurrence, one wave per stream: Match::select lazy arbiter
+//                      (match_object.rs:12-33), literal_index, sync skip, LMD emission and bvx2
+//                      block segmentation (fse/buffer.rs:45-131, fse/backend.rs:76-96)
+//   enc_block_kernel   per bvx2 block: literal gather, histograms, normalize_m1 (weights.rs:
+//                      218-278), weight bytes (weight_encoder.rs:23-37), E tables (encoder.rs:
+//                      219-240), reverse FSE of literals / LMDs (literals.rs:93-133, lmds.rs:
+//                      62-93), header (block.rs:168-196)
+//   enc_pack_kernel    stream assembly: blocks back to back + bvx$ (frontend_bytes.rs:50-61)
+#include <algorithm>
+#include <vector>
+
 #include "internal.h"
 
+struct lzfse_mi_ctx;
+
 namespace lzmi {
+
+constexpr uint32_t TILE_POS = 65536;        // positions per chain tile
+constexpr uint32_t NONE = 0xFFFFFFFFu;      // no previous position
+constexpr uint32_t NONE_TILE = 0xFFFFFFFEu; // no previous position inside the tile (link pending)
+constexpr uint32_t FCAP = 1024;             // cap of the forward length computed per position
+constexpr uint32_t BCAP = 255;              // cap of the backward length computed per position
+constexpr uint32_t REC_CAPPED = 0x80000000u;
+
+__device__ __forceinline__ int e_lane() { return threadIdx.x & 63; }
+__device__ __forceinline__ uint32_t e_readlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ uint32_t bucket_of(uint32_t v) { return (v * 0x9E3779B1u) >> (32 - HASH_BITS); }
+
+struct EncStream {       // one input stream (n > VN_CUTOFF) of the batch
+    uint64_t src_off;    // offset of the stream in d_src
+    uint64_t pos_base;   // offset of the stream in the per-position arrays (prev, rec)
+    uint64_t dst_off, dst_cap;
+    uint64_t lmd_base;   // offset into the LMD array
+    uint64_t stage_base; // offset into the block staging area
+    uint64_t stage_cap;
+    uint32_t n;          // stream length
+    uint32_t tile_base;  // index of the stream's first tile
+    uint32_t blk_base;   // index of the stream's first block slot
+    uint32_t blk_cap;    // number of block slots
+    uint32_t lmd_cap;
+    uint32_t user_index; // index in the caller's arrays
+};
+
+struct EncTile {
+    uint32_t stream;
+    uint32_t first;      // 1 if this is the first tile of its stream
+    uint32_t start;      // first position of the tile (stream relative)
+    uint32_t pad;
+};
+
+struct EncBlock {        // one bvx2 block (written by the walk kernel)
+    uint64_t lmd_start;  // index into the LMD array
+    uint64_t stage_off;  // staging offset of this block's bytes
+    uint32_t src_start;  // first raw byte of the block (stream relative)
+    uint32_t n_lmd, n_lit, n_match;
+    // filled by the block kernel
+    uint32_t hdr_len, lit_len, lmd_len, pad;
+};
+
+struct EncStreamOut {
+    uint32_t n_blocks;
+    int32_t status;
+    uint64_t out_len;
+};
+
+// staging layout of one block: [header + weights | literal payload | lmd payload]
+__host__ __device__ inline uint32_t stage_lit_off() { return 704; }
+__host__ __device__ inline uint32_t stage_lmd_off(uint32_t n_lit) { return 704 + ((((n_lit + 3) / 4 * 4) * 10 + 7) / 8 + 24 + 15) / 16 * 16; }
+__host__ __device__ inline uint32_t stage_need(uint32_t n_lit, uint32_t n_lmd) {
+    return stage_lmd_off(n_lit) + ((8 + (n_lmd * 54 + 7) / 8 + 24 + 15) / 16 * 16);
+}
+
+// ------------------------------------------------------------------------------------ chains
+
+// One wave per tile. Positions are processed in order, 64 per step; the nearest previous
+// position with the same bucket is either a lower lane of the same step (found with 14 ballots)
+// or the LDS last-seen entry written by earlier steps.
+__global__ __launch_bounds__(64) void enc_chain_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
+                                                       const EncTile *__restrict__ tiles, uint32_t n_tiles,
+                                                       uint32_t *__restrict__ prev, uint32_t *__restrict__ summary) {
+    __shared__ uint16_t last[1u << HASH_BITS];  // offset in tile + 1, 0 = none
+    const uint32_t t = blockIdx.x;
+    if (t >= n_tiles) return;
+    const EncTile tl = tiles[t];
+    const EncStream st = streams[tl.stream];
+    const int lane = e_lane();
+    for (uint32_t k = lane; k < (1u << HASH_BITS); k += 64) last[k] = 0;
+    const uint8_t *s = src + st.src_off;
+    uint32_t *pv = prev + st.pos_base;
+    const uint32_t n_pos = st.n - 3;  // positions 0 .. n-4 are hashed (frontend_bytes.rs:166-170)
+    const uint32_t t_end = tl.start + TILE_POS < n_pos ? tl.start + TILE_POS : n_pos;
+    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t p0 = tl.start;
+    uint32_t v_next = (p0 + lane < t_end) ? ld_u32(s + p0 + lane) : 0u;
+    for (; p0 < t_end; p0 += 64) {
+        const uint32_t p = p0 + lane;
+        const bool valid = p < t_end;
+        const uint32_t v = v_next;
+        if (p0 + 64 < t_end) v_next = (p + 64 < t_end) ? ld_u32(s + p + 64) : 0u;
+        const uint32_t key = bucket_of(v);
+        const uint32_t old = last[key];
+        uint64_t same = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < (int)HASH_BITS; b++) {
+            uint64_t bb = __ballot((key >> b) & 1);
+            same &= ((key >> b) & 1) ? bb : ~bb;
+        }
+        const uint64_t lower = same & lt_mask;
+        uint32_t pr;
+        if (lower) pr = p0 + (63 - __builtin_clzll(lower));
+        else pr = old ? (tl.start + old - 1) : NONE_TILE;
+        if (valid) {
+            pv[p] = pr;
+            if ((same >> lane) >> 1 == 0) last[key] = (uint16_t)(p - tl.start + 1);  // newest of its bucket
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    uint32_t *sm = summary + (uint64_t)t * (1u << HASH_BITS);
+    for (uint32_t k = lane; k < (1u << HASH_BITS); k += 64) {
+        uint32_t o = last[k];
+        sm[k] = o ? tl.start + o - 1 : NONE;
+    }
+}
+
+// Cross-tile links: a bucket's first occurrence in a tile points at the newest occurrence in an
+// earlier tile of the same stream. Anything further back than 5 tiles is outside the
+// 262 139-byte window (fse/constants.rs:42) and would end the candidate scan anyway.
+__global__ void enc_link_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
+                                const EncTile *__restrict__ tiles, uint32_t n_tiles, uint32_t *__restrict__ prev,
+                                const uint32_t *__restrict__ summary) {
+    const uint32_t t = blockIdx.y;
+    const EncTile tl = tiles[t];
+    const EncStream st = streams[tl.stream];
+    const uint32_t p = tl.start + blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_pos = st.n - 3;
+    if (p >= n_pos || p >= tl.start + TILE_POS) return;
+    uint32_t *pv = prev + st.pos_base;
+    if (pv[p] != NONE_TILE) return;
+    const uint32_t key = bucket_of(ld_u32(src + st.src_off + p));
+    uint32_t r = NONE;
+    const uint32_t t_idx = tl.start / TILE_POS;  // tile index inside the stream
+    for (uint32_t back = 1; back <= 5 && back <= t_idx; back++) {
+        uint32_t sv = summary[(uint64_t)(t - back) * (1u << HASH_BITS) + key];
+        if (sv != NONE) { r = sv; break; }
+    }
+    pv[p] = r;
+}
+
+// ------------------------------------------------------------------------------------ candidates
+
+// forward common length of src[a..] and src[b..] (b < a), starting at `len`, bounded by max
+__device__ __forceinline__ uint32_t lcp_fwd(const uint8_t *s, uint32_t a, uint32_t b, uint32_t len, uint32_t max) {
+    while (len + 8 <= max) {
+        uint64_t x = ld_u64(s + a + len) ^ ld_u64(s + b + len);
+        if (x) return len + (uint32_t)(__builtin_ctzll(x) >> 3);
+        len += 8;
+    }
+    while (len < max && s[a + len] == s[b + len]) len++;
+    return len;
+}
+
+// common suffix length of src[..a) and src[..b) (b < a), bounded by max (<= b)
+__device__ __forceinline__ uint32_t lcs_bwd(const uint8_t *s, uint32_t a, uint32_t b, uint32_t max) {
+    uint32_t len = 0;
+    while (len + 8 <= max) {
+        uint64_t x = ld_u64(s + a - len - 8) ^ ld_u64(s + b - len - 8);
+        if (x) return len + (uint32_t)(__builtin_clzll(x) >> 3);
+        len += 8;
+    }
+    while (len < max && s[a - len - 1] == s[b - len - 1]) len++;
+    return len;
+}
+
+// rec[i] = { dist | bwd << 18 | capped << 31 , fwd_len }  ; fwd_len == 0: no match at i
+__global__ void enc_cand_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
+                                const EncTile *__restrict__ tiles, const uint32_t *__restrict__ prev,
+                                uint2 *__restrict__ rec) {
+    const uint32_t t = blockIdx.y;
+    const EncTile tl = tiles[t];
+    const EncStream st = streams[tl.stream];
+    const uint32_t i = tl.start + blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = st.n, n_pos = n - 3;
+    if (i >= n_pos || i >= tl.start + TILE_POS) return;
+    const uint8_t *s = src + st.src_off;
+    const uint32_t *pv = prev + st.pos_base;
+    const uint32_t v = ld_u32(s + i);
+    const uint32_t max_total = n - i;
+    const uint32_t cap_total = max_total < FCAP ? max_total : FCAP;
+    uint32_t best_len = 0, best_idx = 0;
+    bool capped = false;
+    uint32_t c = pv[i];
+#pragma unroll 1
+    for (int k = 0; k < 4 && c != NONE; k++) {
+        uint32_t dist = i - c;
+        if (dist > MAX_D_VALUE) break;  // frontend_bytes.rs:222-224: stop, not skip
+        if (ld_u32(s + c) == v) {
+            uint32_t len = lcp_fwd(s, i, c, 4, cap_total);
+            if (len == cap_total && cap_total < max_total) capped = true;
+            if (len > best_len) { best_len = len; best_idx = c; }  // ties keep the newest (:226)
+        }
+        c = pv[c];
+    }
+    uint2 r = make_uint2(0, 0);
+    if (best_len) {
+        uint32_t bmax = best_idx < BCAP ? best_idx : BCAP;
+        uint32_t bw = lcs_bwd(s, i, best_idx, bmax);
+        r.x = (i - best_idx) | (bw << 18) | (capped ? REC_CAPPED : 0u);
+        r.y = best_len;
+    }
+    rec[st.pos_base + i] = r;
+}
+
+// ------------------------------------------------------------------------------------ walk
+
+struct Walker {
+    // stream
+    const uint8_t *s;
+    const uint32_t *pv;
+    const uint2 *rec;
+    uint32_t n, end;
+    // parse state (frontend_bytes.rs:25-32)
+    uint32_t literal_index;
+    uint32_t p_idx, p_midx, p_len;  // pending
+    // backend state (fse/buffer.rs:16-23)
+    uint32_t n_lmd, n_lit, n_match, prev_d;
+    uint32_t blk_src_start;
+    // outputs
+    uint2 *lmds;        // stream's LMD array
+    uint32_t lmd_cap;
+    uint32_t lmd_count; // LMDs written so far (stream)
+    uint32_t blk_lmd_start;
+    EncBlock *blocks;
+    uint32_t blk_cap, blk_count;
+    uint64_t lmd_base, stage_base, stage_cap, stage_used;
+    uint2 stash;        // lane k holds LMD (lmd_count & ~63) + k until flushed
+    int status;
+};
+
+__device__ __forceinline__ void wk_put_lmd(Walker &w, uint32_t l, uint32_t m, uint32_t d) {
+    // fse/buffer.rs:106-117 (push_lmd) / :99-104 (push_l, which passes d = 1 already "seen")
+    const int lane = e_lane();
+    if (w.lmd_count >= w.lmd_cap) { w.status = LZFSE_MI_IO; return; }
+    if (lane == (int)(w.lmd_count & 63)) w.stash = make_uint2(l | (m << 16), d);
+    w.lmd_count++;
+    if ((w.lmd_count & 63) == 0) w.lmds[w.lmd_count - 64 + lane] = w.stash;
+    w.n_lmd++;
+}
+
+__device__ __forceinline__ void wk_flush_stash(Walker &w) {
+    const int lane = e_lane();
+    uint32_t rem = w.lmd_count & 63;
+    if (rem && lane < (int)rem) w.lmds[(w.lmd_count & ~63u) + lane] = w.stash;
+}
+
+__device__ __forceinline__ void wk_push_l(Walker &w, uint32_t l) {
+    w.prev_d = 1;
+    wk_put_lmd(w, l, 0, 1);
+}
+
+__device__ __forceinline__ void wk_push_lmd(Walker &w, uint32_t l, uint32_t m, uint32_t d) {
+    uint32_t ds = (w.prev_d == d) ? 0u : d;
+    w.prev_d = d;
+    wk_put_lmd(w, l, m, ds);
+    w.n_match += m;
+}
+
+// fse/backend.rs:39-54 bookkeeping part of emit_block_v2 + buffer.rs:119-125 reset
+__device__ __forceinline__ void wk_close_block(Walker &w) {
+    if (w.blk_count >= w.blk_cap) { w.status = LZFSE_MI_IO; return; }
+    uint32_t need = stage_need(w.n_lit, w.n_lmd);
+    if (w.stage_used + need > w.stage_cap) { w.status = LZFSE_MI_IO; return; }
+    if (e_lane() == 0) {
+        EncBlock b;
+        b.lmd_start = w.lmd_base + w.blk_lmd_start;
+        b.stage_off = w.stage_base + w.stage_used;
+        b.src_start = w.blk_src_start;
+        b.n_lmd = w.n_lmd; b.n_lit = w.n_lit; b.n_match = w.n_match;
+        b.hdr_len = 0; b.lit_len = 0; b.lmd_len = 0; b.pad = 0;
+        w.blocks[w.blk_count] = b;
+    }
+    w.stage_used += need;
+    w.blk_count++;
+    w.blk_src_start += w.n_lit + w.n_match;
+    w.blk_lmd_start = w.lmd_count;
+    w.n_lmd = 0; w.n_lit = 0; w.n_match = 0; w.prev_d = 0;
+}
+
+// fse/buffer.rs:45-97; returns false when the block is full (caller closes it and retries)
+__device__ __forceinline__ bool wk_buffer_push(Walker &w, uint32_t &n_lit, uint32_t &match_len, uint32_t d) {
+    while (n_lit > MAX_L_VALUE) {
+        if (w.n_lmd == LMDS_PER_BLOCK) return false;
+        uint32_t limit = LITERALS_PER_BLOCK - w.n_lit;
+        if (MAX_L_VALUE <= limit) {
+            w.n_lit += MAX_L_VALUE; n_lit -= MAX_L_VALUE;
+            wk_push_l(w, MAX_L_VALUE);
+        } else if (limit != 0) {
+            w.n_lit += limit; n_lit -= limit;
+            wk_push_l(w, limit);
+            return false;
+        } else return false;
+    }
+    if (w.n_lmd == LMDS_PER_BLOCK) return false;
+    uint32_t literal_len = n_lit;
+    uint32_t limit = LITERALS_PER_BLOCK - w.n_lit;
+    if (literal_len <= limit) {
+        w.n_lit += literal_len; n_lit = 0;
+    } else if (limit != 0) {
+        w.n_lit += limit; n_lit -= limit;
+        wk_push_l(w, limit);
+        return false;
+    } else return false;
+    while (match_len > MAX_M_VALUE) {
+        wk_push_lmd(w, literal_len, MAX_M_VALUE, d);
+        match_len -= MAX_M_VALUE;
+        literal_len = 0;
+        if (w.n_lmd == LMDS_PER_BLOCK) return false;
+    }
+    wk_push_lmd(w, literal_len, match_len, d);
+    match_len = 0;
+    return true;
+}
+
+// fse/backend.rs:76-90 with frontend_bytes.rs:287-302
+__device__ __forceinline__ void wk_push_match(Walker &w, uint32_t idx, uint32_t len, uint32_t dist) {
+    uint32_t n_lit = idx - w.literal_index;
+    w.literal_index = idx + len;
+    uint32_t m = len;
+    for (;;) {
+        if (wk_buffer_push(w, n_lit, m, dist)) break;
+        wk_close_block(w);
+        if (w.status) return;
+    }
+}
+
+// exact forward length by the whole wave (used when a per-position length hit FCAP)
+__device__ uint32_t wave_lcp_fwd(const uint8_t *s, uint32_t a, uint32_t b, uint32_t len, uint32_t max) {
+    const int lane = e_lane();
+    while (len < max) {
+        uint32_t off = len + 8 * lane;
+        uint64_t x = 0;
+        if (off + 8 <= max) x = ld_u64(s + a + off) ^ ld_u64(s + b + off);
+        else
+            for (uint32_t k = 0; off + k < max && k < 8; k++)
+                x |= (uint64_t)(s[a + off + k] ^ s[b + off + k]) << (8 * k);
+        uint64_t bad = __ballot(x != 0);
+        if (bad) {
+            int bl = __builtin_ctzll(bad);
+            uint32_t xl = e_readlane((uint32_t)x, bl), xh = e_readlane((uint32_t)(x >> 32), bl);
+            uint64_t xx = (uint64_t)xl | ((uint64_t)xh << 32);
+            uint32_t r = len + 8 * bl + (uint32_t)(__builtin_ctzll(xx) >> 3);
+            return r < max ? r : max;
+        }
+        len += 512;
+    }
+    return max;
+}
+
+__device__ uint32_t wave_lcs_bwd(const uint8_t *s, uint32_t a, uint32_t b, uint32_t max) {
+    const int lane = e_lane();
+    uint32_t len = 0;
+    while (len < max) {
+        uint32_t off = len + lane;
+        bool bad = off < max && s[a - off - 1] != s[b - off - 1];
+        uint64_t bm = __ballot(bad);
+        if (bm) {
+            uint32_t r = len + __builtin_ctzll(bm);
+            return r < max ? r : max;
+        }
+        len += 64;
+    }
+    return max;
+}
+
+// One wave per stream. All lanes execute the same (uniform) control flow; lanes only differ when
+// they prefetch records, stash LMDs or help with an exact length.
+__global__ __launch_bounds__(64) void enc_walk_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
+                                                      uint32_t n_streams, const uint32_t *__restrict__ prev,
+                                                      const uint2 *__restrict__ rec, uint2 *__restrict__ lmds,
+                                                      EncBlock *__restrict__ blocks, EncStreamOut *__restrict__ outs) {
+    const uint32_t si = blockIdx.x;
+    if (si >= n_streams) return;
+    const EncStream st = streams[si];
+    const int lane = e_lane();
+    Walker w;
+    w.s = src + st.src_off;
+    w.pv = prev + st.pos_base;
+    w.rec = rec + st.pos_base;
+    w.n = st.n; w.end = st.n - 3;
+    w.literal_index = 0; w.p_idx = 0; w.p_midx = 0; w.p_len = 0;
+    w.n_lmd = 0; w.n_lit = 0; w.n_match = 0; w.prev_d = 0; w.blk_src_start = 0;
+    w.lmds = lmds + st.lmd_base; w.lmd_cap = st.lmd_cap; w.lmd_count = 0; w.blk_lmd_start = 0;
+    w.blocks = blocks + st.blk_base; w.blk_cap = st.blk_cap; w.blk_count = 0;
+    w.lmd_base = st.lmd_base; w.stage_base = st.stage_base; w.stage_cap = st.stage_cap; w.stage_used = 0;
+    w.stash = make_uint2(0, 0);
+    w.status = 0;
+
+    // record window: lane k of `cur` holds rec[cbase + k]; `nxt` holds rec[cbase + 64 + k]
+    uint32_t cbase = 0;
+    uint2 cur = (cbase + lane < w.end) ? w.rec[cbase + lane] : make_uint2(0, 0);
+    uint2 nxt = (cbase + 64 + lane < w.end) ? w.rec[cbase + 64 + lane] : make_uint2(0, 0);
+    uint32_t index = 0;
+    while (index < w.end && !w.status) {
+        // bring `index` into the current window
+        if (index >= cbase + 64) {
+            if (index < cbase + 128) { cbase += 64; cur = nxt; }
+            else { cbase = index & ~63u; cur = (cbase + lane < w.end) ? w.rec[cbase + lane] : make_uint2(0, 0); }
+            nxt = (cbase + 64 + lane < w.end) ? w.rec[cbase + 64 + lane] : make_uint2(0, 0);
+        }
+        // skip positions without an incoming match: select() returns None for them (match_object.rs:14)
+        uint64_t have = __ballot(cur.y != 0) & (~0ull << (index - cbase));
+        if (!have) { index = cbase + 64; continue; }
+        const int k = __builtin_ctzll(have);
+        index = cbase + k;
+        if (index >= w.end) break;
+        uint32_t rx = e_readlane(cur.x, k), fwd = e_readlane(cur.y, k);
+        uint32_t dist = rx & 0x3FFFF, bw = (rx >> 18) & 0xFF;
+        uint32_t midx = index - dist;
+        if (rx & REC_CAPPED) {
+            // exact re-evaluation of find_match's forward part (frontend_bytes.rs:214-231)
+            uint32_t v = ld_u32(w.s + index);
+            uint32_t best_len = 0, best_idx = 0;
+            uint32_t c = w.pv[index];
+            for (int q = 0; q < 4 && c != NONE; q++) {
+                if (index - c > MAX_D_VALUE) break;
+                if (ld_u32(w.s + c) == v) {
+                    uint32_t len = wave_lcp_fwd(w.s, index, c, 4, w.n - index);
+                    if (len > best_len) { best_len = len; best_idx = c; }
+                }
+                c = w.pv[c];
+            }
+            fwd = best_len; midx = best_idx; dist = index - midx;
+            uint32_t bmax = midx < BCAP ? midx : BCAP;
+            bw = wave_lcs_bwd(w.s, index, midx, bmax);
+        }
+        // backward extension gate (frontend_bytes.rs:259-268): min(literal_len, match_index)
+        uint32_t room = index - w.literal_index;
+        uint32_t b = bw < room ? bw : room;
+        if (bw == BCAP && room > BCAP && midx > BCAP) {
+            uint32_t bmax = room < midx ? room : midx;
+            b = wave_lcs_bwd(w.s, index, midx, bmax);
+        }
+        const uint32_t i_idx = index - b, i_midx = midx - b, i_len = fwd + b;
+        // Match::select::<40> (match_object.rs:12-33)
+        bool emit = false;
+        uint32_t e_idx = 0, e_midx = 0, e_len = 0;
+        if (i_len >= GOOD_MATCH_LEN) {
+            emit = true; e_idx = i_idx; e_midx = i_midx; e_len = i_len; w.p_len = 0;
+        } else if (w.p_len == 0) {
+            w.p_idx = i_idx; w.p_midx = i_midx; w.p_len = i_len;
+        } else if (w.p_idx + w.p_len <= i_idx) {
+            emit = true; e_idx = w.p_idx; e_midx = w.p_midx; e_len = w.p_len;
+            w.p_idx = i_idx; w.p_midx = i_midx; w.p_len = i_len;
+        } else if (i_len > w.p_len) {
+            emit = true; e_idx = i_idx; e_midx = i_midx; e_len = i_len; w.p_len = 0;
+        } else {
+            emit = true; e_idx = w.p_idx; e_midx = w.p_midx; e_len = w.p_len; w.p_len = 0;
+        }
+        if (emit) {
+            wk_push_match(w, e_idx, e_len, e_idx - e_midx);
+            if (w.literal_index >= w.end) break;
+            index += 1;
+            if (index < w.literal_index) index = w.literal_index;  // sync_history: skipped positions
+        } else {
+            index += 1;
+        }
+    }
+    if (!w.status) {
+        // flush_pending (frontend_bytes.rs:271-285)
+        if (w.p_len != 0) { wk_push_match(w, w.p_idx, w.p_len, w.p_idx - w.p_midx); w.p_len = 0; }
+    }
+    if (!w.status) {
+        // flush_literals -> push_literals == push_match(literals, 0, D = 1) (fse/backend.rs:67-73)
+        uint32_t len = w.n - w.literal_index;
+        if (len) wk_push_match(w, w.n, 0, 1);
+    }
+    if (!w.status) wk_close_block(w);  // finalize (fse/backend.rs:92-95)
+    wk_flush_stash(w);
+    if (lane == 0) {
+        EncStreamOut o;
+        o.n_blocks = w.blk_count; o.status = w.status; o.out_len = 0;
+        outs[si] = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------ block encode
+
+constexpr int BLK_THREADS = 256;
+
+__device__ __forceinline__ uint32_t l_sym_of(uint32_t v) { return v < 16 ? v : 16u + (v >= 20) + (v >= 28) + (v >= 60); }
+__device__ __forceinline__ uint32_t m_sym_of(uint32_t v) { return v < 16 ? v : 16u + (v >= 24) + (v >= 56) + (v >= 312); }
+// fse/constants.rs:323-353: largest symbol whose base <= v; base(4q) = 4 (2^q - 1)
+__device__ __forceinline__ uint32_t d_sym_of(uint32_t v) {
+    uint32_t q = (31 - __builtin_clz(v + 4)) - 2;
+    uint32_t r = (v - 4u * ((1u << q) - 1u)) >> q;
+    return 4 * q + r;
+}
+
+// weights.rs:218-278 (normalize_m1), run by one lane over a table in LDS
+__device__ void normalize_m1(uint16_t *w, uint32_t n, uint32_t in_total, uint32_t out_total) {
+    if (in_total == 0) return;
+    uint32_t shift = __builtin_clz(out_total);
+    uint32_t multiply = (1u << 31) / in_total;
+    uint32_t round = 1u << (shift - 1);
+    uint32_t max_weight = 0, max_index = 0;
+    int32_t remaining = (int32_t)out_total;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t wi = w[i];
+        if (wi == 0) continue;
+        uint32_t f = (wi * multiply + round) >> shift;
+        if (f == 0) f = 1;
+        w[i] = (uint16_t)f;
+        remaining -= (int32_t)f;
+        if (f > max_weight) { max_weight = f; max_index = i; }
+    }
+    if (-remaining < (int32_t)w[max_index] / 4) {
+        w[max_index] = (uint16_t)((int32_t)w[max_index] + remaining);
+    } else {
+        uint32_t overflow = (uint32_t)(-remaining);
+        for (int s = 3; s >= 0; s--)
+            for (uint32_t i = 0; i < n; i++) {
+                if (overflow == 0) break;
+                uint32_t wi = w[i];
+                if (wi == 0) continue;
+                uint32_t k = (wi - 1) >> s;
+                if (k > overflow) k = overflow;
+                w[i] = (uint16_t)(wi - k);
+                overflow -= k;
+            }
+    }
+}
+
+template <int DELTA>
+__device__ __forceinline__ uint32_t e_dpp_shr(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + DELTA, 0xF, 0xF, true);
+}
+
+// forward bit writer of one wave (bits/bit_writer.rs:8-58): lane contributions are OR-combined
+struct BitOut {
+    uint64_t acc;
+    uint32_t fill;
+    uint8_t *out;
+    uint32_t pos;
+};
+
+__device__ __forceinline__ void bo_flush(BitOut &o) {
+    uint32_t nbytes = o.fill >> 3;
+    if (e_lane() == 0) __builtin_memcpy(o.out + o.pos, &o.acc, 8);  // staging has >= 8 spare bytes
+    o.pos += nbytes;
+    o.acc = nbytes == 8 ? 0 : o.acc >> (nbytes * 8);
+    o.fill &= 7;
+}
+
+__device__ __forceinline__ uint32_t bo_finalize(BitOut &o) {
+    uint32_t nbytes = (o.fill + 7) >> 3;
+    if (e_lane() == 0) __builtin_memcpy(o.out + o.pos, &o.acc, 8);
+    o.pos += nbytes;
+    return nbytes * 8 - o.fill;
+}
+
+__global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
+                                                                uint32_t n_streams, const EncStreamOut *__restrict__ outs,
+                                                                const uint2 *__restrict__ lmds, EncBlock *__restrict__ blocks,
+                                                                const uint32_t *__restrict__ slot_stream, uint8_t *__restrict__ stage) {
+    __shared__ __attribute__((aligned(16))) uint8_t lit[LITERALS_PER_BLOCK + 16];
+    __shared__ uint32_t hist[N_WEIGHTS];
+    __shared__ uint16_t wts[N_WEIGHTS];
+    __shared__ uint32_t etab[N_WEIGHTS];      // t_k (low 16) | t_w (high 16), encoder.rs:184-188
+    __shared__ uint32_t wbits[N_WEIGHTS / 4 * 4 + 200];  // weight payload words (<= 630 bytes)
+    __shared__ uint32_t scan_sh[2 * (BLK_THREADS / 64) + 2];
+    __shared__ uint32_t sh_misc[16];
+
+    const uint32_t slot = blockIdx.x;
+    const uint32_t si = slot_stream[slot];
+    if (si >= n_streams) return;
+    const EncStream st = streams[si];
+    const uint32_t bi = slot - st.blk_base;
+    const EncStreamOut so = outs[si];
+    if (so.status || bi >= so.n_blocks) return;
+    EncBlock blk = blocks[slot];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint8_t *s = src + st.src_off;
+    const uint2 *bl = lmds + blk.lmd_start;
+    uint8_t *sg = stage + blk.stage_off;
+
+    for (uint32_t i = tid; i < N_WEIGHTS; i += BLK_THREADS) hist[i] = 0;
+    for (uint32_t i = tid; i < sizeof(wbits) / 4; i += BLK_THREADS) wbits[i] = 0;
+    __syncthreads();
+
+    // ---- literal gather + LMD symbol histograms ----
+    {
+        uint32_t run_lit = 0, run_src = blk.src_start;
+        for (uint32_t g0 = 0; g0 < blk.n_lmd; g0 += BLK_THREADS) {
+            uint32_t idx = g0 + tid;
+            bool valid = idx < blk.n_lmd;
+            uint2 r = valid ? bl[idx] : make_uint2(0, 0);
+            uint32_t l = r.x & 0xFFFF, m = r.x >> 16, d = r.y;
+            // block exclusive scan of l and l + m
+            uint32_t il = l, is = l + m;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                uint32_t a = __shfl_up(il, dd), b2 = __shfl_up(is, dd);
+                if (lane >= dd) { il += a; is += b2; }
+            }
+            if (lane == 63) { scan_sh[wave] = il; scan_sh[BLK_THREADS / 64 + wave] = is; }
+            __syncthreads();
+            uint32_t ol = 0, os = 0, tl = 0, ts = 0;
+            for (int wv = 0; wv < BLK_THREADS / 64; wv++) {
+                uint32_t a = scan_sh[wv], b2 = scan_sh[BLK_THREADS / 64 + wv];
+                if (wv < wave) { ol += a; os += b2; }
+                tl += a; ts += b2;
+            }
+            uint32_t ex_l = ol + il - l, ex_s = os + is - (l + m);
+            if (valid) {
+                const uint8_t *ls = s + run_src + ex_s;
+                uint8_t *ld = lit + run_lit + ex_l;
+                for (uint32_t k = 0; k < l; k++) ld[k] = ls[k];
+                atomicAdd(&hist[l_sym_of(l)], 1u);
+                atomicAdd(&hist[20 + m_sym_of(m)], 1u);
+                atomicAdd(&hist[40 + d_sym_of(d)], 1u);
+            }
+            run_lit += tl; run_src += ts;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    // literals.rs:136-145 pad with literals[0]; weights.rs:56-64 literal histogram (unpadded)
+    const uint32_t n_lit = blk.n_lit, n4 = (n_lit + 3) / 4 * 4;
+    if (tid < 4) lit[n_lit + tid] = n_lit ? lit[0] : 0;
+    for (uint32_t i = tid; i < n_lit; i += BLK_THREADS) atomicAdd(&hist[104 + lit[i]], 1u);
+    __syncthreads();
+    for (uint32_t i = tid; i < N_WEIGHTS; i += BLK_THREADS) wts[i] = (uint16_t)hist[i];
+    __syncthreads();
+    // ---- normalize (one lane per table) ----
+    if (tid == 0 && blk.n_lmd) normalize_m1(wts, 20, blk.n_lmd, L_STATES);
+    if (tid == 64 && blk.n_lmd) normalize_m1(wts + 20, 20, blk.n_lmd, M_STATES);
+    if (tid == 128 && blk.n_lmd) normalize_m1(wts + 40, 64, blk.n_lmd, D_STATES);
+    if (tid == 192 && n_lit) normalize_m1(wts + 104, 256, n_lit, U_STATES);
+    __syncthreads();
+    // ---- weight payload (weight_encoder.rs:23-37, weights.rs:139-163) + E tables (encoder.rs:219-240) ----
+    if (wave == 0) {
+        uint32_t carry_bits = 0;
+        for (uint32_t g0 = 0; g0 < N_WEIGHTS; g0 += 64) {
+            uint32_t k = g0 + lane;
+            uint32_t wv = k < N_WEIGHTS ? wts[k] : 0, code = 0, nb = 0;
+            if (k < N_WEIGHTS) {
+                switch (wv) {
+                case 0: code = 0; nb = 2; break;
+                case 1: code = 2; nb = 2; break;
+                case 2: code = 1; nb = 3; break;
+                case 3: code = 5; nb = 3; break;
+                case 4: code = 3; nb = 5; break;
+                case 5: code = 11; nb = 5; break;
+                case 6: code = 19; nb = 5; break;
+                case 7: code = 27; nb = 5; break;
+                default:
+                    if (wv < 24) { code = ((wv - 8) << 4) + 7; nb = 8; }
+                    else { code = ((wv - 24) << 4) + 15; nb = 14; }
+                }
+            }
+            uint32_t inc = nb;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) { uint32_t a = __shfl_up(inc, dd); if (lane >= dd) inc += a; }
+            uint32_t bitpos = carry_bits + inc - nb;
+            if (nb) {
+                uint64_t v64 = (uint64_t)code << (bitpos & 31);
+                atomicOr(&wbits[bitpos >> 5], (uint32_t)v64);
+                if (v64 >> 32) atomicOr(&wbits[(bitpos >> 5) + 1], (uint32_t)(v64 >> 32));
+            }
+            carry_bits += e_readlane(inc, 63);
+        }
+        if (lane == 0) sh_misc[0] = (carry_bits + 7) / 8;  // n_weight_payload_bytes
+    }
+    if (wave == 1 || wave == 2 || wave == 3) {
+        // E tables: wave 1 -> U (256), wave 2 -> D (64), wave 3 -> L and M (20 each)
+        if (wave == 1) {
+            uint32_t w0 = wts[104 + 4 * lane], w1 = wts[105 + 4 * lane], w2 = wts[106 + 4 * lane], w3 = wts[107 + 4 * lane];
+            uint32_t s4 = w0 + w1 + w2 + w3, inc = s4;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) { uint32_t a = __shfl_up(inc, dd); if (lane >= dd) inc += a; }
+            uint32_t tot = inc - s4;
+            uint32_t ws[4] = {w0, w1, w2, w3};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t wv = ws[q];
+                int32_t tk, tw;
+                if (wv == 0) { tk = -(int32_t)U_STATES; tw = 0; }
+                else { int k = __builtin_clz(wv) - 21; tk = 1024 * k - (int32_t)(wv << k); tw = (int32_t)U_STATES + (int32_t)tot - (int32_t)wv; }
+                etab[104 + 4 * lane + q] = ((uint32_t)tk & 0xFFFF) | ((uint32_t)tw << 16);
+                tot += wv;
+            }
+        } else if (wave == 2) {
+            uint32_t wv = wts[40 + lane], inc = wv;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) { uint32_t a = __shfl_up(inc, dd); if (lane >= dd) inc += a; }
+            uint32_t tot = inc - wv;
+            int32_t tk, tw;
+            if (wv == 0) { tk = -(int32_t)D_STATES; tw = 0; }
+            else { int k = __builtin_clz(wv) - 23; tk = 1024 * k - (int32_t)(wv << k); tw = (int32_t)D_STATES + (int32_t)tot - (int32_t)wv; }
+            etab[40 + lane] = ((uint32_t)tk & 0xFFFF) | ((uint32_t)tw << 16);
+        } else {
+            // lanes 0..19 -> L, lanes 32..51 -> M
+            bool isl = lane < 20, ism = lane >= 32 && lane < 52;
+            uint32_t wv = isl ? wts[lane] : (ism ? wts[20 + lane - 32] : 0), inc = wv;
+#pragma unroll
+            for (int dd = 1; dd < 32; dd <<= 1) { uint32_t a = __shfl_up(inc, dd); if ((lane & 31) >= dd) inc += a; }
+            uint32_t tot = inc - wv;
+            if (isl || ism) {
+                int32_t tk, tw;
+                if (wv == 0) { tk = -64; tw = 0; }
+                else { int k = __builtin_clz(wv) - 25; tk = 1024 * k - (int32_t)(wv << k); tw = 64 + (int32_t)tot - (int32_t)wv; }
+                etab[isl ? lane : 20 + lane - 32] = ((uint32_t)tk & 0xFFFF) | ((uint32_t)tw << 16);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t n_wbytes = sh_misc[0];
+    // weight bytes -> staging after the 32-byte header
+    for (uint32_t i = tid; i < n_wbytes; i += BLK_THREADS) sg[V2_HEADER_SIZE + i] = (uint8_t)(wbits[i >> 2] >> (8 * (i & 3)));
+
+    // ---- the two reverse FSE streams ----
+    if (wave == 0) {
+        // literals.rs:93-133: lane r carries state (3 - r); emission order state3, 2, 1, 0
+        BitOut o; o.acc = 0; o.fill = 0; o.out = sg + stage_lit_off(); o.pos = 0;
+        uint32_t state = U_STATES;
+        const int r = lane & 3;
+        for (uint32_t i = n4; i != 0; i -= 4) {
+            uint32_t sym = lit[i - 1 - r];
+            uint32_t e = etab[104 + sym];
+            int32_t tk = (int32_t)(int16_t)(e & 0xFFFF), tw = (int32_t)(int16_t)(e >> 16);
+            uint32_t nb = (uint32_t)(tk + (int32_t)state) >> 10;
+            uint32_t bits = state & ((1u << nb) - 1u);
+            state = (uint32_t)(tw + (int32_t)(state >> nb));
+            uint32_t pre = nb;
+            pre += e_dpp_shr<1>(pre);
+            pre += e_dpp_shr<2>(pre);  // inclusive over lanes 0..3
+            uint64_t c = (uint64_t)bits << (o.fill + pre - nb);
+            uint32_t clo = (uint32_t)c, chi = (uint32_t)(c >> 32);
+            clo |= e_dpp_shr<1>(clo); chi |= e_dpp_shr<1>(chi);
+            clo |= e_dpp_shr<2>(clo); chi |= e_dpp_shr<2>(chi);
+            o.acc |= (uint64_t)e_readlane(clo, 3) | ((uint64_t)e_readlane(chi, 3) << 32);
+            o.fill += e_readlane(pre, 3);
+            bo_flush(o);
+        }
+        uint32_t unused = bo_finalize(o);
+        if (lane == 0) {
+            sh_misc[1] = o.pos;      // literal payload bytes
+            sh_misc[2] = unused;     // literal bits
+        }
+        // state of lane r belongs to state index 3 - r
+        uint32_t s3 = e_readlane(state, 0), s2 = e_readlane(state, 1), s1 = e_readlane(state, 2), s0 = e_readlane(state, 3);
+        if (lane == 0) { sh_misc[3] = s0 - U_STATES; sh_misc[4] = s1 - U_STATES; sh_misc[5] = s2 - U_STATES; sh_misc[6] = s3 - U_STATES; }
+    } else if (wave == 1) {
+        // lmds.rs:62-93: 8 zero bytes, then LMDs in reverse; per LMD: D, M, L (extra bits then state bits)
+        uint8_t *lo = sg + stage_lmd_off(n_lit);
+        if (lane < 8) lo[lane] = 0;
+        BitOut o; o.acc = 0; o.fill = 0; o.out = lo + 8; o.pos = 0;
+        const int li = lane < 2 ? lane : 2;  // 0 = D, 1 = M, 2 = L
+        uint32_t state = li == 0 ? D_STATES : 64u;
+        const uint32_t tb = li == 0 ? 40u : (li == 1 ? 20u : 0u);
+        uint2 chunk = make_uint2(0, 0);
+        for (uint32_t i = blk.n_lmd; i != 0; i--) {
+            const uint32_t idx = i - 1;
+            if ((idx & 63) == 63 || i == blk.n_lmd) {
+                uint32_t cb = idx & ~63u;
+                chunk = (cb + lane < blk.n_lmd) ? bl[cb + lane] : make_uint2(0, 0);
+            }
+            uint32_t rx = e_readlane(chunk.x, idx & 63), ry = e_readlane(chunk.y, idx & 63);
+            uint32_t v = li == 0 ? ry : (li == 1 ? (rx >> 16) : (rx & 0xFFFF));
+            uint32_t sym = li == 0 ? d_sym_of(v) : (li == 1 ? m_sym_of(v) : l_sym_of(v));
+            uint32_t nx = li == 0 ? d_extra_bits(sym) : (li == 1 ? m_extra_bits(sym) : l_extra_bits(sym));
+            uint32_t bv = li == 0 ? d_base_value(sym) : (li == 1 ? m_base_value(sym) : l_base_value(sym));
+            uint32_t e = etab[tb + sym];
+            int32_t tk = (int32_t)(int16_t)(e & 0xFFFF), tw = (int32_t)(int16_t)(e >> 16);
+            uint32_t nb = (uint32_t)(tk + (int32_t)state) >> 10;
+            uint32_t sbits = state & ((1u << nb) - 1u);
+            state = (uint32_t)(tw + (int32_t)(state >> nb));
+            uint32_t width = nx + nb;
+            uint64_t field = (uint64_t)(v - bv) | ((uint64_t)sbits << nx);
+            uint32_t pre = width;
+            pre += e_dpp_shr<1>(pre);
+            pre += e_dpp_shr<2>(pre);  // inclusive over lanes 0..2
+            uint64_t c = field << (o.fill + pre - width);
+            uint32_t clo = (uint32_t)c, chi = (uint32_t)(c >> 32);
+            if (lane > 2) { clo = 0; chi = 0; }
+            clo |= e_dpp_shr<1>(clo); chi |= e_dpp_shr<1>(chi);
+            clo |= e_dpp_shr<2>(clo); chi |= e_dpp_shr<2>(chi);
+            o.acc |= (uint64_t)e_readlane(clo, 2) | ((uint64_t)e_readlane(chi, 2) << 32);
+            o.fill += e_readlane(pre, 2);
+            bo_flush(o);
+        }
+        uint32_t unused = bo_finalize(o);
+        uint32_t sd = e_readlane(state, 0), sm = e_readlane(state, 1), sl = e_readlane(state, 2);
+        if (lane == 0) {
+            sh_misc[7] = o.pos + 8;  // lmd payload bytes (pad included, lmds.rs:67-69,91)
+            sh_misc[8] = unused;
+            sh_misc[9] = sl - L_STATES; sh_misc[10] = sm - M_STATES; sh_misc[11] = sd - D_STATES;
+        }
+    }
+    __syncthreads();
+    // ---- header (block.rs:168-196) ----
+    if (tid == 0) {
+        uint32_t lit_payload = sh_misc[1], lmd_payload = sh_misc[7];
+        uint64_t p;
+        uint32_t magic = MAGIC_VX2, n_raw = blk.n_lit + blk.n_match;
+        __builtin_memcpy(sg, &magic, 4);
+        __builtin_memcpy(sg + 4, &n_raw, 4);
+        p = (uint64_t)n4 | ((uint64_t)lit_payload << 20) | ((uint64_t)blk.n_lmd << 40) | ((uint64_t)(7 - sh_misc[2]) << 60);
+        __builtin_memcpy(sg + 8, &p, 8);
+        p = (uint64_t)sh_misc[3] | ((uint64_t)sh_misc[4] << 10) | ((uint64_t)sh_misc[5] << 20) | ((uint64_t)sh_misc[6] << 30) |
+            ((uint64_t)lmd_payload << 40) | ((uint64_t)(7 - sh_misc[8]) << 60);
+        __builtin_memcpy(sg + 16, &p, 8);
+        p = (uint64_t)(V2_HEADER_SIZE + n_wbytes) | ((uint64_t)sh_misc[9] << 32) | ((uint64_t)sh_misc[10] << 42) |
+            ((uint64_t)sh_misc[11] << 52);
+        __builtin_memcpy(sg + 24, &p, 8);
+        blocks[slot].hdr_len = V2_HEADER_SIZE + n_wbytes;
+        blocks[slot].lit_len = lit_payload;
+        blocks[slot].lmd_len = lmd_payload;
+    }
+}
+
+// ------------------------------------------------------------------------------------ pack
+
+// One workgroup per stream: concatenates the blocks' three staged segments and appends bvx$.
+__global__ __launch_bounds__(256) void enc_pack_kernel(const EncStream *__restrict__ streams, uint32_t n_streams,
+                                                       const EncBlock *__restrict__ blocks, const uint8_t *__restrict__ stage,
+                                                       uint8_t *__restrict__ dst, EncStreamOut *__restrict__ outs) {
+    const uint32_t si = blockIdx.x;
+    if (si >= n_streams) return;
+    const EncStream st = streams[si];
+    EncStreamOut so = outs[si];
+    if (so.status) return;
+    const int tid = threadIdx.x;
+    uint8_t *d = dst + st.dst_off;
+    uint64_t pos = 0;
+    bool overflow = false;
+    for (uint32_t b = 0; b < so.n_blocks; b++) {
+        const EncBlock blk = blocks[st.blk_base + b];
+        const uint8_t *sg = stage + blk.stage_off;
+        uint64_t need = (uint64_t)blk.hdr_len + blk.lit_len + blk.lmd_len;
+        if (pos + need + 4 > st.dst_cap) { overflow = true; break; }
+        for (uint32_t i = tid; i < blk.hdr_len; i += 256) d[pos + i] = sg[i];
+        pos += blk.hdr_len;
+        const uint8_t *ls = sg + stage_lit_off();
+        for (uint32_t i = tid; i < blk.lit_len; i += 256) d[pos + i] = ls[i];
+        pos += blk.lit_len;
+        const uint8_t *ms = sg + stage_lmd_off(blk.n_lit);
+        for (uint32_t i = tid; i < blk.lmd_len; i += 256) d[pos + i] = ms[i];
+        pos += blk.lmd_len;
+    }
+    if (!overflow && pos + 4 > st.dst_cap) overflow = true;
+    if (!overflow && tid < 4) d[pos + tid] = (uint8_t)(MAGIC_EOS >> (8 * tid));
+    if (tid == 0) {
+        so.status = overflow ? LZFSE_MI_BUFFER_OVERFLOW : 0;
+        so.out_len = overflow ? 0 : pos + 4;
+        outs[si] = so;
+    }
+}
+
+// ------------------------------------------------------------------------------------ host side
+
+enum { EB_STREAMS, EB_TILES, EB_PREV, EB_SUMMARY, EB_REC, EB_LMDS, EB_BLOCKS, EB_OUTS, EB_STAGE, EB_SLOTS, EB_N };
+
+static bool eb_ensure(EncScratch &s, int i, size_t n) {
+    if (n <= s.caps[i]) return true;
+    if (s.bufs[i]) (void)hipFree(s.bufs[i]);
+    s.bufs[i] = nullptr;
+    s.caps[i] = 0;
+    size_t nc = n + n / 8 + 4096;
+    if (hipMalloc(&s.bufs[i], nc) != hipSuccess) return false;
+    s.caps[i] = nc;
+    return true;
+}
 
 void enc_scratch_release(EncScratch &s) {
     for (int i = 0; i < 16; i++) {
@@ -11,13 +896,146 @@ void enc_scratch_release(EncScratch &s) {
     }
 }
 
-int enc_batch_device(lzfse_mi_ctx *, uint32_t count, const uint8_t *, const uint64_t *, const uint64_t *, uint8_t *,
-                     const uint64_t *, const uint64_t *, uint64_t *out_lens, int *statuses) {
+#define E_TRY(x) do { if ((x) != hipSuccess) return LZFSE_MI_IO; } while (0)
+
+int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, const uint64_t *src_off,
+                     const uint64_t *src_len, uint8_t *d_dst, const uint64_t *dst_off, const uint64_t *dst_cap,
+                     uint64_t *out_lens, int *statuses) {
+    hipStream_t stq = ctx_stream(c);
+    EncScratch &S = ctx_enc(c);
+    std::vector<EncStream> hs;
+    std::vector<EncTile> ht;
+    std::vector<uint32_t> hslots;
+    uint64_t pos_total = 0, lmd_total = 0, stage_total = 0;
+    uint32_t blk_total = 0;
     for (uint32_t i = 0; i < count; i++) {
         out_lens[i] = 0;
-        statuses[i] = LZFSE_MI_UNSUPPORTED;
+        statuses[i] = LZFSE_MI_OK;
+        uint64_t n = src_len[i];
+        if (n <= VN_CUTOFF) { statuses[i] = LZFSE_MI_UNSUPPORTED; continue; }  // host-side size classes (frontend_bytes.rs:63-77)
+        if (n > 0x7FFFFFFFull) { statuses[i] = LZFSE_MI_UNSUPPORTED; continue; }  // reposition path (:348-375) not built
+        EncStream e;
+        e.src_off = src_off[i]; e.pos_base = pos_total; e.dst_off = dst_off[i]; e.dst_cap = dst_cap[i];
+        e.n = (uint32_t)n; e.user_index = i;
+        e.tile_base = (uint32_t)ht.size();
+        uint32_t n_pos = e.n - 3;
+        for (uint32_t p = 0; p < n_pos; p += TILE_POS) ht.push_back({(uint32_t)hs.size(), p == 0 ? 1u : 0u, p, 0u});
+        e.blk_base = blk_total;
+        e.blk_cap = e.n / 39000 + 2;
+        e.lmd_base = lmd_total;
+        e.lmd_cap = e.n / 4 + e.n / 256 + 2 * e.blk_cap + 64;
+        e.lmd_cap = (e.lmd_cap + 63) & ~63u;
+        e.stage_base = stage_total;
+        e.stage_cap = (uint64_t)e.n + e.n / 2 + e.n / 4 + (uint64_t)e.blk_cap * 1024 + 4096;
+        e.stage_cap = (e.stage_cap + 255) & ~255ull;
+        for (uint32_t b = 0; b < e.blk_cap; b++) hslots.push_back((uint32_t)hs.size());
+        blk_total += e.blk_cap;
+        pos_total += ((uint64_t)e.n + 255) & ~255ull;
+        lmd_total += e.lmd_cap;
+        stage_total += e.stage_cap;
+        hs.push_back(e);
+    }
+    const uint32_t ns = (uint32_t)hs.size(), nt = (uint32_t)ht.size();
+    if (ns == 0) return LZFSE_MI_OK;
+    // longest streams first: the serial walk of the longest stream bounds the batch
+    std::vector<uint32_t> order(ns);
+    for (uint32_t i = 0; i < ns; i++) order[i] = i;
+    // (walk kernel indexes streams directly; reorder the stream array itself)
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hs[a].n > hs[b].n; });
+    std::vector<EncStream> hs2(ns);
+    std::vector<uint32_t> inv(ns);
+    for (uint32_t i = 0; i < ns; i++) { hs2[i] = hs[order[i]]; inv[order[i]] = i; }
+    for (auto &t : ht) t.stream = inv[t.stream];
+    for (auto &sl : hslots) sl = inv[sl];
+    hs.swap(hs2);
+
+    if (!eb_ensure(S, EB_STREAMS, ns * sizeof(EncStream)) || !eb_ensure(S, EB_TILES, nt * sizeof(EncTile)) ||
+        !eb_ensure(S, EB_PREV, pos_total * 4) || !eb_ensure(S, EB_SUMMARY, (size_t)nt * (1u << HASH_BITS) * 4) ||
+        !eb_ensure(S, EB_REC, pos_total * 8) || !eb_ensure(S, EB_LMDS, lmd_total * 8) ||
+        !eb_ensure(S, EB_BLOCKS, (size_t)blk_total * sizeof(EncBlock)) || !eb_ensure(S, EB_OUTS, ns * sizeof(EncStreamOut)) ||
+        !eb_ensure(S, EB_STAGE, stage_total + 256) || !eb_ensure(S, EB_SLOTS, (size_t)blk_total * 4))
+        return LZFSE_MI_IO;
+    EncStream *d_streams = (EncStream *)S.bufs[EB_STREAMS];
+    EncTile *d_tiles = (EncTile *)S.bufs[EB_TILES];
+    uint32_t *d_prev = (uint32_t *)S.bufs[EB_PREV];
+    uint32_t *d_summary = (uint32_t *)S.bufs[EB_SUMMARY];
+    uint2 *d_rec = (uint2 *)S.bufs[EB_REC];
+    uint2 *d_lmds = (uint2 *)S.bufs[EB_LMDS];
+    EncBlock *d_blocks = (EncBlock *)S.bufs[EB_BLOCKS];
+    EncStreamOut *d_outs = (EncStreamOut *)S.bufs[EB_OUTS];
+    uint8_t *d_stage = (uint8_t *)S.bufs[EB_STAGE];
+    uint32_t *d_slots = (uint32_t *)S.bufs[EB_SLOTS];
+    E_TRY(hipMemcpyAsync(d_streams, hs.data(), ns * sizeof(EncStream), hipMemcpyHostToDevice, stq));
+    E_TRY(hipMemcpyAsync(d_tiles, ht.data(), nt * sizeof(EncTile), hipMemcpyHostToDevice, stq));
+    E_TRY(hipMemcpyAsync(d_slots, hslots.data(), (size_t)blk_total * 4, hipMemcpyHostToDevice, stq));
+    E_TRY(hipMemsetAsync(d_outs, 0, ns * sizeof(EncStreamOut), stq));
+    {
+        StageTimer t(c, "enc_chain");
+        hipLaunchKernelGGL(enc_chain_kernel, dim3(nt), dim3(64), 0, stq, d_src, d_streams, d_tiles, nt, d_prev, d_summary);
+    }
+    {
+        StageTimer t(c, "enc_link");
+        hipLaunchKernelGGL(enc_link_kernel, dim3(TILE_POS / 256, nt), dim3(256), 0, stq, d_src, d_streams, d_tiles, nt, d_prev, d_summary);
+    }
+    {
+        StageTimer t(c, "enc_cand");
+        hipLaunchKernelGGL(enc_cand_kernel, dim3(TILE_POS / 256, nt), dim3(256), 0, stq, d_src, d_streams, d_tiles, d_prev, d_rec);
+    }
+    {
+        StageTimer t(c, "enc_walk");
+        hipLaunchKernelGGL(enc_walk_kernel, dim3(ns), dim3(64), 0, stq, d_src, d_streams, ns, d_prev, d_rec, d_lmds, d_blocks, d_outs);
+    }
+    {
+        StageTimer t(c, "enc_block");
+        hipLaunchKernelGGL(enc_block_kernel, dim3(blk_total), dim3(BLK_THREADS), 0, stq, d_src, d_streams, ns, d_outs, d_lmds,
+                           d_blocks, d_slots, d_stage);
+    }
+    {
+        StageTimer t(c, "enc_pack");
+        hipLaunchKernelGGL(enc_pack_kernel, dim3(ns), dim3(256), 0, stq, d_streams, ns, d_blocks, d_stage, d_dst, d_outs);
+    }
+    std::vector<EncStreamOut> ho(ns);
+    E_TRY(hipMemcpyAsync(ho.data(), d_outs, ns * sizeof(EncStreamOut), hipMemcpyDeviceToHost, stq));
+    E_TRY(hipStreamSynchronize(stq));
+    if (hipGetLastError() != hipSuccess) return LZFSE_MI_IO;
+    for (uint32_t i = 0; i < ns; i++) {
+        uint32_t u = hs[i].user_index;
+        statuses[u] = ho[i].status;
+        out_lens[u] = ho[i].status ? 0 : ho[i].out_len;
     }
     return LZFSE_MI_OK;
+}
+
+// Debug hook for stage-level parity tests (tests/test_gpu_encode.py): per-position results of
+// the match-finder stages for ONE stream resident in device memory. Not part of the public ABI.
+extern "C" int lzfse_mi_debug_candidates(lzfse_mi_ctx *c, const uint8_t *h_src, size_t n, uint32_t *h_prev, uint32_t *h_rec_xy) {
+    if (!c || n <= VN_CUTOFF || n > 0x7FFFFFFFull) return LZFSE_MI_BAD_ARGUMENT;
+    hipStream_t stq = ctx_stream(c);
+    EncScratch &S = ctx_enc(c);
+    EncStream e{};
+    e.src_off = 0; e.pos_base = 0; e.n = (uint32_t)n;
+    std::vector<EncTile> ht;
+    for (uint32_t p = 0; p < e.n - 3; p += TILE_POS) ht.push_back({0u, p == 0 ? 1u : 0u, p, 0u});
+    uint32_t nt = (uint32_t)ht.size();
+    size_t padn = (n + 255) & ~(size_t)255;
+    if (!eb_ensure(S, EB_STREAMS, sizeof(EncStream)) || !eb_ensure(S, EB_TILES, nt * sizeof(EncTile)) ||
+        !eb_ensure(S, EB_PREV, padn * 4) || !eb_ensure(S, EB_SUMMARY, (size_t)nt * (1u << HASH_BITS) * 4) ||
+        !eb_ensure(S, EB_REC, padn * 8) || !eb_ensure(S, EB_STAGE, padn + 256))
+        return LZFSE_MI_IO;
+    uint8_t *d_src = (uint8_t *)S.bufs[EB_STAGE];
+    E_TRY(hipMemcpyAsync(d_src, h_src, n, hipMemcpyHostToDevice, stq));
+    E_TRY(hipMemcpyAsync(S.bufs[EB_STREAMS], &e, sizeof e, hipMemcpyHostToDevice, stq));
+    E_TRY(hipMemcpyAsync(S.bufs[EB_TILES], ht.data(), nt * sizeof(EncTile), hipMemcpyHostToDevice, stq));
+    hipLaunchKernelGGL(enc_chain_kernel, dim3(nt), dim3(64), 0, stq, d_src, (EncStream *)S.bufs[EB_STREAMS], (EncTile *)S.bufs[EB_TILES], nt,
+                       (uint32_t *)S.bufs[EB_PREV], (uint32_t *)S.bufs[EB_SUMMARY]);
+    hipLaunchKernelGGL(enc_link_kernel, dim3(TILE_POS / 256, nt), dim3(256), 0, stq, d_src, (EncStream *)S.bufs[EB_STREAMS],
+                       (EncTile *)S.bufs[EB_TILES], nt, (uint32_t *)S.bufs[EB_PREV], (uint32_t *)S.bufs[EB_SUMMARY]);
+    hipLaunchKernelGGL(enc_cand_kernel, dim3(TILE_POS / 256, nt), dim3(256), 0, stq, d_src, (EncStream *)S.bufs[EB_STREAMS],
+                       (EncTile *)S.bufs[EB_TILES], (uint32_t *)S.bufs[EB_PREV], (uint2 *)S.bufs[EB_REC]);
+    E_TRY(hipMemcpyAsync(h_prev, S.bufs[EB_PREV], (n - 3) * 4, hipMemcpyDeviceToHost, stq));
+    E_TRY(hipMemcpyAsync(h_rec_xy, S.bufs[EB_REC], (n - 3) * 8, hipMemcpyDeviceToHost, stq));
+    E_TRY(hipStreamSynchronize(stq));
+    return hipGetLastError() == hipSuccess ? LZFSE_MI_OK : LZFSE_MI_IO;
 }
 
 }  // namespace lzmi

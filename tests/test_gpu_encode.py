@@ -1,0 +1,125 @@
+"""GPU parity tests (encode): every stage and the final bytes vs the oracle, bit-exact."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle_py import rng_gen_vec, seq_masked
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import lzfse_rust_amd as m
+    return m.Context(0)
+
+
+def gpu_candidates(ctx, raw):
+    from lzfse_rust_amd import _native
+    L = _native.lib()
+    f = L.lzfse_mi_debug_candidates
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    a = np.frombuffer(raw, dtype=np.uint8)
+    prev = np.zeros(a.size - 3, dtype=np.uint32)
+    rec = np.zeros((a.size - 3, 2), dtype=np.uint32)
+    st = f(ctx._h, a.ctypes.data, a.size, prev.ctypes.data, rec.ctypes.data)
+    assert st == 0
+    return prev, rec
+
+
+def synth_cases():
+    rng = np.random.default_rng(3)
+    words = [bytes(rng.integers(97, 123, size=int(rng.integers(2, 10)), dtype=np.uint8)) for _ in range(2000)]
+    text = b" ".join(words[int(i)] for i in rng.integers(0, 2000, size=120000))
+    return {
+        "text": text,
+        "zeros_4097": bytes(4097),
+        "zeros_300k": bytes(300000),
+        "abc": b"abc" * 70000,
+        "period_70k": (rng.integers(0, 256, size=70000, dtype=np.uint8).tobytes()) * 4,
+        "noise_mask": seq_masked(1, 0x01010101, 1 << 19),
+        "noise": rng_gen_vec(9, 200000),
+        "ramp": bytes(range(256)) * 1500,
+        "tail3": text[:4100],
+    }
+
+
+def test_candidate_stage_matches_oracle(ctx, oracle, snappy_raw):
+    """enc_chain/enc_link/enc_cand vs the oracle's as-if-visited find_match at every position."""
+    cases = dict(synth_cases())
+    for k in ("html", "alice29.txt", "kppkn.gtb", "urls.10K"):
+        cases[k] = snappy_raw[k]
+    for name, raw in cases.items():
+        mi, fl = oracle.candidates(raw)
+        prev, rec = gpu_candidates(ctx, raw)
+        n = len(raw) - 3
+        idx = np.arange(n, dtype=np.int64)
+        fwd = rec[:, 1]
+        dist = rec[:, 0] & 0x3FFFF
+        capped = (rec[:, 0] >> 31) != 0
+        exact = ~capped
+        assert (fwd[exact] == fl[exact]).all(), name
+        has = exact & (fl > 0)
+        assert ((idx[has] - dist[has]) == mi[has]).all(), name
+        assert (fwd[capped] >= 1024).all() and (fl[capped] >= 1024).all(), name
+
+
+def test_encode_bit_exact_snappy(ctx, oracle, snappy_raw):
+    names = list(snappy_raw)
+    outs, st = ctx.encode_batch([snappy_raw[n] for n in names])
+    for n, o, e in zip(names, outs, st):
+        assert e == 0, (n, e)
+        exp = oracle.encode(snappy_raw[n])
+        assert len(o) == len(exp), (n, len(o), len(exp))
+        assert o.tobytes() == exp, n
+
+
+def test_encode_bit_exact_synthetic(ctx, oracle):
+    cases = synth_cases()
+    names = list(cases)
+    outs, st = ctx.encode_batch([cases[n] for n in names])
+    for n, o, e in zip(names, outs, st):
+        assert e == 0, (n, e)
+        assert o.tobytes() == oracle.encode(cases[n]), n
+
+
+def test_encode_zero_4097_kat(ctx):
+    """The reference's only bvx2 byte-exact KAT (frontend_bytes.rs:513-531) through the GPU path."""
+    from test_oracle import ZERO_4097
+    outs, st = ctx.encode_batch([bytes(4097)])
+    assert st[0] == 0 and outs[0].tobytes() == ZERO_4097
+
+
+def test_encode_many_sizes(ctx, oracle):
+    rng = np.random.default_rng(8)
+    raws = []
+    base = synth_cases()["text"]
+    for n in list(range(4097, 4130)) + [8191, 8192, 8193, 39999, 40000, 40001, 65535, 65536, 65537, 131073]:
+        raws.append(base[:n])
+    for n in (5000, 70000):
+        raws.append(rng.integers(0, 4, size=n, dtype=np.uint8).tobytes())
+    outs, st = ctx.encode_batch(raws)
+    for r, o, e in zip(raws, outs, st):
+        assert e == 0
+        assert o.tobytes() == oracle.encode(r), len(r)
+
+
+def test_encode_decode_roundtrip_gpu(ctx, snappy_raw):
+    raws = list(snappy_raw.values()) * 8
+    encs, st = ctx.encode_batch(raws)
+    assert all(e == 0 for e in st)
+    outs, st = ctx.decode_batch([e.tobytes() for e in encs])
+    assert all(e == 0 for e in st)
+    for r, o in zip(raws, outs):
+        assert o.tobytes() == r
+
+
+def test_encode_api_appends(ctx, oracle, snappy_raw):
+    import lzfse_rust_amd as m
+    enc = m.LzfseEncoder(context=ctx)
+    dst = bytearray(b"xy")
+    n = enc.encode_bytes(snappy_raw["html"], dst)
+    assert bytes(dst[2:]) == oracle.encode(snappy_raw["html"]) and n == len(dst) - 2
