@@ -29,7 +29,7 @@ struct lzfse_mi_ctx;
 
 namespace lzmi {
 
-constexpr uint32_t TILE_POS = 65536;        // positions per chain tile
+constexpr uint32_t TILE_POS = 65535;        // positions per chain tile (offset + 1 must fit u16)
 constexpr uint32_t NONE = 0xFFFFFFFFu;      // no previous position
 constexpr uint32_t NONE_TILE = 0xFFFFFFFEu; // no previous position inside the tile (link pending)
 constexpr uint32_t FCAP = 1024;             // cap of the forward length computed per position
@@ -975,11 +975,11 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     }
     {
         StageTimer t(c, "enc_link");
-        hipLaunchKernelGGL(enc_link_kernel, dim3(TILE_POS / 256, nt), dim3(256), 0, stq, d_src, d_streams, d_tiles, nt, d_prev, d_summary);
+        hipLaunchKernelGGL(enc_link_kernel, dim3((TILE_POS + 255) / 256, nt), dim3(256), 0, stq, d_src, d_streams, d_tiles, nt, d_prev, d_summary);
     }
     {
         StageTimer t(c, "enc_cand");
-        hipLaunchKernelGGL(enc_cand_kernel, dim3(TILE_POS / 256, nt), dim3(256), 0, stq, d_src, d_streams, d_tiles, d_prev, d_rec);
+        hipLaunchKernelGGL(enc_cand_kernel, dim3((TILE_POS + 255) / 256, nt), dim3(256), 0, stq, d_src, d_streams, d_tiles, d_prev, d_rec);
     }
     {
         StageTimer t(c, "enc_walk");
@@ -1028,9 +1028,9 @@ extern "C" int lzfse_mi_debug_candidates(lzfse_mi_ctx *c, const uint8_t *h_src, 
     E_TRY(hipMemcpyAsync(S.bufs[EB_TILES], ht.data(), nt * sizeof(EncTile), hipMemcpyHostToDevice, stq));
     hipLaunchKernelGGL(enc_chain_kernel, dim3(nt), dim3(64), 0, stq, d_src, (EncStream *)S.bufs[EB_STREAMS], (EncTile *)S.bufs[EB_TILES], nt,
                        (uint32_t *)S.bufs[EB_PREV], (uint32_t *)S.bufs[EB_SUMMARY]);
-    hipLaunchKernelGGL(enc_link_kernel, dim3(TILE_POS / 256, nt), dim3(256), 0, stq, d_src, (EncStream *)S.bufs[EB_STREAMS],
+    hipLaunchKernelGGL(enc_link_kernel, dim3((TILE_POS + 255) / 256, nt), dim3(256), 0, stq, d_src, (EncStream *)S.bufs[EB_STREAMS],
                        (EncTile *)S.bufs[EB_TILES], nt, (uint32_t *)S.bufs[EB_PREV], (uint32_t *)S.bufs[EB_SUMMARY]);
-    hipLaunchKernelGGL(enc_cand_kernel, dim3(TILE_POS / 256, nt), dim3(256), 0, stq, d_src, (EncStream *)S.bufs[EB_STREAMS],
+    hipLaunchKernelGGL(enc_cand_kernel, dim3((TILE_POS + 255) / 256, nt), dim3(256), 0, stq, d_src, (EncStream *)S.bufs[EB_STREAMS],
                        (EncTile *)S.bufs[EB_TILES], (uint32_t *)S.bufs[EB_PREV], (uint2 *)S.bufs[EB_REC]);
     E_TRY(hipMemcpyAsync(h_prev, S.bufs[EB_PREV], (n - 3) * 4, hipMemcpyDeviceToHost, stq));
     E_TRY(hipMemcpyAsync(h_rec_xy, S.bufs[EB_REC], (n - 3) * 8, hipMemcpyDeviceToHost, stq));
