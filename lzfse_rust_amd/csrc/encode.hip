@@ -21,6 +21,8 @@
 //                      62-93), header (block.rs:168-196)
 //   enc_pack_kernel    stream assembly: blocks back to back + bvx$ (frontend_bytes.rs:50-61)
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "internal.h"
@@ -75,6 +77,9 @@ struct EncStreamOut {
     uint32_t n_blocks;
     int32_t status;
     uint64_t out_len;
+    // walk statistics (diagnostics only)
+    uint32_t iters, emits, capped, refills;
+    uint64_t cycles;
 };
 
 // staging layout of one block: [header + weights | literal payload | lmd payload]
@@ -411,28 +416,45 @@ __global__ __launch_bounds__(64) void enc_walk_kernel(const uint8_t *__restrict_
     w.stash = make_uint2(0, 0);
     w.status = 0;
 
-    // record window: lane k of `cur` holds rec[cbase + k]; `nxt` holds rec[cbase + 64 + k]
+    // record window: 256 positions in registers; lane k of r_j holds rec[cbase + 64 j + k]. One
+    // (stalling) refill per 256 positions; has_j = lanes of r_j with an incoming match.
     uint32_t cbase = 0;
-    uint2 cur = (cbase + lane < w.end) ? w.rec[cbase + lane] : make_uint2(0, 0);
-    uint2 nxt = (cbase + 64 + lane < w.end) ? w.rec[cbase + 64 + lane] : make_uint2(0, 0);
+    uint2 r0, r1, r2, r3;
+    uint64_t has0, has1, has2, has3;
+#define WK_LOAD_WINDOW()                                                                           \
+    do {                                                                                           \
+        r0 = (cbase + lane < w.end) ? w.rec[cbase + lane] : make_uint2(0, 0);                      \
+        r1 = (cbase + 64 + lane < w.end) ? w.rec[cbase + 64 + lane] : make_uint2(0, 0);            \
+        r2 = (cbase + 128 + lane < w.end) ? w.rec[cbase + 128 + lane] : make_uint2(0, 0);          \
+        r3 = (cbase + 192 + lane < w.end) ? w.rec[cbase + 192 + lane] : make_uint2(0, 0);          \
+        has0 = __ballot(r0.y != 0); has1 = __ballot(r1.y != 0);                                    \
+        has2 = __ballot(r2.y != 0); has3 = __ballot(r3.y != 0);                                    \
+    } while (0)
+    WK_LOAD_WINDOW();
     uint32_t index = 0;
+    uint32_t st_iters = 0, st_emits = 0, st_capped = 0, st_refills = 0;
+    const uint64_t t_begin = __builtin_amdgcn_s_memtime();
     while (index < w.end && !w.status) {
-        // bring `index` into the current window
-        if (index >= cbase + 64) {
-            if (index < cbase + 128) { cbase += 64; cur = nxt; }
-            else { cbase = index & ~63u; cur = (cbase + lane < w.end) ? w.rec[cbase + lane] : make_uint2(0, 0); }
-            nxt = (cbase + 64 + lane < w.end) ? w.rec[cbase + 64 + lane] : make_uint2(0, 0);
+        if (index >= cbase + 256) {
+            cbase = index & ~63u;
+            WK_LOAD_WINDOW();
+            st_refills++;
         }
         // skip positions without an incoming match: select() returns None for them (match_object.rs:14)
-        uint64_t have = __ballot(cur.y != 0) & (~0ull << (index - cbase));
-        if (!have) { index = cbase + 64; continue; }
+        uint32_t off = index - cbase, j = off >> 6;
+        uint64_t have = (j == 0 ? has0 : j == 1 ? has1 : j == 2 ? has2 : has3) & (~0ull << (off & 63));
+        while (!have && j < 3) { j++; have = j == 1 ? has1 : j == 2 ? has2 : has3; }
+        if (!have) { index = cbase + 256; continue; }
         const int k = __builtin_ctzll(have);
-        index = cbase + k;
+        index = cbase + 64 * j + k;
         if (index >= w.end) break;
+        const uint2 cur = j == 0 ? r0 : j == 1 ? r1 : j == 2 ? r2 : r3;
+        st_iters++;
         uint32_t rx = e_readlane(cur.x, k), fwd = e_readlane(cur.y, k);
         uint32_t dist = rx & 0x3FFFF, bw = (rx >> 18) & 0xFF;
         uint32_t midx = index - dist;
         if (rx & REC_CAPPED) {
+            st_capped++;
             // exact re-evaluation of find_match's forward part (frontend_bytes.rs:214-231)
             uint32_t v = ld_u32(w.s + index);
             uint32_t best_len = 0, best_idx = 0;
@@ -473,6 +495,7 @@ __global__ __launch_bounds__(64) void enc_walk_kernel(const uint8_t *__restrict_
             emit = true; e_idx = w.p_idx; e_midx = w.p_midx; e_len = w.p_len; w.p_len = 0;
         }
         if (emit) {
+            st_emits++;
             wk_push_match(w, e_idx, e_len, e_idx - e_midx);
             if (w.literal_index >= w.end) break;
             index += 1;
@@ -495,6 +518,8 @@ __global__ __launch_bounds__(64) void enc_walk_kernel(const uint8_t *__restrict_
     if (lane == 0) {
         EncStreamOut o;
         o.n_blocks = w.blk_count; o.status = w.status; o.out_len = 0;
+        o.iters = st_iters; o.emits = st_emits; o.capped = st_capped; o.refills = st_refills;
+        o.cycles = __builtin_amdgcn_s_memtime() - t_begin;
         outs[si] = o;
     }
 }
@@ -502,6 +527,10 @@ __global__ __launch_bounds__(64) void enc_walk_kernel(const uint8_t *__restrict_
 // ------------------------------------------------------------------------------------ block encode
 
 constexpr int BLK_THREADS = 256;
+constexpr uint32_t CL = 2048;                         // literals per chunk (8 per thread)
+constexpr uint32_t CE = 512;                          // LMDs per chunk (2 per thread)
+constexpr uint32_t PK_LIT = CL * 10 / 32 + 8;         // <= 10 bits per literal
+constexpr uint32_t PK_LMD = CE * 54 / 32 + 8;         // <= 54 bits per LMD
 
 __device__ __forceinline__ uint32_t l_sym_of(uint32_t v) { return v < 16 ? v : 16u + (v >= 20) + (v >= 28) + (v >= 60); }
 __device__ __forceinline__ uint32_t m_sym_of(uint32_t v) { return v < 16 ? v : 16u + (v >= 24) + (v >= 56) + (v >= 312); }
@@ -546,6 +575,19 @@ __device__ void normalize_m1(uint16_t *w, uint32_t n, uint32_t in_total, uint32_
     }
 }
 
+// OR a <= 64-bit little-endian bit field into a u32 LDS bit buffer at bit offset o
+__device__ __forceinline__ void or_bits(uint32_t *pk, uint32_t o, uint64_t v) {
+    uint32_t wi = o >> 5, sh = o & 31;
+    uint32_t w0 = (uint32_t)(v << sh);
+    uint64_t rest = sh ? (v >> (32 - sh)) : (v >> 32);
+    uint32_t w1 = (uint32_t)rest, w2 = (uint32_t)(rest >> 32);
+    if (w0) atomicOr(&pk[wi], w0);
+    if (w1) atomicOr(&pk[wi + 1], w1);
+    if (w2) atomicOr(&pk[wi + 2], w2);
+}
+
+static_assert(CE / BLK_THREADS == 2 && CL / BLK_THREADS == 8, "chunk shapes are baked into enc_block_kernel");
+
 template <int DELTA>
 __device__ __forceinline__ uint32_t e_dpp_shr(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + DELTA, 0xF, 0xF, true);
@@ -583,8 +625,12 @@ __global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *_
     __shared__ uint16_t wts[N_WEIGHTS];
     __shared__ uint32_t etab[N_WEIGHTS];      // t_k (low 16) | t_w (high 16), encoder.rs:184-188
     __shared__ uint32_t wbits[N_WEIGHTS / 4 * 4 + 200];  // weight payload words (<= 630 bytes)
-    __shared__ uint32_t scan_sh[2 * (BLK_THREADS / 64) + 2];
+    __shared__ uint32_t scan_sh[3 * (BLK_THREADS / 64) + 2];
     __shared__ uint32_t sh_misc[16];
+    __shared__ uint32_t cl[CL];            // literal chunk: E entry -> (state bits | nb << 16)
+    __shared__ uint32_t ce[3 * CE];        // LMD chunk: D, M, L entries per LMD
+    __shared__ uint32_t pk_lit[PK_LIT];    // bit buffers of the current chunk
+    __shared__ uint32_t pk_lmd[PK_LMD];
 
     const uint32_t slot = blockIdx.x;
     const uint32_t si = slot_stream[slot];
@@ -734,84 +780,166 @@ __global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *_
     // weight bytes -> staging after the 32-byte header
     for (uint32_t i = tid; i < n_wbytes; i += BLK_THREADS) sg[V2_HEADER_SIZE + i] = (uint8_t)(wbits[i >> 2] >> (8 * (i & 3)));
 
-    // ---- the two reverse FSE streams ----
-    if (wave == 0) {
-        // literals.rs:93-133: lane r carries state (3 - r); emission order state3, 2, 1, 0
-        BitOut o; o.acc = 0; o.fill = 0; o.out = sg + stage_lit_off(); o.pos = 0;
-        uint32_t state = U_STATES;
-        const int r = lane & 3;
-        for (uint32_t i = n4; i != 0; i -= 4) {
-            uint32_t sym = lit[i - 1 - r];
-            uint32_t e = etab[104 + sym];
-            int32_t tk = (int32_t)(int16_t)(e & 0xFFFF), tw = (int32_t)(int16_t)(e >> 16);
-            uint32_t nb = (uint32_t)(tk + (int32_t)state) >> 10;
-            uint32_t bits = state & ((1u << nb) - 1u);
-            state = (uint32_t)(tw + (int32_t)(state >> nb));
-            uint32_t pre = nb;
-            pre += e_dpp_shr<1>(pre);
-            pre += e_dpp_shr<2>(pre);  // inclusive over lanes 0..3
-            uint64_t c = (uint64_t)bits << (o.fill + pre - nb);
-            uint32_t clo = (uint32_t)c, chi = (uint32_t)(c >> 32);
-            clo |= e_dpp_shr<1>(clo); chi |= e_dpp_shr<1>(chi);
-            clo |= e_dpp_shr<2>(clo); chi |= e_dpp_shr<2>(chi);
-            o.acc |= (uint64_t)e_readlane(clo, 3) | ((uint64_t)e_readlane(chi, 3) << 32);
-            o.fill += e_readlane(pre, 3);
-            bo_flush(o);
-        }
-        uint32_t unused = bo_finalize(o);
-        if (lane == 0) {
-            sh_misc[1] = o.pos;      // literal payload bytes
-            sh_misc[2] = unused;     // literal bits
-        }
-        // state of lane r belongs to state index 3 - r
-        uint32_t s3 = e_readlane(state, 0), s2 = e_readlane(state, 1), s1 = e_readlane(state, 2), s0 = e_readlane(state, 3);
-        if (lane == 0) { sh_misc[3] = s0 - U_STATES; sh_misc[4] = s1 - U_STATES; sh_misc[5] = s2 - U_STATES; sh_misc[6] = s3 - U_STATES; }
-    } else if (wave == 1) {
-        // lmds.rs:62-93: 8 zero bytes, then LMDs in reverse; per LMD: D, M, L (extra bits then state bits)
-        uint8_t *lo = sg + stage_lmd_off(n_lit);
-        if (lane < 8) lo[lane] = 0;
-        BitOut o; o.acc = 0; o.fill = 0; o.out = lo + 8; o.pos = 0;
-        const int li = lane < 2 ? lane : 2;  // 0 = D, 1 = M, 2 = L
-        uint32_t state = li == 0 ? D_STATES : 64u;
-        const uint32_t tb = li == 0 ? 40u : (li == 1 ? 20u : 0u);
-        uint2 chunk = make_uint2(0, 0);
-        for (uint32_t i = blk.n_lmd; i != 0; i--) {
-            const uint32_t idx = i - 1;
-            if ((idx & 63) == 63 || i == blk.n_lmd) {
-                uint32_t cb = idx & ~63u;
-                chunk = (cb + lane < blk.n_lmd) ? bl[cb + lane] : make_uint2(0, 0);
+    // ---- the two reverse FSE streams (literals.rs:93-133, lmds.rs:62-93) ----
+    // Only the state recurrence s' = t_w + (s >> nb), nb = (t_k + s) >> 10 (encoder.rs:191-199) is
+    // serial. Per chunk: (A0) all threads look up the E-table entry of every symbol, (A) one lane
+    // per state chain runs the recurrence and leaves (state bits | nb << 16) in place, (B) all
+    // threads prefix-sum the field widths and OR the fields into an LDS bit buffer whose
+    // completed words are stored coalesced.
+    {
+        const uint32_t n_lmd = blk.n_lmd;
+        uint32_t *lit_words = (uint32_t *)(sg + stage_lit_off());
+        uint8_t *lmd_base = sg + stage_lmd_off(n_lit);
+        uint32_t *lmd_words = (uint32_t *)(lmd_base + 8);
+        if (tid < 2) ((uint32_t *)lmd_base)[tid] = 0;  // 8-byte pad (lmds.rs:67-69)
+        const uint32_t it_lit = (n4 + CL - 1) / CL, it_lmd = (n_lmd + CE - 1) / CE;
+        const uint32_t n_it = it_lit > it_lmd ? it_lit : it_lmd;
+        uint32_t lit_bits_done = 0, lmd_bits_done = 0;  // bits already emitted (uniform)
+        // chain states: wave 0 lanes 0..3 -> literal state (3 - lane); wave 1 lanes 0..2 -> D, M, L
+        uint32_t cstate = (wave == 0) ? U_STATES : (lane == 0 ? D_STATES : 64u);
+        for (uint32_t i = tid; i < PK_LIT; i += BLK_THREADS) pk_lit[i] = 0;
+        for (uint32_t i = tid; i < PK_LMD; i += BLK_THREADS) pk_lmd[i] = 0;
+        __syncthreads();
+        for (uint32_t it = 0; it < n_it; it++) {
+            const uint32_t le0 = it * CL, me0 = it * CE;
+            const uint32_t lcnt = le0 < n4 ? (n4 - le0 < CL ? n4 - le0 : CL) : 0;
+            const uint32_t mcnt = me0 < n_lmd ? (n_lmd - me0 < CE ? n_lmd - me0 : CE) : 0;
+            // ---- A0 ----
+            for (uint32_t k = tid; k < lcnt; k += BLK_THREADS) cl[k] = etab[104 + lit[n4 - 1 - (le0 + k)]];
+            uint2 mrec[CE / BLK_THREADS];
+#pragma unroll
+            for (int u = 0; u < CE / BLK_THREADS; u++) {
+                uint32_t k = tid + u * BLK_THREADS;
+                mrec[u] = make_uint2(0, 0);
+                if (k < mcnt) {
+                    uint2 r = bl[n_lmd - 1 - (me0 + k)];
+                    mrec[u] = r;
+                    ce[3 * k + 0] = etab[40 + d_sym_of(r.y)];
+                    ce[3 * k + 1] = etab[20 + m_sym_of(r.x >> 16)];
+                    ce[3 * k + 2] = etab[l_sym_of(r.x & 0xFFFF)];
+                }
             }
-            uint32_t rx = e_readlane(chunk.x, idx & 63), ry = e_readlane(chunk.y, idx & 63);
-            uint32_t v = li == 0 ? ry : (li == 1 ? (rx >> 16) : (rx & 0xFFFF));
-            uint32_t sym = li == 0 ? d_sym_of(v) : (li == 1 ? m_sym_of(v) : l_sym_of(v));
-            uint32_t nx = li == 0 ? d_extra_bits(sym) : (li == 1 ? m_extra_bits(sym) : l_extra_bits(sym));
-            uint32_t bv = li == 0 ? d_base_value(sym) : (li == 1 ? m_base_value(sym) : l_base_value(sym));
-            uint32_t e = etab[tb + sym];
-            int32_t tk = (int32_t)(int16_t)(e & 0xFFFF), tw = (int32_t)(int16_t)(e >> 16);
-            uint32_t nb = (uint32_t)(tk + (int32_t)state) >> 10;
-            uint32_t sbits = state & ((1u << nb) - 1u);
-            state = (uint32_t)(tw + (int32_t)(state >> nb));
-            uint32_t width = nx + nb;
-            uint64_t field = (uint64_t)(v - bv) | ((uint64_t)sbits << nx);
-            uint32_t pre = width;
-            pre += e_dpp_shr<1>(pre);
-            pre += e_dpp_shr<2>(pre);  // inclusive over lanes 0..2
-            uint64_t c = field << (o.fill + pre - width);
-            uint32_t clo = (uint32_t)c, chi = (uint32_t)(c >> 32);
-            if (lane > 2) { clo = 0; chi = 0; }
-            clo |= e_dpp_shr<1>(clo); chi |= e_dpp_shr<1>(chi);
-            clo |= e_dpp_shr<2>(clo); chi |= e_dpp_shr<2>(chi);
-            o.acc |= (uint64_t)e_readlane(clo, 2) | ((uint64_t)e_readlane(chi, 2) << 32);
-            o.fill += e_readlane(pre, 2);
-            bo_flush(o);
+            __syncthreads();
+            // ---- A: serial state chains ----
+            if (wave == 0 && lane < 4) {
+                for (uint32_t k = lane; k < lcnt; k += 4) {
+                    uint32_t e = cl[k];
+                    int32_t tk = (int32_t)(int16_t)(e & 0xFFFF), tw = (int32_t)(int16_t)(e >> 16);
+                    uint32_t nb = (uint32_t)(tk + (int32_t)cstate) >> 10;
+                    cl[k] = (cstate & ((1u << nb) - 1u)) | (nb << 16);
+                    cstate = (uint32_t)(tw + (int32_t)(cstate >> nb));
+                }
+            } else if (wave == 1 && lane < 3) {
+                for (uint32_t k = lane; k < 3 * mcnt; k += 3) {
+                    uint32_t e = ce[k];
+                    int32_t tk = (int32_t)(int16_t)(e & 0xFFFF), tw = (int32_t)(int16_t)(e >> 16);
+                    uint32_t nb = (uint32_t)(tk + (int32_t)cstate) >> 10;
+                    ce[k] = (cstate & ((1u << nb) - 1u)) | (nb << 16);
+                    cstate = (uint32_t)(tw + (int32_t)(cstate >> nb));
+                }
+            }
+            __syncthreads();
+            // ---- B: widths, prefix sums, bit packing ----
+            // literals: thread owns 8 consecutive emissions
+            uint64_t lv0 = 0, lv1 = 0;  // up to 80 bits
+            uint32_t lw = 0;
+            {
+                uint32_t k0 = tid * (CL / BLK_THREADS);
+#pragma unroll
+                for (int u = 0; u < (int)(CL / BLK_THREADS); u++) {
+                    uint32_t k = k0 + u;
+                    if (k < lcnt) {
+                        uint32_t e = cl[k];
+                        uint32_t nb = e >> 16;
+                        uint64_t v = e & 0xFFFF;
+                        if (lw < 64) { lv0 |= v << lw; if (lw + nb > 64) lv1 |= v >> (64 - lw); }
+                        else lv1 |= v << (lw - 64);
+                        lw += nb;
+                    }
+                }
+            }
+            // LMDs: thread owns emissions tid and tid + 256; field order D, M, L (extra bits, then state bits)
+            uint64_t mv[CE / BLK_THREADS];
+            uint32_t mw[CE / BLK_THREADS];
+#pragma unroll
+            for (int u = 0; u < CE / BLK_THREADS; u++) {
+                uint32_t k = tid + u * BLK_THREADS;
+                mv[u] = 0; mw[u] = 0;
+                if (k < mcnt) {
+                    uint2 r = mrec[u];
+                    uint32_t vd = r.y, vm = r.x >> 16, vl = r.x & 0xFFFF;
+                    uint32_t sd = d_sym_of(vd), sm = m_sym_of(vm), sl = l_sym_of(vl);
+                    uint32_t ed = ce[3 * k], em = ce[3 * k + 1], el = ce[3 * k + 2];
+                    uint32_t nxd = d_extra_bits(sd), nxm = m_extra_bits(sm), nxl = l_extra_bits(sl);
+                    uint64_t fd = (uint64_t)(vd - d_base_value(sd)) | ((uint64_t)(ed & 0xFFFF) << nxd);
+                    uint32_t wd = nxd + (ed >> 16);
+                    uint64_t fm = (uint64_t)(vm - m_base_value(sm)) | ((uint64_t)(em & 0xFFFF) << nxm);
+                    uint32_t wm = nxm + (em >> 16);
+                    uint64_t fl = (uint64_t)(vl - l_base_value(sl)) | ((uint64_t)(el & 0xFFFF) << nxl);
+                    uint32_t wl = nxl + (el >> 16);
+                    mv[u] = fd | (fm << wd) | (fl << (wd + wm));
+                    mw[u] = wd + wm + wl;
+                }
+            }
+            // block exclusive scans: literal widths (per thread), LMD widths (per thread, per slice u)
+            uint32_t a = lw, b2 = mw[0], c2 = CE / BLK_THREADS > 1 ? mw[CE / BLK_THREADS - 1] : 0;
+            uint32_t ia = a, ib = b2, ic = c2;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                uint32_t x = __shfl_up(ia, dd), y = __shfl_up(ib, dd), z = __shfl_up(ic, dd);
+                if (lane >= dd) { ia += x; ib += y; ic += z; }
+            }
+            if (lane == 63) { scan_sh[wave] = ia; scan_sh[4 + wave] = ib; scan_sh[8 + wave] = ic; }
+            __syncthreads();
+            uint32_t oa = 0, ob = 0, oc = 0, ta = 0, tb2 = 0, tc = 0;
+            for (int wv = 0; wv < BLK_THREADS / 64; wv++) {
+                uint32_t x = scan_sh[wv], y = scan_sh[4 + wv], z = scan_sh[8 + wv];
+                if (wv < wave) { oa += x; ob += y; oc += z; }
+                ta += x; tb2 += y; tc += z;
+            }
+            const uint32_t ex_a = oa + ia - a, ex_b = ob + ib - b2, ex_c = tb2 + oc + ic - c2;
+            // OR fields into the LDS bit buffers (word 0 starts at the last incomplete output word)
+            {
+                uint32_t o = (lit_bits_done & 31) + ex_a;
+                if (lw) {
+                    or_bits(pk_lit, o, lv0);
+                    if (lw > 64) or_bits(pk_lit, o + 64, lv1);
+                }
+#pragma unroll
+                for (int u = 0; u < (int)(CE / BLK_THREADS); u++)
+                    if (mw[u]) or_bits(pk_lmd, (lmd_bits_done & 31) + (u == 0 ? ex_b : ex_c), mv[u]);
+            }
+            __syncthreads();
+            // store completed words, carry the incomplete one to word 0
+            {
+                uint32_t have = (lit_bits_done & 31) + ta, full = have >> 5;
+                uint32_t w0 = lit_bits_done >> 5;
+                for (uint32_t k = tid; k < full; k += BLK_THREADS) lit_words[w0 + k] = pk_lit[k];
+                uint32_t carry = pk_lit[full];
+                uint32_t have_m = (lmd_bits_done & 31) + tb2 + tc, full_m = have_m >> 5;
+                uint32_t m0 = lmd_bits_done >> 5;
+                for (uint32_t k = tid; k < full_m; k += BLK_THREADS) lmd_words[m0 + k] = pk_lmd[k];
+                uint32_t carry_m = pk_lmd[full_m];
+                __syncthreads();
+                for (uint32_t k = tid; k <= full + 3 && k < PK_LIT; k += BLK_THREADS) pk_lit[k] = k == 0 ? carry : 0;
+                for (uint32_t k = tid; k <= full_m + 3 && k < PK_LMD; k += BLK_THREADS) pk_lmd[k] = k == 0 ? carry_m : 0;
+                lit_bits_done += ta;
+                lmd_bits_done += tb2 + tc;
+            }
+            __syncthreads();
         }
-        uint32_t unused = bo_finalize(o);
-        uint32_t sd = e_readlane(state, 0), sm = e_readlane(state, 1), sl = e_readlane(state, 2);
-        if (lane == 0) {
-            sh_misc[7] = o.pos + 8;  // lmd payload bytes (pad included, lmds.rs:67-69,91)
-            sh_misc[8] = unused;
-            sh_misc[9] = sl - L_STATES; sh_misc[10] = sm - M_STATES; sh_misc[11] = sd - D_STATES;
+        // finalize (bit_writer.rs:46-57): the last partial word, unused bits of the last byte
+        if (tid == 0) {
+            lit_words[lit_bits_done >> 5] = pk_lit[0];
+            lmd_words[lmd_bits_done >> 5] = pk_lmd[0];
+            uint32_t lb = (lit_bits_done + 7) >> 3, mb = (lmd_bits_done + 7) >> 3;
+            sh_misc[1] = lb;                           // literal payload bytes
+            sh_misc[2] = lb * 8 - lit_bits_done;       // literal bits
+            sh_misc[7] = mb + 8;                       // lmd payload bytes incl. pad (lmds.rs:67-69,91)
+            sh_misc[8] = mb * 8 - lmd_bits_done;
         }
+        if (wave == 0 && lane < 4) sh_misc[3 + (3 - lane)] = cstate - U_STATES;   // lane r carries state 3 - r
+        if (wave == 1 && lane < 3) sh_misc[lane == 0 ? 11 : (lane == 1 ? 10 : 9)] = cstate - (lane == 0 ? D_STATES : 64u);
     }
     __syncthreads();
     // ---- header (block.rs:168-196) ----
@@ -1002,6 +1130,12 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         uint32_t u = hs[i].user_index;
         statuses[u] = ho[i].status;
         out_lens[u] = ho[i].status ? 0 : ho[i].out_len;
+    }
+    if (getenv("LZFSE_MI_WALK_STATS")) {
+        for (uint32_t i = 0; i < ns && i < 16; i++)
+            fprintf(stderr, "walk[%u] n=%u iters=%u emits=%u capped=%u refills=%u cycles=%llu (%.1f cyc/iter)\n", i, hs[i].n,
+                    ho[i].iters, ho[i].emits, ho[i].capped, ho[i].refills, (unsigned long long)ho[i].cycles,
+                    ho[i].iters ? (double)ho[i].cycles / ho[i].iters : 0.0);
     }
     return LZFSE_MI_OK;
 }
