@@ -1,0 +1,107 @@
+// Shared definitions of the encode kernels (encode.hip, encode_parse.hip).
+#pragma once
+#include "internal.h"
+
+namespace lzmi {
+
+constexpr uint32_t TILE_POS = 65472;        // positions per chain tile: multiple of 64, offset + 1 fits u16
+constexpr uint32_t SEG = 4096;              // positions per speculative-parse segment
+constexpr uint32_t OVER = 1024;             // overrun of a segment walker into the next segment
+constexpr uint32_t SEG_EV_CAP = (SEG + OVER) / 4 + 4;  // every emit advances literal_index by >= 4
+constexpr uint32_t NONE = 0xFFFFFFFFu;      // no previous position
+constexpr uint32_t NONE_TILE = 0xFFFFFFFEu; // no previous position inside the tile (link pending)
+constexpr uint32_t FCAP = 1024;             // cap of the forward length computed per position
+constexpr uint32_t BCAP = 255;              // cap of the backward length computed per position
+constexpr uint32_t REC_CAPPED = 0x80000000u;
+
+__device__ __forceinline__ int e_lane() { return threadIdx.x & 63; }
+__device__ __forceinline__ uint32_t e_readlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ uint32_t bucket_of(uint32_t v) { return (v * 0x9E3779B1u) >> (32 - HASH_BITS); }
+
+struct EncStream {       // one input stream (n > VN_CUTOFF) of the batch
+    uint64_t src_off;    // offset of the stream in d_src
+    uint64_t pos_base;   // offset of the stream in the per-position arrays (prev, rec)
+    uint64_t dst_off, dst_cap;
+    uint64_t lmd_base;   // offset into the LMD array
+    uint64_t stage_base; // offset into the block staging area
+    uint64_t stage_cap;
+    uint32_t n;          // stream length
+    uint32_t tile_base;  // index of the stream's first tile
+    uint32_t blk_base;   // index of the stream's first block slot
+    uint32_t blk_cap;    // number of block slots
+    uint32_t lmd_cap;
+    uint32_t user_index; // index in the caller's arrays
+    // speculative parse
+    uint32_t seg_base, n_seg;      // segments of this stream in the segment arrays
+    uint32_t range_base, range_cap;
+    uint64_t match_base;           // offset into the match / gap / prefix-sum arrays
+    uint32_t match_cap, pad0;
+};
+
+struct SpecEvent {   // one emitted match of a segment walker + the walker state after it
+    uint32_t e_idx, e_len, e_dist, e_lit;          // match and literal_index before it
+    uint32_t index_after, p_idx, p_midx, p_len;    // state after (pending zeroed when empty)
+};
+struct SpecHeader {
+    uint32_t n_events, status;                     // status 1: aborted on a record needing an exact length
+    uint32_t f_index, f_lit, f_pidx, f_pmidx, f_plen, pad;  // final state
+};
+struct MatchRec {    // ordered match list of a stream: literal run [lit_pos, lit_pos + l), then m bytes at distance d
+    uint32_t lit_pos, l, m, d;
+};
+struct RangeRec {    // a run of events adopted into the match list
+    uint64_t begin;  // kind 0: absolute SpecEvent index, kind 1: index into the stream's gap events
+    uint32_t count, out_off;
+    uint32_t kind, pad;
+};
+
+struct EncTile {
+    uint32_t stream;
+    uint32_t first;      // 1 if this is the first tile of its stream
+    uint32_t start;      // first position of the tile (stream relative)
+    uint32_t pad;
+};
+
+struct EncBlock {        // one bvx2 block (written by the walk kernel)
+    uint64_t lmd_start;  // index into the LMD array
+    uint64_t stage_off;  // staging offset of this block's bytes
+    uint32_t src_start;  // first raw byte of the block (stream relative)
+    uint32_t n_lmd, n_lit, n_match;
+    // filled by the block kernel
+    uint32_t hdr_len, lit_len, lmd_len, pad;
+    // events that lie completely inside the block (enc_segment_kernel -> enc_lmd_kernel)
+    uint32_t ev_begin, ev_end, head_lmds, head_prev_d;
+};
+
+struct EncStreamOut {
+    uint32_t n_blocks;
+    int32_t status;
+    uint64_t out_len;
+    uint32_t n_matches, n_ranges;
+    // walk statistics (diagnostics only)
+    uint32_t iters, emits, capped, refills;
+    uint64_t cycles;
+};
+
+// staging layout of one block: [header + weights | literal payload | lmd payload]
+__host__ __device__ inline uint32_t stage_lit_off() { return 704; }
+__host__ __device__ inline uint32_t stage_lmd_off(uint32_t n_lit) { return 704 + ((((n_lit + 3) / 4 * 4) * 10 + 7) / 8 + 24 + 15) / 16 * 16; }
+__host__ __device__ inline uint32_t stage_need(uint32_t n_lit, uint32_t n_lmd) {
+    return stage_lmd_off(n_lit) + ((8 + (n_lmd * 54 + 7) / 8 + 24 + 15) / 16 * 16);
+}
+
+
+// encode_parse.hip
+void launch_enc_spec(const EncStream *streams, const uint2 *segs, uint32_t n_segs, const uint2 *rec, const uint64_t *bitmap,
+                     SpecEvent *logs, SpecHeader *hdrs, hipStream_t st);
+void launch_enc_stitch(const uint8_t *src, const EncStream *streams, uint32_t ns, const uint32_t *prev, const uint2 *rec,
+                       const uint64_t *bitmap, const SpecEvent *logs, const SpecHeader *hdrs, RangeRec *ranges, MatchRec *gaps,
+                       EncStreamOut *outs, hipStream_t st);
+void launch_enc_compact(const EncStream *streams, const uint32_t *slot_stream, uint32_t n_slots, const EncStreamOut *outs,
+                        const RangeRec *ranges, const SpecEvent *logs, const MatchRec *gaps, MatchRec *matches, hipStream_t st);
+void launch_enc_segment(const EncStream *streams, uint32_t ns, const MatchRec *matches, uint32_t *pc, uint32_t *pl, uint2 *lmds,
+                        EncBlock *blocks, EncStreamOut *outs, hipStream_t st);
+void launch_enc_lmd(const EncStream *streams, const uint32_t *slot_stream, uint32_t n_slots, const EncStreamOut *outs,
+                    const EncBlock *blocks, const MatchRec *matches, const uint32_t *pc, uint2 *lmds, hipStream_t st);
+
+}  // namespace lzmi

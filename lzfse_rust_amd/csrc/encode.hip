@@ -25,69 +25,11 @@
 #include <cstdlib>
 #include <vector>
 
-#include "internal.h"
+#include "enc_common.h"
 
 struct lzfse_mi_ctx;
 
 namespace lzmi {
-
-constexpr uint32_t TILE_POS = 65535;        // positions per chain tile (offset + 1 must fit u16)
-constexpr uint32_t NONE = 0xFFFFFFFFu;      // no previous position
-constexpr uint32_t NONE_TILE = 0xFFFFFFFEu; // no previous position inside the tile (link pending)
-constexpr uint32_t FCAP = 1024;             // cap of the forward length computed per position
-constexpr uint32_t BCAP = 255;              // cap of the backward length computed per position
-constexpr uint32_t REC_CAPPED = 0x80000000u;
-
-__device__ __forceinline__ int e_lane() { return threadIdx.x & 63; }
-__device__ __forceinline__ uint32_t e_readlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
-__device__ __forceinline__ uint32_t bucket_of(uint32_t v) { return (v * 0x9E3779B1u) >> (32 - HASH_BITS); }
-
-struct EncStream {       // one input stream (n > VN_CUTOFF) of the batch
-    uint64_t src_off;    // offset of the stream in d_src
-    uint64_t pos_base;   // offset of the stream in the per-position arrays (prev, rec)
-    uint64_t dst_off, dst_cap;
-    uint64_t lmd_base;   // offset into the LMD array
-    uint64_t stage_base; // offset into the block staging area
-    uint64_t stage_cap;
-    uint32_t n;          // stream length
-    uint32_t tile_base;  // index of the stream's first tile
-    uint32_t blk_base;   // index of the stream's first block slot
-    uint32_t blk_cap;    // number of block slots
-    uint32_t lmd_cap;
-    uint32_t user_index; // index in the caller's arrays
-};
-
-struct EncTile {
-    uint32_t stream;
-    uint32_t first;      // 1 if this is the first tile of its stream
-    uint32_t start;      // first position of the tile (stream relative)
-    uint32_t pad;
-};
-
-struct EncBlock {        // one bvx2 block (written by the walk kernel)
-    uint64_t lmd_start;  // index into the LMD array
-    uint64_t stage_off;  // staging offset of this block's bytes
-    uint32_t src_start;  // first raw byte of the block (stream relative)
-    uint32_t n_lmd, n_lit, n_match;
-    // filled by the block kernel
-    uint32_t hdr_len, lit_len, lmd_len, pad;
-};
-
-struct EncStreamOut {
-    uint32_t n_blocks;
-    int32_t status;
-    uint64_t out_len;
-    // walk statistics (diagnostics only)
-    uint32_t iters, emits, capped, refills;
-    uint64_t cycles;
-};
-
-// staging layout of one block: [header + weights | literal payload | lmd payload]
-__host__ __device__ inline uint32_t stage_lit_off() { return 704; }
-__host__ __device__ inline uint32_t stage_lmd_off(uint32_t n_lit) { return 704 + ((((n_lit + 3) / 4 * 4) * 10 + 7) / 8 + 24 + 15) / 16 * 16; }
-__host__ __device__ inline uint32_t stage_need(uint32_t n_lit, uint32_t n_lmd) {
-    return stage_lmd_off(n_lit) + ((8 + (n_lmd * 54 + 7) / 8 + 24 + 15) / 16 * 16);
-}
 
 // ------------------------------------------------------------------------------------ chains
 
@@ -194,42 +136,49 @@ __device__ __forceinline__ uint32_t lcs_bwd(const uint8_t *s, uint32_t a, uint32
 }
 
 // rec[i] = { dist | bwd << 18 | capped << 31 , fwd_len }  ; fwd_len == 0: no match at i
-__global__ void enc_cand_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
-                                const EncTile *__restrict__ tiles, const uint32_t *__restrict__ prev,
-                                uint2 *__restrict__ rec) {
+__global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
+                                                       const EncTile *__restrict__ tiles, const uint32_t *__restrict__ prev,
+                                                       uint2 *__restrict__ rec, uint64_t *__restrict__ bitmap) {
     const uint32_t t = blockIdx.y;
     const EncTile tl = tiles[t];
     const EncStream st = streams[tl.stream];
     const uint32_t i = tl.start + blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n = st.n, n_pos = n - 3;
-    if (i >= n_pos || i >= tl.start + TILE_POS) return;
+    if (tl.start + blockIdx.x * blockDim.x >= n_pos) return;  // block-uniform
+    const bool valid = i < n_pos && i < tl.start + TILE_POS;
     const uint8_t *s = src + st.src_off;
     const uint32_t *pv = prev + st.pos_base;
-    const uint32_t v = ld_u32(s + i);
-    const uint32_t max_total = n - i;
-    const uint32_t cap_total = max_total < FCAP ? max_total : FCAP;
-    uint32_t best_len = 0, best_idx = 0;
-    bool capped = false;
-    uint32_t c = pv[i];
-#pragma unroll 1
-    for (int k = 0; k < 4 && c != NONE; k++) {
-        uint32_t dist = i - c;
-        if (dist > MAX_D_VALUE) break;  // frontend_bytes.rs:222-224: stop, not skip
-        if (ld_u32(s + c) == v) {
-            uint32_t len = lcp_fwd(s, i, c, 4, cap_total);
-            if (len == cap_total && cap_total < max_total) capped = true;
-            if (len > best_len) { best_len = len; best_idx = c; }  // ties keep the newest (:226)
-        }
-        c = pv[c];
-    }
     uint2 r = make_uint2(0, 0);
-    if (best_len) {
-        uint32_t bmax = best_idx < BCAP ? best_idx : BCAP;
-        uint32_t bw = lcs_bwd(s, i, best_idx, bmax);
-        r.x = (i - best_idx) | (bw << 18) | (capped ? REC_CAPPED : 0u);
-        r.y = best_len;
+    if (valid) {
+        const uint32_t v = ld_u32(s + i);
+        const uint32_t max_total = n - i;
+        const uint32_t cap_total = max_total < FCAP ? max_total : FCAP;
+        uint32_t best_len = 0, best_idx = 0;
+        bool capped = false;
+        uint32_t c = pv[i];
+#pragma unroll 1
+        for (int k = 0; k < 4 && c != NONE; k++) {
+            uint32_t dist = i - c;
+            if (dist > MAX_D_VALUE) break;  // frontend_bytes.rs:222-224: stop, not skip
+            if (ld_u32(s + c) == v) {
+                uint32_t len = lcp_fwd(s, i, c, 4, cap_total);
+                if (len == cap_total && cap_total < max_total) capped = true;
+                if (len > best_len) { best_len = len; best_idx = c; }  // ties keep the newest (:226)
+            }
+            c = pv[c];
+        }
+        if (best_len) {
+            uint32_t bmax = best_idx < BCAP ? best_idx : BCAP;
+            uint32_t bw = lcs_bwd(s, i, best_idx, bmax);
+            r.x = (i - best_idx) | (bw << 18) | (capped ? REC_CAPPED : 0u);
+            r.y = best_len;
+        }
+        rec[st.pos_base + i] = r;
     }
-    rec[st.pos_base + i] = r;
+    // has-match bitmap: tile starts are multiples of 64, so a wave covers exactly one word
+    const uint64_t bits = __ballot(valid && r.y != 0);
+    // (words past the stream's last position belong to the next stream: never touch them)
+    if (e_lane() == 0 && i < tl.start + TILE_POS && i < n_pos) bitmap[(st.pos_base + i) >> 6] = bits;
 }
 
 // ------------------------------------------------------------------------------------ walk
@@ -1003,7 +952,9 @@ __global__ __launch_bounds__(256) void enc_pack_kernel(const EncStream *__restri
 
 // ------------------------------------------------------------------------------------ host side
 
-enum { EB_STREAMS, EB_TILES, EB_PREV, EB_SUMMARY, EB_REC, EB_LMDS, EB_BLOCKS, EB_OUTS, EB_STAGE, EB_SLOTS, EB_N };
+enum { EB_STREAMS, EB_TILES, EB_PREV, EB_SUMMARY, EB_REC, EB_LMDS, EB_BLOCKS, EB_OUTS, EB_STAGE, EB_SLOTS,
+       EB_BITMAP, EB_SEGS, EB_LOGS, EB_HDRS, EB_RANGES, EB_GAPS, EB_MATCHES, EB_PC, EB_PL, EB_RSLOTS, EB_N };
+static_assert(EB_N <= 32, "EncScratch slots");
 
 static bool eb_ensure(EncScratch &s, int i, size_t n) {
     if (n <= s.caps[i]) return true;
@@ -1017,7 +968,7 @@ static bool eb_ensure(EncScratch &s, int i, size_t n) {
 }
 
 void enc_scratch_release(EncScratch &s) {
-    for (int i = 0; i < 16; i++) {
+    for (int i = 0; i < 32; i++) {
         if (s.bufs[i]) (void)hipFree(s.bufs[i]);
         s.bufs[i] = nullptr;
         s.caps[i] = 0;
@@ -1031,23 +982,35 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
                      uint64_t *out_lens, int *statuses) {
     hipStream_t stq = ctx_stream(c);
     EncScratch &S = ctx_enc(c);
+    const char *walk_env = getenv("LZFSE_MI_WALK");
+    const bool serial_walk = walk_env && walk_env[0] == 's';  // diagnostic: the single-wave walker
     std::vector<EncStream> hs;
-    std::vector<EncTile> ht;
-    std::vector<uint32_t> hslots;
-    uint64_t pos_total = 0, lmd_total = 0, stage_total = 0;
-    uint32_t blk_total = 0;
     for (uint32_t i = 0; i < count; i++) {
         out_lens[i] = 0;
         statuses[i] = LZFSE_MI_OK;
         uint64_t n = src_len[i];
         if (n <= VN_CUTOFF) { statuses[i] = LZFSE_MI_UNSUPPORTED; continue; }  // host-side size classes (frontend_bytes.rs:63-77)
         if (n > 0x7FFFFFFFull) { statuses[i] = LZFSE_MI_UNSUPPORTED; continue; }  // reposition path (:348-375) not built
-        EncStream e;
-        e.src_off = src_off[i]; e.pos_base = pos_total; e.dst_off = dst_off[i]; e.dst_cap = dst_cap[i];
+        EncStream e{};
+        e.src_off = src_off[i]; e.dst_off = dst_off[i]; e.dst_cap = dst_cap[i];
         e.n = (uint32_t)n; e.user_index = i;
+        hs.push_back(e);
+    }
+    const uint32_t ns = (uint32_t)hs.size();
+    if (ns == 0) return LZFSE_MI_OK;
+    // longest streams first: per-stream serial stages of the longest stream bound the batch
+    std::stable_sort(hs.begin(), hs.end(), [](const EncStream &a, const EncStream &b) { return a.n > b.n; });
+    std::vector<EncTile> ht;
+    std::vector<uint32_t> hslots, hrslots;
+    std::vector<uint2> hsegs;
+    uint64_t pos_total = 0, lmd_total = 0, stage_total = 0, match_total = 0;
+    uint32_t blk_total = 0, range_total = 0;
+    for (uint32_t si = 0; si < ns; si++) {
+        EncStream &e = hs[si];
+        e.pos_base = pos_total;
         e.tile_base = (uint32_t)ht.size();
-        uint32_t n_pos = e.n - 3;
-        for (uint32_t p = 0; p < n_pos; p += TILE_POS) ht.push_back({(uint32_t)hs.size(), p == 0 ? 1u : 0u, p, 0u});
+        const uint32_t n_pos = e.n - 3;
+        for (uint32_t p = 0; p < n_pos; p += TILE_POS) ht.push_back({si, p == 0 ? 1u : 0u, p, 0u});
         e.blk_base = blk_total;
         e.blk_cap = e.n / 39000 + 2;
         e.lmd_base = lmd_total;
@@ -1056,32 +1019,38 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         e.stage_base = stage_total;
         e.stage_cap = (uint64_t)e.n + e.n / 2 + e.n / 4 + (uint64_t)e.blk_cap * 1024 + 4096;
         e.stage_cap = (e.stage_cap + 255) & ~255ull;
-        for (uint32_t b = 0; b < e.blk_cap; b++) hslots.push_back((uint32_t)hs.size());
+        e.seg_base = (uint32_t)hsegs.size();
+        e.n_seg = (n_pos + SEG - 1) / SEG;
+        for (uint32_t k = 0; k < e.n_seg; k++) hsegs.push_back(make_uint2(si, k));
+        e.range_base = range_total;
+        e.range_cap = 2 * e.n_seg + 4;
+        e.match_base = match_total;
+        e.match_cap = e.n / 4 + 8;
+        for (uint32_t b = 0; b < e.blk_cap; b++) hslots.push_back(si);
+        for (uint32_t b = 0; b < e.range_cap; b++) hrslots.push_back(si);
         blk_total += e.blk_cap;
+        range_total += e.range_cap;
         pos_total += ((uint64_t)e.n + 255) & ~255ull;
         lmd_total += e.lmd_cap;
         stage_total += e.stage_cap;
-        hs.push_back(e);
+        match_total += e.match_cap;
     }
-    const uint32_t ns = (uint32_t)hs.size(), nt = (uint32_t)ht.size();
-    if (ns == 0) return LZFSE_MI_OK;
-    // longest streams first: the serial walk of the longest stream bounds the batch
-    std::vector<uint32_t> order(ns);
-    for (uint32_t i = 0; i < ns; i++) order[i] = i;
-    // (walk kernel indexes streams directly; reorder the stream array itself)
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hs[a].n > hs[b].n; });
-    std::vector<EncStream> hs2(ns);
-    std::vector<uint32_t> inv(ns);
-    for (uint32_t i = 0; i < ns; i++) { hs2[i] = hs[order[i]]; inv[order[i]] = i; }
-    for (auto &t : ht) t.stream = inv[t.stream];
-    for (auto &sl : hslots) sl = inv[sl];
-    hs.swap(hs2);
+    const uint32_t nt = (uint32_t)ht.size(), nseg = (uint32_t)hsegs.size();
+    if (nt > 65535) return LZFSE_MI_UNSUPPORTED;  // grid.y limit of the per-tile kernels (4 GiB per call)
 
     if (!eb_ensure(S, EB_STREAMS, ns * sizeof(EncStream)) || !eb_ensure(S, EB_TILES, nt * sizeof(EncTile)) ||
         !eb_ensure(S, EB_PREV, pos_total * 4) || !eb_ensure(S, EB_SUMMARY, (size_t)nt * (1u << HASH_BITS) * 4) ||
         !eb_ensure(S, EB_REC, pos_total * 8) || !eb_ensure(S, EB_LMDS, lmd_total * 8) ||
         !eb_ensure(S, EB_BLOCKS, (size_t)blk_total * sizeof(EncBlock)) || !eb_ensure(S, EB_OUTS, ns * sizeof(EncStreamOut)) ||
-        !eb_ensure(S, EB_STAGE, stage_total + 256) || !eb_ensure(S, EB_SLOTS, (size_t)blk_total * 4))
+        !eb_ensure(S, EB_STAGE, stage_total + 256) || !eb_ensure(S, EB_SLOTS, (size_t)blk_total * 4) ||
+        !eb_ensure(S, EB_BITMAP, pos_total / 8 + 64))
+        return LZFSE_MI_IO;
+    if (!serial_walk &&
+        (!eb_ensure(S, EB_SEGS, (size_t)nseg * sizeof(uint2)) || !eb_ensure(S, EB_LOGS, (size_t)nseg * SEG_EV_CAP * sizeof(SpecEvent)) ||
+         !eb_ensure(S, EB_HDRS, (size_t)nseg * sizeof(SpecHeader)) || !eb_ensure(S, EB_RANGES, (size_t)range_total * sizeof(RangeRec)) ||
+         !eb_ensure(S, EB_GAPS, match_total * sizeof(MatchRec)) || !eb_ensure(S, EB_MATCHES, match_total * sizeof(MatchRec)) ||
+         !eb_ensure(S, EB_PC, match_total * 4) || !eb_ensure(S, EB_PL, match_total * 4) ||
+         !eb_ensure(S, EB_RSLOTS, (size_t)range_total * 4)))
         return LZFSE_MI_IO;
     EncStream *d_streams = (EncStream *)S.bufs[EB_STREAMS];
     EncTile *d_tiles = (EncTile *)S.bufs[EB_TILES];
@@ -1093,10 +1062,12 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     EncStreamOut *d_outs = (EncStreamOut *)S.bufs[EB_OUTS];
     uint8_t *d_stage = (uint8_t *)S.bufs[EB_STAGE];
     uint32_t *d_slots = (uint32_t *)S.bufs[EB_SLOTS];
+    uint64_t *d_bitmap = (uint64_t *)S.bufs[EB_BITMAP];
     E_TRY(hipMemcpyAsync(d_streams, hs.data(), ns * sizeof(EncStream), hipMemcpyHostToDevice, stq));
     E_TRY(hipMemcpyAsync(d_tiles, ht.data(), nt * sizeof(EncTile), hipMemcpyHostToDevice, stq));
     E_TRY(hipMemcpyAsync(d_slots, hslots.data(), (size_t)blk_total * 4, hipMemcpyHostToDevice, stq));
     E_TRY(hipMemsetAsync(d_outs, 0, ns * sizeof(EncStreamOut), stq));
+    E_TRY(hipMemsetAsync(d_bitmap, 0, pos_total / 8 + 64, stq));
     {
         StageTimer t(c, "enc_chain");
         hipLaunchKernelGGL(enc_chain_kernel, dim3(nt), dim3(64), 0, stq, d_src, d_streams, d_tiles, nt, d_prev, d_summary);
@@ -1107,11 +1078,40 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     }
     {
         StageTimer t(c, "enc_cand");
-        hipLaunchKernelGGL(enc_cand_kernel, dim3((TILE_POS + 255) / 256, nt), dim3(256), 0, stq, d_src, d_streams, d_tiles, d_prev, d_rec);
+        hipLaunchKernelGGL(enc_cand_kernel, dim3((TILE_POS + 255) / 256, nt), dim3(256), 0, stq, d_src, d_streams, d_tiles, d_prev, d_rec, d_bitmap);
     }
-    {
+    if (serial_walk) {
         StageTimer t(c, "enc_walk");
         hipLaunchKernelGGL(enc_walk_kernel, dim3(ns), dim3(64), 0, stq, d_src, d_streams, ns, d_prev, d_rec, d_lmds, d_blocks, d_outs);
+    } else {
+        uint2 *d_segs = (uint2 *)S.bufs[EB_SEGS];
+        SpecEvent *d_logs = (SpecEvent *)S.bufs[EB_LOGS];
+        SpecHeader *d_hdrs = (SpecHeader *)S.bufs[EB_HDRS];
+        RangeRec *d_ranges = (RangeRec *)S.bufs[EB_RANGES];
+        MatchRec *d_gaps = (MatchRec *)S.bufs[EB_GAPS], *d_matches = (MatchRec *)S.bufs[EB_MATCHES];
+        uint32_t *d_pc = (uint32_t *)S.bufs[EB_PC], *d_pl = (uint32_t *)S.bufs[EB_PL], *d_rslots = (uint32_t *)S.bufs[EB_RSLOTS];
+        E_TRY(hipMemcpyAsync(d_segs, hsegs.data(), (size_t)nseg * sizeof(uint2), hipMemcpyHostToDevice, stq));
+        E_TRY(hipMemcpyAsync(d_rslots, hrslots.data(), (size_t)range_total * 4, hipMemcpyHostToDevice, stq));
+        {
+            StageTimer t(c, "enc_spec");
+            launch_enc_spec(d_streams, d_segs, nseg, d_rec, d_bitmap, d_logs, d_hdrs, stq);
+        }
+        {
+            StageTimer t(c, "enc_stitch");
+            launch_enc_stitch(d_src, d_streams, ns, d_prev, d_rec, d_bitmap, d_logs, d_hdrs, d_ranges, d_gaps, d_outs, stq);
+        }
+        {
+            StageTimer t(c, "enc_compact");
+            launch_enc_compact(d_streams, d_rslots, range_total, d_outs, d_ranges, d_logs, d_gaps, d_matches, stq);
+        }
+        {
+            StageTimer t(c, "enc_segment");
+            launch_enc_segment(d_streams, ns, d_matches, d_pc, d_pl, d_lmds, d_blocks, d_outs, stq);
+        }
+        {
+            StageTimer t(c, "enc_lmd");
+            launch_enc_lmd(d_streams, d_slots, blk_total, d_outs, d_blocks, d_matches, d_pc, d_lmds, stq);
+        }
     }
     {
         StageTimer t(c, "enc_block");
@@ -1133,9 +1133,9 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     }
     if (getenv("LZFSE_MI_WALK_STATS")) {
         for (uint32_t i = 0; i < ns && i < 16; i++)
-            fprintf(stderr, "walk[%u] n=%u iters=%u emits=%u capped=%u refills=%u cycles=%llu (%.1f cyc/iter)\n", i, hs[i].n,
-                    ho[i].iters, ho[i].emits, ho[i].capped, ho[i].refills, (unsigned long long)ho[i].cycles,
-                    ho[i].iters ? (double)ho[i].cycles / ho[i].iters : 0.0);
+            fprintf(stderr, "walk[%u] n=%u segs=%u matches=%u ranges=%u true_iters=%u syncs=%u fallbacks=%u cycles=%llu\n", i, hs[i].n,
+                    hs[i].n_seg, ho[i].n_matches, ho[i].n_ranges, ho[i].iters, ho[i].emits, ho[i].capped,
+                    (unsigned long long)ho[i].cycles);
     }
     return LZFSE_MI_OK;
 }
@@ -1154,7 +1154,7 @@ extern "C" int lzfse_mi_debug_candidates(lzfse_mi_ctx *c, const uint8_t *h_src, 
     size_t padn = (n + 255) & ~(size_t)255;
     if (!eb_ensure(S, EB_STREAMS, sizeof(EncStream)) || !eb_ensure(S, EB_TILES, nt * sizeof(EncTile)) ||
         !eb_ensure(S, EB_PREV, padn * 4) || !eb_ensure(S, EB_SUMMARY, (size_t)nt * (1u << HASH_BITS) * 4) ||
-        !eb_ensure(S, EB_REC, padn * 8) || !eb_ensure(S, EB_STAGE, padn + 256))
+        !eb_ensure(S, EB_REC, padn * 8) || !eb_ensure(S, EB_STAGE, padn + 256) || !eb_ensure(S, EB_BITMAP, padn / 8 + 64))
         return LZFSE_MI_IO;
     uint8_t *d_src = (uint8_t *)S.bufs[EB_STAGE];
     E_TRY(hipMemcpyAsync(d_src, h_src, n, hipMemcpyHostToDevice, stq));
@@ -1165,7 +1165,7 @@ extern "C" int lzfse_mi_debug_candidates(lzfse_mi_ctx *c, const uint8_t *h_src, 
     hipLaunchKernelGGL(enc_link_kernel, dim3((TILE_POS + 255) / 256, nt), dim3(256), 0, stq, d_src, (EncStream *)S.bufs[EB_STREAMS],
                        (EncTile *)S.bufs[EB_TILES], nt, (uint32_t *)S.bufs[EB_PREV], (uint32_t *)S.bufs[EB_SUMMARY]);
     hipLaunchKernelGGL(enc_cand_kernel, dim3((TILE_POS + 255) / 256, nt), dim3(256), 0, stq, d_src, (EncStream *)S.bufs[EB_STREAMS],
-                       (EncTile *)S.bufs[EB_TILES], (uint32_t *)S.bufs[EB_PREV], (uint2 *)S.bufs[EB_REC]);
+                       (EncTile *)S.bufs[EB_TILES], (uint32_t *)S.bufs[EB_PREV], (uint2 *)S.bufs[EB_REC], (uint64_t *)S.bufs[EB_BITMAP]);
     E_TRY(hipMemcpyAsync(h_prev, S.bufs[EB_PREV], (n - 3) * 4, hipMemcpyDeviceToHost, stq));
     E_TRY(hipMemcpyAsync(h_rec_xy, S.bufs[EB_REC], (n - 3) * 8, hipMemcpyDeviceToHost, stq));
     E_TRY(hipStreamSynchronize(stq));

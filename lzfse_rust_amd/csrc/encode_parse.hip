@@ -1,0 +1,625 @@
+// Parallel form of the reference's serial parse (encode/frontend_bytes.rs:160-211 + match_object.rs
+// + fse/buffer.rs). The parse is a deterministic state machine over positions with state
+//     (index, literal_index, pending match)
+// driven by the per-position candidate records of enc_cand_kernel. Two walkers that reach the
+// same state evolve identically, so:
+//
+//   enc_spec_kernel     one LANE per 4 KiB segment walks its segment (plus a 1 KiB overrun) from
+//                       the guessed state (index = lit = segment start, no pending) and logs every
+//                       emitted match together with the state after it
+//   enc_stitch_kernel   one wave per stream: the log of segment 0 is exact; for every boundary the
+//                       first pair of events of log k / log k+1 with identical state-after is the
+//                       hand-over point. If the logs do not meet (or a log aborted on a capped
+//                       record) the true walk continues here, scalar, until they do
+//   enc_compact_kernel  adopted log ranges + gap events -> ordered match list (lit_pos, L, M, D)
+//   enc_segment_kernel  prefix sums of LMD / literal counts; serial only per bvx2 block: binary
+//                       search of the last event that fits (10 000 LMDs / 40 000 literals,
+//                       fse/buffer.rs:45-97), exact simulation of the boundary event
+//   enc_lmd_kernel      per block: every event writes its LMDs (L > 315 and M > 2 359 splits,
+//                       D zeroing against the previous LMD, buffer.rs:99-117)
+#include "enc_common.h"
+
+namespace lzmi {
+
+// ------------------------------------------------------------------------------------ shared step
+
+struct WState {
+    uint32_t index, lit, p_idx, p_midx, p_len;
+};
+
+__device__ __forceinline__ uint32_t next_has(const uint64_t *bm, uint32_t index, uint32_t stop) {
+    uint32_t w = index >> 6;
+    uint64_t bits = bm[w] & (~0ull << (index & 63));
+    while (!bits) {
+        w++;
+        if ((w << 6) >= stop) return stop;
+        bits = bm[w];
+    }
+    return (w << 6) + (uint32_t)__builtin_ctzll(bits);
+}
+
+// Match::select::<40> (match_object.rs:12-33) on an incoming match; returns true on emit
+__device__ __forceinline__ bool select40(WState &st, uint32_t i_idx, uint32_t i_midx, uint32_t i_len,
+                                         uint32_t &e_idx, uint32_t &e_midx, uint32_t &e_len) {
+    if (i_len >= GOOD_MATCH_LEN) {
+        e_idx = i_idx; e_midx = i_midx; e_len = i_len; st.p_len = 0;
+        return true;
+    }
+    if (st.p_len == 0) {
+        st.p_idx = i_idx; st.p_midx = i_midx; st.p_len = i_len;
+        return false;
+    }
+    if (st.p_idx + st.p_len <= i_idx) {
+        e_idx = st.p_idx; e_midx = st.p_midx; e_len = st.p_len;
+        st.p_idx = i_idx; st.p_midx = i_midx; st.p_len = i_len;
+        return true;
+    }
+    if (i_len > st.p_len) {
+        e_idx = i_idx; e_midx = i_midx; e_len = i_len; st.p_len = 0;
+        return true;
+    }
+    e_idx = st.p_idx; e_midx = st.p_midx; e_len = st.p_len; st.p_len = 0;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------ speculative walk
+
+__global__ __launch_bounds__(64) void enc_spec_kernel(const EncStream *__restrict__ streams, const uint2 *__restrict__ segs,
+                                                      uint32_t n_segs, const uint2 *__restrict__ rec,
+                                                      const uint64_t *__restrict__ bitmap, SpecEvent *__restrict__ logs,
+                                                      SpecHeader *__restrict__ hdrs) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_segs) return;
+    const uint2 sg = segs[g];
+    const EncStream &es = streams[sg.x];
+    const uint32_t end = es.n - 3;
+    const uint32_t S = sg.y * SEG;
+    const uint32_t stop = (S + SEG + OVER < end) ? S + SEG + OVER : end;
+    const uint2 *r = rec + es.pos_base;
+    const uint64_t *bm = bitmap + (es.pos_base >> 6);
+    SpecEvent *ev = logs + (uint64_t)g * SEG_EV_CAP;
+    WState st;
+    st.index = S; st.lit = S; st.p_idx = 0; st.p_midx = 0; st.p_len = 0;
+    uint32_t nev = 0, status = 0;
+    while (st.index < stop) {
+        uint32_t p = next_has(bm, st.index, stop);
+        if (p >= stop) { st.index = stop; break; }
+        st.index = p;
+        const uint2 rr = r[p];
+        if (rr.x & REC_CAPPED) { status = 1; break; }  // needs the exact wave-wide length: left to the stitcher
+        const uint32_t dist = rr.x & 0x3FFFF, bw = (rr.x >> 18) & 0xFF, fwd = rr.y;
+        const uint32_t midx = p - dist;
+        const uint32_t room = p - st.lit;
+        if (bw == BCAP && room > BCAP && midx > BCAP) { status = 1; break; }
+        const uint32_t b = bw < room ? bw : room;  // frontend_bytes.rs:259-268
+        uint32_t e_idx = 0, e_midx = 0, e_len = 0;
+        const uint32_t lit_before = st.lit;
+        if (select40(st, p - b, midx - b, fwd + b, e_idx, e_midx, e_len)) {
+            st.lit = e_idx + e_len;
+            st.index = (p + 1 > st.lit) ? p + 1 : st.lit;
+            if (nev < SEG_EV_CAP) {
+                SpecEvent e;
+                e.e_idx = e_idx; e.e_len = e_len; e.e_dist = e_idx - e_midx; e.e_lit = lit_before;
+                e.index_after = st.index;
+                e.p_idx = st.p_len ? st.p_idx : 0; e.p_midx = st.p_len ? st.p_midx : 0; e.p_len = st.p_len;
+                ev[nev] = e;
+            }
+            nev++;
+        } else {
+            st.index = p + 1;
+        }
+    }
+    SpecHeader h;
+    h.n_events = nev < SEG_EV_CAP ? nev : SEG_EV_CAP;
+    h.status = nev > SEG_EV_CAP ? 2u : status;  // 2: log overflow (cannot happen: every emit advances lit by >= 4)
+    h.f_index = st.index; h.f_lit = st.lit;
+    h.f_pidx = st.p_len ? st.p_idx : 0; h.f_pmidx = st.p_len ? st.p_midx : 0; h.f_plen = st.p_len;
+    h.pad = 0;
+    hdrs[g] = h;
+}
+
+// ------------------------------------------------------------------------------------ stitch
+
+__device__ __forceinline__ bool ev_state_eq(const SpecEvent &a, const SpecEvent &b) {
+    return a.index_after == b.index_after && a.e_idx + a.e_len == b.e_idx + b.e_len && a.p_len == b.p_len &&
+           (a.p_len == 0 || (a.p_idx == b.p_idx && a.p_midx == b.p_midx));
+}
+
+// first event of a log with index_after >= key
+__device__ __forceinline__ uint32_t ev_lower_bound(const SpecEvent *ev, uint32_t n, uint32_t key) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (ev[mid].index_after < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ uint32_t st_wave_lcp_fwd(const uint8_t *s, uint32_t a, uint32_t b, uint32_t len, uint32_t max) {
+    const int lane = e_lane();
+    while (len < max) {
+        uint32_t off = len + 8 * lane;
+        uint64_t x = 0;
+        if (off + 8 <= max) x = ld_u64(s + a + off) ^ ld_u64(s + b + off);
+        else
+            for (uint32_t k = 0; off + k < max && k < 8; k++)
+                x |= (uint64_t)(s[a + off + k] ^ s[b + off + k]) << (8 * k);
+        uint64_t bad = __ballot(x != 0);
+        if (bad) {
+            int bl = __builtin_ctzll(bad);
+            uint32_t xl = e_readlane((uint32_t)x, bl), xh = e_readlane((uint32_t)(x >> 32), bl);
+            uint64_t xx = (uint64_t)xl | ((uint64_t)xh << 32);
+            uint32_t r = len + 8 * bl + (uint32_t)(__builtin_ctzll(xx) >> 3);
+            return r < max ? r : max;
+        }
+        len += 512;
+    }
+    return max;
+}
+
+__device__ uint32_t st_wave_lcs_bwd(const uint8_t *s, uint32_t a, uint32_t b, uint32_t max) {
+    const int lane = e_lane();
+    uint32_t len = 0;
+    while (len < max) {
+        uint32_t off = len + lane;
+        bool bad = off < max && s[a - off - 1] != s[b - off - 1];
+        uint64_t bm = __ballot(bad);
+        if (bm) {
+            uint32_t r = len + (uint32_t)__builtin_ctzll(bm);
+            return r < max ? r : max;
+        }
+        len += 64;
+    }
+    return max;
+}
+
+struct Stitch {
+    RangeRec *ranges;
+    uint32_t n_ranges, range_cap;
+    MatchRec *gaps;
+    uint32_t n_gaps, gap_cap;
+    uint32_t out_count;  // matches emitted so far
+    uint32_t gap_open;   // first gap event of the currently open gap range
+    int status;
+};
+
+__device__ __forceinline__ void sx_add_range(Stitch &x, uint32_t kind, uint64_t begin, uint32_t count) {
+    if (!count) return;
+    if (x.n_ranges >= x.range_cap) { x.status = LZFSE_MI_IO; return; }
+    if (e_lane() == 0) {
+        RangeRec r;
+        r.begin = begin; r.count = count; r.out_off = x.out_count; r.kind = kind;
+        x.ranges[x.n_ranges] = r;
+    }
+    x.n_ranges++;
+    x.out_count += count;
+}
+
+__device__ __forceinline__ void sx_close_gap(Stitch &x) {
+    if (x.n_gaps > x.gap_open) sx_add_range(x, 1, x.gap_open, x.n_gaps - x.gap_open);
+    x.gap_open = x.n_gaps;
+}
+
+__device__ __forceinline__ void sx_gap_event(Stitch &x, uint32_t lit_before, uint32_t e_idx, uint32_t e_len, uint32_t dist) {
+    if (x.n_gaps >= x.gap_cap) { x.status = LZFSE_MI_IO; return; }
+    if (e_lane() == 0) {
+        MatchRec m;
+        m.lit_pos = lit_before; m.l = e_idx - lit_before; m.m = e_len; m.d = dist;
+        x.gaps[x.n_gaps] = m;
+    }
+    x.n_gaps++;
+}
+
+// One wave per stream; control flow and values are wave-uniform.
+__global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
+                                                        uint32_t n_streams, const uint32_t *__restrict__ prev,
+                                                        const uint2 *__restrict__ rec, const uint64_t *__restrict__ bitmap,
+                                                        const SpecEvent *__restrict__ logs, const SpecHeader *__restrict__ hdrs,
+                                                        RangeRec *__restrict__ ranges, MatchRec *__restrict__ gaps,
+                                                        EncStreamOut *__restrict__ outs) {
+    const uint32_t si = blockIdx.x;
+    if (si >= n_streams) return;
+    const EncStream &es = streams[si];
+    const uint8_t *s = src + es.src_off;
+    const uint32_t *pv = prev + es.pos_base;
+    const uint2 *r = rec + es.pos_base;
+    const uint64_t *bm = bitmap + (es.pos_base >> 6);
+    const uint32_t n = es.n, end = n - 3, K = es.n_seg;
+    const SpecEvent *L0 = logs + (uint64_t)es.seg_base * SEG_EV_CAP;
+    const SpecHeader *H0 = hdrs + es.seg_base;
+    Stitch x;
+    x.ranges = ranges + es.range_base; x.n_ranges = 0; x.range_cap = es.range_cap;
+    x.gaps = gaps + es.match_base; x.n_gaps = 0; x.gap_cap = es.match_cap;
+    x.out_count = 0; x.gap_open = 0; x.status = 0;
+    uint32_t st_iters = 0, st_syncs = 0, st_fallbacks = 0;
+    const uint64_t t_begin = __builtin_amdgcn_s_memtime();
+
+    uint32_t k = 0, a = 0;     // following log k; events [a, ..) of it are true and not yet adopted
+    WState T;                  // valid in walking mode
+    T.index = 0; T.lit = 0; T.p_idx = 0; T.p_midx = 0; T.p_len = 0;
+    bool walking = false, done = false;
+    while (!done && !x.status) {
+        if (!walking) {
+            const SpecHeader hk = H0[k];
+            const SpecEvent *Lk = L0 + (uint64_t)k * SEG_EV_CAP;
+            bool found = false;
+            if (k + 1 < K) {
+                const uint32_t nk1 = H0[k + 1].n_events;
+                const SpecEvent *Lk1 = Lk + SEG_EV_CAP;
+                uint32_t i = ev_lower_bound(Lk, hk.n_events, (k + 1) * SEG), j = 0;
+                while (i < hk.n_events && j < nk1) {
+                    const SpecEvent ei = Lk[i], ej = Lk1[j];
+                    if (ei.index_after < ej.index_after) i++;
+                    else if (ei.index_after > ej.index_after) j++;
+                    else if (ev_state_eq(ei, ej)) { found = true; break; }
+                    else { i++; j++; }
+                }
+                if (found) {
+                    // logs run in lock-step from (i, j) on; hand over no earlier than event a - 1
+                    uint32_t i_eff = (a > 0 && i + 1 < a) ? a - 1 : i;
+                    uint32_t j_eff = j + (i_eff - i);
+                    if (i_eff >= a) sx_add_range(x, 0, (uint64_t)(es.seg_base + k) * SEG_EV_CAP + a, i_eff - a + 1);
+                    k = k + 1;
+                    a = j_eff + 1;
+                    st_syncs++;
+                }
+            }
+            if (!found) {
+                // adopt the rest of log k and continue from its final state
+                if (hk.n_events > a) sx_add_range(x, 0, (uint64_t)(es.seg_base + k) * SEG_EV_CAP + a, hk.n_events - a);
+                T.index = hk.f_index; T.lit = hk.f_lit; T.p_idx = hk.f_pidx; T.p_midx = hk.f_pmidx; T.p_len = hk.f_plen;
+                walking = true;
+                st_fallbacks++;
+                x.gap_open = x.n_gaps;
+            }
+            continue;
+        }
+        // ---- true walk (exact, scalar): frontend_bytes.rs:183-208 ----
+        if (T.index >= end) { done = true; break; }
+        uint32_t p = next_has(bm, T.index, end);
+        if (p >= end) { T.index = end; done = true; break; }
+        st_iters++;
+        T.index = p;
+        const uint2 rr = r[p];
+        uint32_t dist = rr.x & 0x3FFFF, bw = (rr.x >> 18) & 0xFF, fwd = rr.y;
+        uint32_t midx = p - dist;
+        if (rr.x & REC_CAPPED) {
+            // exact forward part of find_match (frontend_bytes.rs:214-231) by the whole wave
+            uint32_t v = ld_u32(s + p), best_len = 0, best_idx = 0, c = pv[p];
+            for (int q = 0; q < 4 && c != NONE; q++) {
+                if (p - c > MAX_D_VALUE) break;
+                if (ld_u32(s + c) == v) {
+                    uint32_t len = st_wave_lcp_fwd(s, p, c, 4, n - p);
+                    if (len > best_len) { best_len = len; best_idx = c; }
+                }
+                c = pv[c];
+            }
+            fwd = best_len; midx = best_idx; dist = p - midx;
+            bw = st_wave_lcs_bwd(s, p, midx, midx < BCAP ? midx : BCAP);
+        }
+        const uint32_t room = p - T.lit;
+        uint32_t b = bw < room ? bw : room;
+        if (bw == BCAP && room > BCAP && midx > BCAP) b = st_wave_lcs_bwd(s, p, midx, room < midx ? room : midx);
+        uint32_t e_idx = 0, e_midx = 0, e_len = 0;
+        const uint32_t lit_before = T.lit;
+        if (select40(T, p - b, midx - b, fwd + b, e_idx, e_midx, e_len)) {
+            sx_gap_event(x, lit_before, e_idx, e_len, e_idx - e_midx);
+            T.lit = e_idx + e_len;
+            if (T.lit >= end) { T.index = end; done = true; break; }
+            T.index = (p + 1 > T.lit) ? p + 1 : T.lit;
+            // does the log of the segment we are in agree with this state?
+            uint32_t kk = T.index / SEG;
+            if (kk >= K) kk = K - 1;
+            if (kk > k || (kk == k && false)) {
+                const SpecHeader hh = H0[kk];
+                const SpecEvent *Lkk = L0 + (uint64_t)kk * SEG_EV_CAP;
+                uint32_t j = ev_lower_bound(Lkk, hh.n_events, T.index);
+                if (j < hh.n_events) {
+                    SpecEvent t;
+                    t.index_after = T.index; t.e_idx = T.lit; t.e_len = 0;
+                    t.p_idx = T.p_idx; t.p_midx = T.p_midx; t.p_len = T.p_len;
+                    if (ev_state_eq(t, Lkk[j])) {
+                        sx_close_gap(x);
+                        k = kk; a = j + 1;
+                        walking = false;
+                        st_syncs++;
+                    }
+                }
+            }
+        } else {
+            T.index = p + 1;
+        }
+    }
+    if (!x.status) {
+        if (!walking) {
+            // left the loop while following: cannot happen (the last segment always ends in walking mode)
+            x.status = LZFSE_MI_IO;
+        } else {
+            // flush_pending (frontend_bytes.rs:271-285), then flush_literals (:304-317)
+            if (T.p_len != 0) {
+                sx_gap_event(x, T.lit, T.p_idx, T.p_len, T.p_idx - T.p_midx);
+                T.lit = T.p_idx + T.p_len;
+                T.p_len = 0;
+            }
+            if (n - T.lit) sx_gap_event(x, T.lit, n, 0, 1);
+            sx_close_gap(x);
+        }
+    }
+    if (e_lane() == 0) {
+        EncStreamOut o;
+        o.n_blocks = 0; o.status = x.status; o.out_len = 0;
+        o.n_matches = x.out_count; o.n_ranges = x.n_ranges;
+        o.iters = st_iters; o.emits = st_syncs; o.capped = st_fallbacks; o.refills = 0;
+        o.cycles = __builtin_amdgcn_s_memtime() - t_begin;
+        outs[si] = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------ compaction
+
+// number of LMDs an event expands to when no block limit interferes (fse/buffer.rs:56-97)
+__device__ __forceinline__ uint32_t lmd_count_of(uint32_t l, uint32_t m) {
+    uint32_t a = l ? (l - 1) / MAX_L_VALUE : 0;
+    uint32_t b = m ? (m + MAX_M_VALUE - 1) / MAX_M_VALUE : 1;
+    return a + b;
+}
+
+// one wave per range slot
+__global__ __launch_bounds__(64) void enc_compact_kernel(const EncStream *__restrict__ streams, const uint32_t *__restrict__ slot_stream,
+                                                         const EncStreamOut *__restrict__ outs, const RangeRec *__restrict__ ranges,
+                                                         const SpecEvent *__restrict__ logs, const MatchRec *__restrict__ gaps,
+                                                         MatchRec *__restrict__ matches) {
+    const uint32_t slot = blockIdx.x;
+    const uint32_t si = slot_stream[slot];
+    const EncStream &es = streams[si];
+    const uint32_t ri = slot - es.range_base;
+    const EncStreamOut so = outs[si];
+    if (so.status || ri >= so.n_ranges) return;
+    const RangeRec rg = ranges[slot];
+    MatchRec *out = matches + es.match_base + rg.out_off;
+    const int lane = e_lane();
+    if (rg.kind == 0) {
+        const SpecEvent *ev = logs + rg.begin;
+        for (uint32_t q = lane; q < rg.count; q += 64) {
+            const SpecEvent e = ev[q];
+            MatchRec m;
+            m.lit_pos = e.e_lit; m.l = e.e_idx - e.e_lit; m.m = e.e_len; m.d = e.e_dist;
+            out[q] = m;
+        }
+    } else {
+        const MatchRec *g = gaps + es.match_base + rg.begin;
+        for (uint32_t q = lane; q < rg.count; q += 64) out[q] = g[q];
+    }
+}
+
+// ------------------------------------------------------------------------------------ block segmentation
+
+constexpr int SEGM_THREADS = 1024;
+
+struct Emit {  // serial LMD emitter used for the (rare) events that straddle a block boundary
+    uint2 *lmds;
+    uint32_t lmd_cap, lmd_count;
+    uint32_t n_lmd, n_lit, n_match, prev_d;
+    int status;
+};
+
+__device__ __forceinline__ void em_put(Emit &w, uint32_t l, uint32_t m, uint32_t d) {
+    if (w.lmd_count >= w.lmd_cap) { w.status = LZFSE_MI_IO; return; }
+    w.lmds[w.lmd_count++] = make_uint2(l | (m << 16), d);
+    w.n_lmd++;
+}
+__device__ __forceinline__ void em_push_l(Emit &w, uint32_t l) { w.prev_d = 1; em_put(w, l, 0, 1); }
+__device__ __forceinline__ void em_push_lmd(Emit &w, uint32_t l, uint32_t m, uint32_t d) {
+    uint32_t ds = (w.prev_d == d) ? 0u : d;
+    w.prev_d = d;
+    em_put(w, l, m, ds);
+    w.n_match += m;
+}
+// fse/buffer.rs:45-97
+__device__ bool em_buffer_push(Emit &w, uint32_t &n_lit, uint32_t &match_len, uint32_t d) {
+    while (n_lit > MAX_L_VALUE) {
+        if (w.n_lmd == LMDS_PER_BLOCK) return false;
+        uint32_t limit = LITERALS_PER_BLOCK - w.n_lit;
+        if (MAX_L_VALUE <= limit) { w.n_lit += MAX_L_VALUE; n_lit -= MAX_L_VALUE; em_push_l(w, MAX_L_VALUE); }
+        else if (limit != 0) { w.n_lit += limit; n_lit -= limit; em_push_l(w, limit); return false; }
+        else return false;
+    }
+    if (w.n_lmd == LMDS_PER_BLOCK) return false;
+    uint32_t literal_len = n_lit;
+    uint32_t limit = LITERALS_PER_BLOCK - w.n_lit;
+    if (literal_len <= limit) { w.n_lit += literal_len; n_lit = 0; }
+    else if (limit != 0) { w.n_lit += limit; n_lit -= limit; em_push_l(w, limit); return false; }
+    else return false;
+    while (match_len > MAX_M_VALUE) {
+        em_push_lmd(w, literal_len, MAX_M_VALUE, d);
+        match_len -= MAX_M_VALUE;
+        literal_len = 0;
+        if (w.n_lmd == LMDS_PER_BLOCK) return false;
+    }
+    em_push_lmd(w, literal_len, match_len, d);
+    match_len = 0;
+    return true;
+}
+
+// One workgroup per stream: prefix sums of per-event LMD and literal counts, then thread 0 cuts
+// the event list into bvx2 blocks.
+__global__ __launch_bounds__(SEGM_THREADS) void enc_segment_kernel(const EncStream *__restrict__ streams, uint32_t n_streams,
+                                                                  const MatchRec *__restrict__ matches, uint32_t *__restrict__ pc,
+                                                                  uint32_t *__restrict__ pl, uint2 *__restrict__ lmds,
+                                                                  EncBlock *__restrict__ blocks, EncStreamOut *__restrict__ outs) {
+    __shared__ uint32_t sh[2 * (SEGM_THREADS / 64) + 2];
+    const uint32_t si = blockIdx.x;
+    if (si >= n_streams) return;
+    const EncStream &es = streams[si];
+    EncStreamOut so = outs[si];
+    if (so.status) return;
+    const uint32_t E = so.n_matches;
+    const MatchRec *mt = matches + es.match_base;
+    uint32_t *PC = pc + es.match_base, *PL = pl + es.match_base;  // inclusive prefix sums
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t carry_c = 0, carry_l = 0;
+    for (uint32_t g0 = 0; g0 < E; g0 += SEGM_THREADS) {
+        uint32_t j = g0 + tid;
+        uint32_t c = 0, l = 0;
+        if (j < E) { MatchRec m = mt[j]; c = lmd_count_of(m.l, m.m); l = m.l; }
+        uint32_t ic = c, il = l;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t xx = __shfl_up(ic, d), yy = __shfl_up(il, d);
+            if (lane >= d) { ic += xx; il += yy; }
+        }
+        if (lane == 63) { sh[wave] = ic; sh[SEGM_THREADS / 64 + wave] = il; }
+        __syncthreads();
+        uint32_t oc = 0, ol = 0, tc = 0, tl = 0;
+        for (int w = 0; w < SEGM_THREADS / 64; w++) {
+            uint32_t xx = sh[w], yy = sh[SEGM_THREADS / 64 + w];
+            if (w < wave) { oc += xx; ol += yy; }
+            tc += xx; tl += yy;
+        }
+        if (j < E) { PC[j] = carry_c + oc + ic; PL[j] = carry_l + ol + il; }
+        carry_c += tc; carry_l += tl;
+        __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid != 0) return;
+    // ---- serial over blocks ----
+    Emit w;
+    w.lmds = lmds + es.lmd_base; w.lmd_cap = es.lmd_cap; w.lmd_count = 0;
+    w.n_lmd = 0; w.n_lit = 0; w.n_match = 0; w.prev_d = 0; w.status = 0;
+    EncBlock *bk = blocks + es.blk_base;
+    uint32_t n_blk = 0;
+    uint64_t stage_used = 0;
+    uint32_t j = 0;             // next unprocessed event
+    bool rem = false;           // remainder of a boundary event pending
+    uint32_t rem_l = 0, rem_m = 0, rem_d = 0;
+    uint32_t raw_pos = 0;       // first raw byte of the current block
+    bool more = true;
+    while (more && !w.status) {
+        const uint32_t blk_lmd_start = w.lmd_count;
+        w.n_lmd = 0; w.n_lit = 0; w.n_match = 0; w.prev_d = 0;
+        bool full = false;
+        if (rem) {
+            if (em_buffer_push(w, rem_l, rem_m, rem_d)) rem = false; else full = true;
+        }
+        uint32_t ev_begin = j, ev_end = j, head_lmds = w.n_lmd, head_prev_d = w.prev_d;
+        if (!full) {
+            // events [j, j2) fit completely: n_lmd + sum c <= 10 000 and n_lit + sum l <= 40 000
+            const uint32_t base_c = j ? PC[j - 1] : 0, base_l = j ? PL[j - 1] : 0;
+            const uint32_t room_c = LMDS_PER_BLOCK - w.n_lmd, room_l = LITERALS_PER_BLOCK - w.n_lit;
+            uint32_t lo = j, hi = E;  // first event that does NOT fit
+            while (lo < hi) {
+                uint32_t mid = (lo + hi) >> 1;
+                if (PC[mid] - base_c <= room_c && PL[mid] - base_l <= room_l) lo = mid + 1; else hi = mid;
+            }
+            const uint32_t j2 = lo;
+            ev_end = j2;
+            if (j2 > j) {
+                const uint32_t dc = PC[j2 - 1] - base_c, dl = PL[j2 - 1] - base_l;
+                const MatchRec last = mt[j2 - 1];
+                const uint32_t end_pos = last.lit_pos + last.l + last.m;
+                // raw bytes of the full events = end_pos - (start of event j's literals)
+                const uint32_t start_pos = mt[j].lit_pos;
+                w.n_lmd += dc; w.n_lit += dl; w.n_match += (end_pos - start_pos) - dl;
+                w.lmd_count += dc;  // written by enc_lmd_kernel
+                w.prev_d = last.d;  // every event ends with push_lmd(.., d)
+                if (w.lmd_count > w.lmd_cap) { w.status = LZFSE_MI_IO; break; }
+            }
+            j = j2;
+            if (j < E) {
+                // boundary event: fills the block (by construction it cannot complete)
+                MatchRec m = mt[j];
+                rem_l = m.l; rem_m = m.m; rem_d = m.d;
+                j++;
+                if (em_buffer_push(w, rem_l, rem_m, rem_d)) rem = false; else { rem = true; full = true; }
+            }
+        }
+        if (!full && j >= E && !rem) more = false;  // final block (fse/backend.rs:92-95)
+        // close the block
+        if (n_blk >= es.blk_cap) { w.status = LZFSE_MI_IO; break; }
+        const uint32_t need = stage_need(w.n_lit, w.n_lmd);
+        if (stage_used + need > es.stage_cap) { w.status = LZFSE_MI_IO; break; }
+        EncBlock b;
+        b.lmd_start = es.lmd_base + blk_lmd_start;
+        b.stage_off = es.stage_base + stage_used;
+        b.src_start = raw_pos;
+        b.n_lmd = w.n_lmd; b.n_lit = w.n_lit; b.n_match = w.n_match;
+        b.hdr_len = 0; b.lit_len = 0; b.lmd_len = 0; b.pad = 0;
+        b.ev_begin = ev_begin; b.ev_end = ev_end; b.head_lmds = head_lmds; b.head_prev_d = head_prev_d;
+        bk[n_blk++] = b;
+        stage_used += need;
+        raw_pos += w.n_lit + w.n_match;
+    }
+    so.n_blocks = n_blk;
+    so.status = w.status;
+    outs[si] = so;
+}
+
+// ------------------------------------------------------------------------------------ LMD writing
+
+// One workgroup per block slot: the block's complete events write their LMDs
+// (fse/buffer.rs:56-117 without block limits, which enc_segment_kernel resolved).
+__global__ __launch_bounds__(256) void enc_lmd_kernel(const EncStream *__restrict__ streams, const uint32_t *__restrict__ slot_stream,
+                                                      const EncStreamOut *__restrict__ outs, const EncBlock *__restrict__ blocks,
+                                                      const MatchRec *__restrict__ matches, const uint32_t *__restrict__ pc,
+                                                      uint2 *__restrict__ lmds) {
+    const uint32_t slot = blockIdx.x;
+    const uint32_t si = slot_stream[slot];
+    const EncStream &es = streams[si];
+    const uint32_t bi = slot - es.blk_base;
+    const EncStreamOut so = outs[si];
+    if (so.status || bi >= so.n_blocks) return;
+    const EncBlock b = blocks[slot];
+    if (b.ev_end <= b.ev_begin) return;
+    const MatchRec *mt = matches + es.match_base;
+    const uint32_t *PC = pc + es.match_base;
+    uint2 *out = lmds + b.lmd_start + b.head_lmds;
+    const uint32_t base_c = b.ev_begin ? PC[b.ev_begin - 1] : 0;
+    for (uint32_t j = b.ev_begin + threadIdx.x; j < b.ev_end; j += blockDim.x) {
+        const MatchRec m = mt[j];
+        uint32_t o = (j ? PC[j - 1] : 0) - base_c;
+        uint32_t prev_d = (j == b.ev_begin) ? b.head_prev_d : mt[j - 1].d;
+        uint32_t l = m.l, mm = m.m;
+        while (l > MAX_L_VALUE) {  // push_l: (315, 0, 1), prev_d = 1
+            out[o++] = make_uint2(MAX_L_VALUE, 1);
+            l -= MAX_L_VALUE;
+            prev_d = 1;
+        }
+        while (mm > MAX_M_VALUE) {
+            out[o++] = make_uint2(l | (MAX_M_VALUE << 16), prev_d == m.d ? 0u : m.d);
+            prev_d = m.d;
+            mm -= MAX_M_VALUE;
+            l = 0;
+        }
+        out[o] = make_uint2(l | (mm << 16), prev_d == m.d ? 0u : m.d);
+    }
+}
+
+// ------------------------------------------------------------------------------------ launchers
+
+void launch_enc_spec(const EncStream *streams, const uint2 *segs, uint32_t n_segs, const uint2 *rec, const uint64_t *bitmap,
+                     SpecEvent *logs, SpecHeader *hdrs, hipStream_t st) {
+    if (!n_segs) return;
+    hipLaunchKernelGGL(enc_spec_kernel, dim3((n_segs + 63) / 64), dim3(64), 0, st, streams, segs, n_segs, rec, bitmap, logs, hdrs);
+}
+void launch_enc_stitch(const uint8_t *src, const EncStream *streams, uint32_t ns, const uint32_t *prev, const uint2 *rec,
+                       const uint64_t *bitmap, const SpecEvent *logs, const SpecHeader *hdrs, RangeRec *ranges, MatchRec *gaps,
+                       EncStreamOut *outs, hipStream_t st) {
+    hipLaunchKernelGGL(enc_stitch_kernel, dim3(ns), dim3(64), 0, st, src, streams, ns, prev, rec, bitmap, logs, hdrs, ranges, gaps, outs);
+}
+void launch_enc_compact(const EncStream *streams, const uint32_t *slot_stream, uint32_t n_slots, const EncStreamOut *outs,
+                        const RangeRec *ranges, const SpecEvent *logs, const MatchRec *gaps, MatchRec *matches, hipStream_t st) {
+    if (!n_slots) return;
+    hipLaunchKernelGGL(enc_compact_kernel, dim3(n_slots), dim3(64), 0, st, streams, slot_stream, outs, ranges, logs, gaps, matches);
+}
+void launch_enc_segment(const EncStream *streams, uint32_t ns, const MatchRec *matches, uint32_t *pc, uint32_t *pl, uint2 *lmds,
+                        EncBlock *blocks, EncStreamOut *outs, hipStream_t st) {
+    hipLaunchKernelGGL(enc_segment_kernel, dim3(ns), dim3(SEGM_THREADS), 0, st, streams, ns, matches, pc, pl, lmds, blocks, outs);
+}
+void launch_enc_lmd(const EncStream *streams, const uint32_t *slot_stream, uint32_t n_slots, const EncStreamOut *outs,
+                    const EncBlock *blocks, const MatchRec *matches, const uint32_t *pc, uint2 *lmds, hipStream_t st) {
+    if (!n_slots) return;
+    hipLaunchKernelGGL(enc_lmd_kernel, dim3(n_slots), dim3(256), 0, st, streams, slot_stream, outs, blocks, matches, pc, lmds);
+}
+
+}  // namespace lzmi

@@ -26,8 +26,8 @@ void launch_dec_lz(int variant, const uint8_t *src, const StreamIn *streams, con
 
 // ---- encode.hip ----
 struct EncScratch {
-    void *bufs[16] = {};
-    size_t caps[16] = {};
+    void *bufs[32] = {};
+    size_t caps[32] = {};
 };
 EncScratch &ctx_enc(lzfse_mi_ctx *c);
 void enc_scratch_release(EncScratch &s);
