@@ -4,14 +4,15 @@
 
 namespace lzmi {
 
-constexpr uint32_t TILE_POS = 65472;        // positions per chain tile: multiple of 64, offset + 1 fits u16
+constexpr uint32_t TILE_POS = 65472;        // positions per chain tile: multiple of 64 and of CAND_P, offset + 1 fits u16
 constexpr uint32_t SEG = 4096;              // positions per speculative-parse segment
 constexpr uint32_t OVER = 1024;             // overrun of a segment walker into the next segment
 constexpr uint32_t SEG_EV_CAP = (SEG + OVER) / 4 + 4;  // every emit advances literal_index by >= 4
 constexpr uint32_t NONE = 0xFFFFFFFFu;      // no previous position
 constexpr uint32_t NONE_TILE = 0xFFFFFFFEu; // no previous position inside the tile (link pending)
-constexpr uint32_t FCAP = 1024;             // cap of the forward length computed per position
-constexpr uint32_t BCAP = 255;              // cap of the backward length computed per position
+constexpr uint32_t FCAP = 1024;             // cap of the forward length computed per position (>= GOOD_MATCH_LEN)
+constexpr uint32_t XCAP = 4096;             // cap of the exact per-lane extension in the segment walkers
+constexpr uint32_t BCAP = 32;               // cap of the backward length computed per position
 constexpr uint32_t REC_CAPPED = 0x80000000u;
 
 __device__ __forceinline__ int e_lane() { return threadIdx.x & 63; }
@@ -92,9 +93,9 @@ __host__ __device__ inline uint32_t stage_need(uint32_t n_lit, uint32_t n_lmd) {
 
 
 // encode_parse.hip
-void launch_enc_spec(const EncStream *streams, const uint2 *segs, uint32_t n_segs, const uint2 *rec, const uint64_t *bitmap,
-                     SpecEvent *logs, SpecHeader *hdrs, hipStream_t st);
-void launch_enc_stitch(const uint8_t *src, const EncStream *streams, uint32_t ns, const uint32_t *prev, const uint2 *rec,
+void launch_enc_spec(const uint8_t *src, const EncStream *streams, const uint2 *segs, uint32_t n_segs, const uint2 *prev,
+                     const uint2 *rec, const uint64_t *bitmap, SpecEvent *logs, SpecHeader *hdrs, hipStream_t st);
+void launch_enc_stitch(const uint8_t *src, const EncStream *streams, uint32_t ns, const uint2 *prev, const uint2 *rec,
                        const uint64_t *bitmap, const SpecEvent *logs, const SpecHeader *hdrs, RangeRec *ranges, MatchRec *gaps,
                        EncStreamOut *outs, hipStream_t st);
 void launch_enc_compact(const EncStream *streams, const uint32_t *slot_stream, uint32_t n_slots, const EncStreamOut *outs,

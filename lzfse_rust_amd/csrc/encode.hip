@@ -38,7 +38,7 @@ namespace lzmi {
 // or the LDS last-seen entry written by earlier steps.
 __global__ __launch_bounds__(64) void enc_chain_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
                                                        const EncTile *__restrict__ tiles, uint32_t n_tiles,
-                                                       uint32_t *__restrict__ prev, uint32_t *__restrict__ summary) {
+                                                       uint2 *__restrict__ prev, uint32_t *__restrict__ summary) {
     __shared__ uint16_t last[1u << HASH_BITS];  // offset in tile + 1, 0 = none
     const uint32_t t = blockIdx.x;
     if (t >= n_tiles) return;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(64) void enc_chain_kernel(const uint8_t *__restrict
     const int lane = e_lane();
     for (uint32_t k = lane; k < (1u << HASH_BITS); k += 64) last[k] = 0;
     const uint8_t *s = src + st.src_off;
-    uint32_t *pv = prev + st.pos_base;
+    uint2 *pv = prev + st.pos_base;  // {previous position in the bucket, 4-byte value at this position}
     const uint32_t n_pos = st.n - 3;  // positions 0 .. n-4 are hashed (frontend_bytes.rs:166-170)
     const uint32_t t_end = tl.start + TILE_POS < n_pos ? tl.start + TILE_POS : n_pos;
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64) void enc_chain_kernel(const uint8_t *__restrict
         if (lower) pr = p0 + (63 - __builtin_clzll(lower));
         else pr = old ? (tl.start + old - 1) : NONE_TILE;
         if (valid) {
-            pv[p] = pr;
+            pv[p] = make_uint2(pr, v);
             if ((same >> lane) >> 1 == 0) last[key] = (uint16_t)(p - tl.start + 1);  // newest of its bucket
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(64) void enc_chain_kernel(const uint8_t *__restrict
 // earlier tile of the same stream. Anything further back than 5 tiles is outside the
 // 262 139-byte window (fse/constants.rs:42) and would end the candidate scan anyway.
 __global__ void enc_link_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
-                                const EncTile *__restrict__ tiles, uint32_t n_tiles, uint32_t *__restrict__ prev,
+                                const EncTile *__restrict__ tiles, uint32_t n_tiles, uint2 *__restrict__ prev,
                                 const uint32_t *__restrict__ summary) {
     const uint32_t t = blockIdx.y;
     const EncTile tl = tiles[t];
@@ -98,16 +98,17 @@ __global__ void enc_link_kernel(const uint8_t *__restrict__ src, const EncStream
     const uint32_t p = tl.start + blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n_pos = st.n - 3;
     if (p >= n_pos || p >= tl.start + TILE_POS) return;
-    uint32_t *pv = prev + st.pos_base;
-    if (pv[p] != NONE_TILE) return;
-    const uint32_t key = bucket_of(ld_u32(src + st.src_off + p));
+    uint2 *pv = prev + st.pos_base;
+    const uint2 cur = pv[p];
+    if (cur.x != NONE_TILE) return;
+    const uint32_t key = bucket_of(cur.y);
     uint32_t r = NONE;
     const uint32_t t_idx = tl.start / TILE_POS;  // tile index inside the stream
     for (uint32_t back = 1; back <= 5 && back <= t_idx; back++) {
         uint32_t sv = summary[(uint64_t)(t - back) * (1u << HASH_BITS) + key];
         if (sv != NONE) { r = sv; break; }
     }
-    pv[p] = r;
+    pv[p].x = r;
 }
 
 // ------------------------------------------------------------------------------------ candidates
@@ -135,9 +136,39 @@ __device__ __forceinline__ uint32_t lcs_bwd(const uint8_t *s, uint32_t a, uint32
     return len;
 }
 
+// exact forward length by the whole wave, 512 bytes per step (every lane must call)
+__device__ uint32_t cand_wave_lcp(const uint8_t *s, uint32_t a, uint32_t b, uint32_t len, uint32_t max) {
+    const int lane = e_lane();
+    while (len < max) {
+        uint32_t off = len + 8 * lane;
+        uint64_t x = 0;
+        if (off + 8 <= max) x = ld_u64(s + a + off) ^ ld_u64(s + b + off);
+        else
+            for (uint32_t k = 0; off + k < max && k < 8; k++)
+                x |= (uint64_t)(s[a + off + k] ^ s[b + off + k]) << (8 * k);
+        uint64_t bad = __ballot(x != 0);
+        if (bad) {
+            int bl = __builtin_ctzll(bad);
+            uint32_t xl = e_readlane((uint32_t)x, bl), xh = e_readlane((uint32_t)(x >> 32), bl);
+            uint64_t xx = (uint64_t)xl | ((uint64_t)xh << 32);
+            uint32_t r = len + 8 * bl + (uint32_t)(__builtin_ctzll(xx) >> 3);
+            return r < max ? r : max;
+        }
+        len += 512;
+    }
+    return max;
+}
+
 // rec[i] = { dist | bwd << 18 | capped << 31 , fwd_len }  ; fwd_len == 0: no match at i
+//
+// One lane per position, hops in lock-step. A lane compares at most CAND_C1 bytes on its own. Lanes
+// that are still equal there are grouped into runs of consecutive positions with the same distance
+// (the inside of one long match): only the head of a run is extended, by the whole wave, and the
+// followers derive LCP(i + t, c + t) = LCP(i, c) - t. Repetitive data costs O(1) per position.
+constexpr uint32_t CAND_C1 = 64;
+
 __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
-                                                       const EncTile *__restrict__ tiles, const uint32_t *__restrict__ prev,
+                                                       const EncTile *__restrict__ tiles, const uint2 *__restrict__ prev,
                                                        uint2 *__restrict__ rec, uint64_t *__restrict__ bitmap) {
     const uint32_t t = blockIdx.y;
     const EncTile tl = tiles[t];
@@ -147,26 +178,62 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
     if (tl.start + blockIdx.x * blockDim.x >= n_pos) return;  // block-uniform
     const bool valid = i < n_pos && i < tl.start + TILE_POS;
     const uint8_t *s = src + st.src_off;
-    const uint32_t *pv = prev + st.pos_base;
+    const uint2 *pv = prev + st.pos_base;
+    const int lane = e_lane();
+    const uint2 self = valid ? pv[i] : make_uint2(NONE, 0);
+    const uint32_t v = self.y;
+    const uint32_t max_total = valid ? n - i : 0;
+    const uint32_t cap_total = max_total < FCAP ? max_total : FCAP;
+    const uint32_t c1 = cap_total < CAND_C1 ? cap_total : CAND_C1;
+    uint32_t best_len = 0, best_idx = 0;
+    bool capped = false;
+    bool alive = valid;
+    uint32_t c = self.x;
+#pragma unroll 1
+    for (int q = 0; q < 4; q++) {
+        if (!__any(alive)) break;
+        uint32_t dist = 0, len = 0;
+        bool eq = false;
+        uint2 rc = make_uint2(NONE, 0);
+        if (alive) {
+            if (c == NONE) alive = false;
+            else {
+                dist = i - c;
+                if (dist > MAX_D_VALUE) alive = false;  // frontend_bytes.rs:222-224: stop, not skip
+                else { rc = pv[c]; eq = rc.y == v; }    // one 8-byte gather per hop: next link + value
+            }
+        }
+        if (alive && eq) len = lcp_fwd(s, i, c, 4, c1);
+        // ---- runs of lanes still equal after CAND_C1 bytes ----
+        const bool more = alive && eq && len == CAND_C1 && CAND_C1 < cap_total;
+        const uint64_t mm = __ballot(more);
+        if (mm) {
+            const uint32_t dist_lo = __shfl_up(dist, 1);
+            const bool head = more && !(lane > 0 && ((mm >> (lane - 1)) & 1) && dist_lo == dist);
+            const uint64_t hm = __ballot(head);
+            uint64_t it = hm;
+            while (it) {
+                const int h = __builtin_ctzll(it);
+                it &= it - 1;
+                const uint32_t i_h = e_readlane(i, h), c_h = e_readlane(c, h);
+                const uint32_t maxh = n - i_h;
+                const uint32_t limh = maxh < FCAP + 64 ? maxh : FCAP + 64;
+                const uint32_t hl = cand_wave_lcp(s, i_h, c_h, CAND_C1, limh);
+                const uint64_t upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1);     // lanes 0 .. lane
+                const uint64_t above_h = (h == 63) ? 0ull : ~((2ull << h) - 1);        // lanes h+1 .. 63
+                const bool mine = more && lane >= h && (hm & above_h & upto) == 0;     // no other head in (h, lane]
+                if (mine) len = hl - (uint32_t)(lane - h);
+            }
+            if (more && len > cap_total) len = cap_total;
+        }
+        if (alive && eq) {
+            if (len == cap_total && cap_total < max_total) capped = true;
+            if (len > best_len) { best_len = len; best_idx = c; }  // ties keep the newest (:226)
+        }
+        c = rc.x;
+    }
     uint2 r = make_uint2(0, 0);
     if (valid) {
-        const uint32_t v = ld_u32(s + i);
-        const uint32_t max_total = n - i;
-        const uint32_t cap_total = max_total < FCAP ? max_total : FCAP;
-        uint32_t best_len = 0, best_idx = 0;
-        bool capped = false;
-        uint32_t c = pv[i];
-#pragma unroll 1
-        for (int k = 0; k < 4 && c != NONE; k++) {
-            uint32_t dist = i - c;
-            if (dist > MAX_D_VALUE) break;  // frontend_bytes.rs:222-224: stop, not skip
-            if (ld_u32(s + c) == v) {
-                uint32_t len = lcp_fwd(s, i, c, 4, cap_total);
-                if (len == cap_total && cap_total < max_total) capped = true;
-                if (len > best_len) { best_len = len; best_idx = c; }  // ties keep the newest (:226)
-            }
-            c = pv[c];
-        }
         if (best_len) {
             uint32_t bmax = best_idx < BCAP ? best_idx : BCAP;
             uint32_t bw = lcs_bwd(s, i, best_idx, bmax);
@@ -178,7 +245,7 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
     // has-match bitmap: tile starts are multiples of 64, so a wave covers exactly one word
     const uint64_t bits = __ballot(valid && r.y != 0);
     // (words past the stream's last position belong to the next stream: never touch them)
-    if (e_lane() == 0 && i < tl.start + TILE_POS && i < n_pos) bitmap[(st.pos_base + i) >> 6] = bits;
+    if (lane == 0 && i < tl.start + TILE_POS && i < n_pos) bitmap[(st.pos_base + i) >> 6] = bits;
 }
 
 // ------------------------------------------------------------------------------------ walk
@@ -186,7 +253,7 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
 struct Walker {
     // stream
     const uint8_t *s;
-    const uint32_t *pv;
+    const uint2 *pv;
     const uint2 *rec;
     uint32_t n, end;
     // parse state (frontend_bytes.rs:25-32)
@@ -345,7 +412,7 @@ __device__ uint32_t wave_lcs_bwd(const uint8_t *s, uint32_t a, uint32_t b, uint3
 // One wave per stream. All lanes execute the same (uniform) control flow; lanes only differ when
 // they prefetch records, stash LMDs or help with an exact length.
 __global__ __launch_bounds__(64) void enc_walk_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
-                                                      uint32_t n_streams, const uint32_t *__restrict__ prev,
+                                                      uint32_t n_streams, const uint2 *__restrict__ prev,
                                                       const uint2 *__restrict__ rec, uint2 *__restrict__ lmds,
                                                       EncBlock *__restrict__ blocks, EncStreamOut *__restrict__ outs) {
     const uint32_t si = blockIdx.x;
@@ -407,14 +474,14 @@ __global__ __launch_bounds__(64) void enc_walk_kernel(const uint8_t *__restrict_
             // exact re-evaluation of find_match's forward part (frontend_bytes.rs:214-231)
             uint32_t v = ld_u32(w.s + index);
             uint32_t best_len = 0, best_idx = 0;
-            uint32_t c = w.pv[index];
+            uint32_t c = w.pv[index].x;
             for (int q = 0; q < 4 && c != NONE; q++) {
                 if (index - c > MAX_D_VALUE) break;
                 if (ld_u32(w.s + c) == v) {
                     uint32_t len = wave_lcp_fwd(w.s, index, c, 4, w.n - index);
                     if (len > best_len) { best_len = len; best_idx = c; }
                 }
-                c = w.pv[c];
+                c = w.pv[c].x;
             }
             fwd = best_len; midx = best_idx; dist = index - midx;
             uint32_t bmax = midx < BCAP ? midx : BCAP;
@@ -1039,7 +1106,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     if (nt > 65535) return LZFSE_MI_UNSUPPORTED;  // grid.y limit of the per-tile kernels (4 GiB per call)
 
     if (!eb_ensure(S, EB_STREAMS, ns * sizeof(EncStream)) || !eb_ensure(S, EB_TILES, nt * sizeof(EncTile)) ||
-        !eb_ensure(S, EB_PREV, pos_total * 4) || !eb_ensure(S, EB_SUMMARY, (size_t)nt * (1u << HASH_BITS) * 4) ||
+        !eb_ensure(S, EB_PREV, pos_total * 8) || !eb_ensure(S, EB_SUMMARY, (size_t)nt * (1u << HASH_BITS) * 4) ||
         !eb_ensure(S, EB_REC, pos_total * 8) || !eb_ensure(S, EB_LMDS, lmd_total * 8) ||
         !eb_ensure(S, EB_BLOCKS, (size_t)blk_total * sizeof(EncBlock)) || !eb_ensure(S, EB_OUTS, ns * sizeof(EncStreamOut)) ||
         !eb_ensure(S, EB_STAGE, stage_total + 256) || !eb_ensure(S, EB_SLOTS, (size_t)blk_total * 4) ||
@@ -1054,7 +1121,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         return LZFSE_MI_IO;
     EncStream *d_streams = (EncStream *)S.bufs[EB_STREAMS];
     EncTile *d_tiles = (EncTile *)S.bufs[EB_TILES];
-    uint32_t *d_prev = (uint32_t *)S.bufs[EB_PREV];
+    uint2 *d_prev = (uint2 *)S.bufs[EB_PREV];
     uint32_t *d_summary = (uint32_t *)S.bufs[EB_SUMMARY];
     uint2 *d_rec = (uint2 *)S.bufs[EB_REC];
     uint2 *d_lmds = (uint2 *)S.bufs[EB_LMDS];
@@ -1094,7 +1161,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         E_TRY(hipMemcpyAsync(d_rslots, hrslots.data(), (size_t)range_total * 4, hipMemcpyHostToDevice, stq));
         {
             StageTimer t(c, "enc_spec");
-            launch_enc_spec(d_streams, d_segs, nseg, d_rec, d_bitmap, d_logs, d_hdrs, stq);
+            launch_enc_spec(d_src, d_streams, d_segs, nseg, d_prev, d_rec, d_bitmap, d_logs, d_hdrs, stq);
         }
         {
             StageTimer t(c, "enc_stitch");
@@ -1153,7 +1220,7 @@ extern "C" int lzfse_mi_debug_candidates(lzfse_mi_ctx *c, const uint8_t *h_src, 
     uint32_t nt = (uint32_t)ht.size();
     size_t padn = (n + 255) & ~(size_t)255;
     if (!eb_ensure(S, EB_STREAMS, sizeof(EncStream)) || !eb_ensure(S, EB_TILES, nt * sizeof(EncTile)) ||
-        !eb_ensure(S, EB_PREV, padn * 4) || !eb_ensure(S, EB_SUMMARY, (size_t)nt * (1u << HASH_BITS) * 4) ||
+        !eb_ensure(S, EB_PREV, padn * 8) || !eb_ensure(S, EB_SUMMARY, (size_t)nt * (1u << HASH_BITS) * 4) ||
         !eb_ensure(S, EB_REC, padn * 8) || !eb_ensure(S, EB_STAGE, padn + 256) || !eb_ensure(S, EB_BITMAP, padn / 8 + 64))
         return LZFSE_MI_IO;
     uint8_t *d_src = (uint8_t *)S.bufs[EB_STAGE];
@@ -1161,12 +1228,12 @@ extern "C" int lzfse_mi_debug_candidates(lzfse_mi_ctx *c, const uint8_t *h_src, 
     E_TRY(hipMemcpyAsync(S.bufs[EB_STREAMS], &e, sizeof e, hipMemcpyHostToDevice, stq));
     E_TRY(hipMemcpyAsync(S.bufs[EB_TILES], ht.data(), nt * sizeof(EncTile), hipMemcpyHostToDevice, stq));
     hipLaunchKernelGGL(enc_chain_kernel, dim3(nt), dim3(64), 0, stq, d_src, (EncStream *)S.bufs[EB_STREAMS], (EncTile *)S.bufs[EB_TILES], nt,
-                       (uint32_t *)S.bufs[EB_PREV], (uint32_t *)S.bufs[EB_SUMMARY]);
+                       (uint2 *)S.bufs[EB_PREV], (uint32_t *)S.bufs[EB_SUMMARY]);
     hipLaunchKernelGGL(enc_link_kernel, dim3((TILE_POS + 255) / 256, nt), dim3(256), 0, stq, d_src, (EncStream *)S.bufs[EB_STREAMS],
-                       (EncTile *)S.bufs[EB_TILES], nt, (uint32_t *)S.bufs[EB_PREV], (uint32_t *)S.bufs[EB_SUMMARY]);
+                       (EncTile *)S.bufs[EB_TILES], nt, (uint2 *)S.bufs[EB_PREV], (uint32_t *)S.bufs[EB_SUMMARY]);
     hipLaunchKernelGGL(enc_cand_kernel, dim3((TILE_POS + 255) / 256, nt), dim3(256), 0, stq, d_src, (EncStream *)S.bufs[EB_STREAMS],
-                       (EncTile *)S.bufs[EB_TILES], (uint32_t *)S.bufs[EB_PREV], (uint2 *)S.bufs[EB_REC], (uint64_t *)S.bufs[EB_BITMAP]);
-    E_TRY(hipMemcpyAsync(h_prev, S.bufs[EB_PREV], (n - 3) * 4, hipMemcpyDeviceToHost, stq));
+                       (EncTile *)S.bufs[EB_TILES], (uint2 *)S.bufs[EB_PREV], (uint2 *)S.bufs[EB_REC], (uint64_t *)S.bufs[EB_BITMAP]);
+    E_TRY(hipMemcpyAsync(h_prev, S.bufs[EB_PREV], (n - 3) * 8, hipMemcpyDeviceToHost, stq));  // {prev, value} pairs
     E_TRY(hipMemcpyAsync(h_rec_xy, S.bufs[EB_REC], (n - 3) * 8, hipMemcpyDeviceToHost, stq));
     E_TRY(hipStreamSynchronize(stq));
     return hipGetLastError() == hipSuccess ? LZFSE_MI_OK : LZFSE_MI_IO;

@@ -64,77 +64,7 @@ __device__ __forceinline__ bool select40(WState &st, uint32_t i_idx, uint32_t i_
 
 // ------------------------------------------------------------------------------------ speculative walk
 
-__global__ __launch_bounds__(64) void enc_spec_kernel(const EncStream *__restrict__ streams, const uint2 *__restrict__ segs,
-                                                      uint32_t n_segs, const uint2 *__restrict__ rec,
-                                                      const uint64_t *__restrict__ bitmap, SpecEvent *__restrict__ logs,
-                                                      SpecHeader *__restrict__ hdrs) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_segs) return;
-    const uint2 sg = segs[g];
-    const EncStream &es = streams[sg.x];
-    const uint32_t end = es.n - 3;
-    const uint32_t S = sg.y * SEG;
-    const uint32_t stop = (S + SEG + OVER < end) ? S + SEG + OVER : end;
-    const uint2 *r = rec + es.pos_base;
-    const uint64_t *bm = bitmap + (es.pos_base >> 6);
-    SpecEvent *ev = logs + (uint64_t)g * SEG_EV_CAP;
-    WState st;
-    st.index = S; st.lit = S; st.p_idx = 0; st.p_midx = 0; st.p_len = 0;
-    uint32_t nev = 0, status = 0;
-    while (st.index < stop) {
-        uint32_t p = next_has(bm, st.index, stop);
-        if (p >= stop) { st.index = stop; break; }
-        st.index = p;
-        const uint2 rr = r[p];
-        if (rr.x & REC_CAPPED) { status = 1; break; }  // needs the exact wave-wide length: left to the stitcher
-        const uint32_t dist = rr.x & 0x3FFFF, bw = (rr.x >> 18) & 0xFF, fwd = rr.y;
-        const uint32_t midx = p - dist;
-        const uint32_t room = p - st.lit;
-        if (bw == BCAP && room > BCAP && midx > BCAP) { status = 1; break; }
-        const uint32_t b = bw < room ? bw : room;  // frontend_bytes.rs:259-268
-        uint32_t e_idx = 0, e_midx = 0, e_len = 0;
-        const uint32_t lit_before = st.lit;
-        if (select40(st, p - b, midx - b, fwd + b, e_idx, e_midx, e_len)) {
-            st.lit = e_idx + e_len;
-            st.index = (p + 1 > st.lit) ? p + 1 : st.lit;
-            if (nev < SEG_EV_CAP) {
-                SpecEvent e;
-                e.e_idx = e_idx; e.e_len = e_len; e.e_dist = e_idx - e_midx; e.e_lit = lit_before;
-                e.index_after = st.index;
-                e.p_idx = st.p_len ? st.p_idx : 0; e.p_midx = st.p_len ? st.p_midx : 0; e.p_len = st.p_len;
-                ev[nev] = e;
-            }
-            nev++;
-        } else {
-            st.index = p + 1;
-        }
-    }
-    SpecHeader h;
-    h.n_events = nev < SEG_EV_CAP ? nev : SEG_EV_CAP;
-    h.status = nev > SEG_EV_CAP ? 2u : status;  // 2: log overflow (cannot happen: every emit advances lit by >= 4)
-    h.f_index = st.index; h.f_lit = st.lit;
-    h.f_pidx = st.p_len ? st.p_idx : 0; h.f_pmidx = st.p_len ? st.p_midx : 0; h.f_plen = st.p_len;
-    h.pad = 0;
-    hdrs[g] = h;
-}
-
-// ------------------------------------------------------------------------------------ stitch
-
-__device__ __forceinline__ bool ev_state_eq(const SpecEvent &a, const SpecEvent &b) {
-    return a.index_after == b.index_after && a.e_idx + a.e_len == b.e_idx + b.e_len && a.p_len == b.p_len &&
-           (a.p_len == 0 || (a.p_idx == b.p_idx && a.p_midx == b.p_midx));
-}
-
-// first event of a log with index_after >= key
-__device__ __forceinline__ uint32_t ev_lower_bound(const SpecEvent *ev, uint32_t n, uint32_t key) {
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (ev[mid].index_after < key) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-
+// exact forward / backward lengths by the whole wave (512 / 64 bytes per step); every lane must call
 __device__ uint32_t st_wave_lcp_fwd(const uint8_t *s, uint32_t a, uint32_t b, uint32_t len, uint32_t max) {
     const int lane = e_lane();
     while (len < max) {
@@ -171,6 +101,130 @@ __device__ uint32_t st_wave_lcs_bwd(const uint8_t *s, uint32_t a, uint32_t b, ui
         len += 64;
     }
     return max;
+}
+
+// All 64 lanes stay in the loop until every segment of the wave is finished, so that a lane whose
+// record is capped can have its exact lengths computed by the whole wave (one request at a time).
+__global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
+                                                      const uint2 *__restrict__ segs, uint32_t n_segs,
+                                                      const uint2 *__restrict__ prev, const uint2 *__restrict__ rec,
+                                                      const uint64_t *__restrict__ bitmap, SpecEvent *__restrict__ logs,
+                                                      SpecHeader *__restrict__ hdrs) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool exists = g < n_segs;
+    const uint2 sg = exists ? segs[g] : make_uint2(0, 0);
+    const EncStream &es = streams[sg.x];
+    const uint32_t end = es.n - 3;
+    const uint32_t S = sg.y * SEG;
+    const uint32_t stop = exists ? ((S + SEG + OVER < end) ? S + SEG + OVER : end) : 0;
+    const uint2 *r = rec + es.pos_base;
+    const uint64_t *bm = bitmap + (es.pos_base >> 6);
+    SpecEvent *ev = logs + (uint64_t)g * SEG_EV_CAP;
+    const int lane = e_lane();
+    WState st;
+    st.index = exists ? S : 0; st.lit = S; st.p_idx = 0; st.p_midx = 0; st.p_len = 0;
+    uint32_t nev = 0, status = 0;
+    bool running = exists && st.index < stop;
+    while (__any(running)) {
+        uint32_t p = 0;
+        uint2 rr = make_uint2(0, 0);
+        bool have = false;
+        if (running) {
+            p = next_has(bm, st.index, stop);
+            if (p >= stop) { st.index = stop; running = false; }
+            else { st.index = p; rr = r[p]; have = true; }
+        }
+        uint32_t dist = rr.x & 0x3FFFF, bw = (rr.x >> 18) & 0xFF, fwd = rr.y;
+        uint32_t midx = p - dist;
+        // ---- exact re-evaluation of capped records, one requesting lane at a time, by the whole wave ----
+        uint64_t req = __ballot(have && (rr.x & REC_CAPPED));
+        while (req) {
+            const int L = __builtin_ctzll(req);
+            req &= req - 1;
+            const uint32_t q_stream = e_readlane(sg.x, L), q_p = e_readlane(p, L);
+            const EncStream &qs = streams[q_stream];
+            const uint8_t *s = src + qs.src_off;
+            const uint2 *pv = prev + qs.pos_base;
+            const uint32_t maxl = qs.n - q_p;
+            const uint32_t lim = maxl < XCAP ? maxl : XCAP;
+            const uint2 self = pv[q_p];
+            uint32_t best_len = 0, best_idx = 0, c = self.x;
+            bool over = false;
+            for (int q = 0; q < 4 && c != NONE; q++) {  // frontend_bytes.rs:214-231
+                if (q_p - c > MAX_D_VALUE) break;
+                const uint2 rc = pv[c];
+                if (rc.y == self.y) {
+                    uint32_t len = st_wave_lcp_fwd(s, q_p, c, 4, lim);
+                    if (len == lim && lim < maxl) over = true;
+                    if (len > best_len) { best_len = len; best_idx = c; }
+                }
+                c = rc.x;
+            }
+            const uint32_t bl = st_wave_lcs_bwd(s, q_p, best_idx, best_idx < BCAP ? best_idx : BCAP);
+            if (lane == L) {
+                if (over) { status = 1; running = false; have = false; }  // longer than XCAP: left to the stitcher
+                else { fwd = best_len; midx = best_idx; dist = q_p - best_idx; bw = bl; }
+            }
+        }
+        // ---- exact backward length when the capped one may be too short (frontend_bytes.rs:259-268) ----
+        const uint32_t room = p - st.lit;
+        uint32_t b = bw < room ? bw : room;
+        uint64_t reqb = __ballot(have && bw == BCAP && room > BCAP && midx > BCAP);
+        while (reqb) {
+            const int L = __builtin_ctzll(reqb);
+            reqb &= reqb - 1;
+            const uint32_t q_stream = e_readlane(sg.x, L), q_p = e_readlane(p, L), q_m = e_readlane(midx, L), q_room = e_readlane(room, L);
+            const uint8_t *s = src + streams[q_stream].src_off;
+            const uint32_t bl = st_wave_lcs_bwd(s, q_p, q_m, q_room < q_m ? q_room : q_m);
+            if (lane == L) b = bl;
+        }
+        if (have) {
+            {
+                uint32_t e_idx = 0, e_midx = 0, e_len = 0;
+                const uint32_t lit_before = st.lit;
+                if (select40(st, p - b, midx - b, fwd + b, e_idx, e_midx, e_len)) {
+                    st.lit = e_idx + e_len;
+                    st.index = (p + 1 > st.lit) ? p + 1 : st.lit;
+                    if (nev < SEG_EV_CAP) {
+                        SpecEvent e;
+                        e.e_idx = e_idx; e.e_len = e_len; e.e_dist = e_idx - e_midx; e.e_lit = lit_before;
+                        e.index_after = st.index;
+                        e.p_idx = st.p_len ? st.p_idx : 0; e.p_midx = st.p_len ? st.p_midx : 0; e.p_len = st.p_len;
+                        ev[nev] = e;
+                    }
+                    nev++;
+                } else {
+                    st.index = p + 1;
+                }
+                if (st.index >= stop) running = false;
+            }
+        }
+    }
+    if (!exists) return;
+    SpecHeader h;
+    h.n_events = nev < SEG_EV_CAP ? nev : SEG_EV_CAP;
+    h.status = nev > SEG_EV_CAP ? 2u : status;  // 2: log overflow (cannot happen: every emit advances lit by >= 4)
+    h.f_index = st.index; h.f_lit = st.lit;
+    h.f_pidx = st.p_len ? st.p_idx : 0; h.f_pmidx = st.p_len ? st.p_midx : 0; h.f_plen = st.p_len;
+    h.pad = 0;
+    hdrs[g] = h;
+}
+
+// ------------------------------------------------------------------------------------ stitch
+
+__device__ __forceinline__ bool ev_state_eq(const SpecEvent &a, const SpecEvent &b) {
+    return a.index_after == b.index_after && a.e_idx + a.e_len == b.e_idx + b.e_len && a.p_len == b.p_len &&
+           (a.p_len == 0 || (a.p_idx == b.p_idx && a.p_midx == b.p_midx));
+}
+
+// first event of a log with index_after >= key
+__device__ __forceinline__ uint32_t ev_lower_bound(const SpecEvent *ev, uint32_t n, uint32_t key) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (ev[mid].index_after < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
 }
 
 struct Stitch {
@@ -212,7 +266,7 @@ __device__ __forceinline__ void sx_gap_event(Stitch &x, uint32_t lit_before, uin
 
 // One wave per stream; control flow and values are wave-uniform.
 __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
-                                                        uint32_t n_streams, const uint32_t *__restrict__ prev,
+                                                        uint32_t n_streams, const uint2 *__restrict__ prev,
                                                         const uint2 *__restrict__ rec, const uint64_t *__restrict__ bitmap,
                                                         const SpecEvent *__restrict__ logs, const SpecHeader *__restrict__ hdrs,
                                                         RangeRec *__restrict__ ranges, MatchRec *__restrict__ gaps,
@@ -221,7 +275,7 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
     if (si >= n_streams) return;
     const EncStream &es = streams[si];
     const uint8_t *s = src + es.src_off;
-    const uint32_t *pv = prev + es.pos_base;
+    const uint2 *pv = prev + es.pos_base;
     const uint2 *r = rec + es.pos_base;
     const uint64_t *bm = bitmap + (es.pos_base >> 6);
     const uint32_t n = es.n, end = n - 3, K = es.n_seg;
@@ -285,14 +339,14 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
         uint32_t midx = p - dist;
         if (rr.x & REC_CAPPED) {
             // exact forward part of find_match (frontend_bytes.rs:214-231) by the whole wave
-            uint32_t v = ld_u32(s + p), best_len = 0, best_idx = 0, c = pv[p];
+            uint32_t v = ld_u32(s + p), best_len = 0, best_idx = 0, c = pv[p].x;
             for (int q = 0; q < 4 && c != NONE; q++) {
                 if (p - c > MAX_D_VALUE) break;
                 if (ld_u32(s + c) == v) {
                     uint32_t len = st_wave_lcp_fwd(s, p, c, 4, n - p);
                     if (len > best_len) { best_len = len; best_idx = c; }
                 }
-                c = pv[c];
+                c = pv[c].x;
             }
             fwd = best_len; midx = best_idx; dist = p - midx;
             bw = st_wave_lcs_bwd(s, p, midx, midx < BCAP ? midx : BCAP);
@@ -597,12 +651,13 @@ __global__ __launch_bounds__(256) void enc_lmd_kernel(const EncStream *__restric
 
 // ------------------------------------------------------------------------------------ launchers
 
-void launch_enc_spec(const EncStream *streams, const uint2 *segs, uint32_t n_segs, const uint2 *rec, const uint64_t *bitmap,
-                     SpecEvent *logs, SpecHeader *hdrs, hipStream_t st) {
+void launch_enc_spec(const uint8_t *src, const EncStream *streams, const uint2 *segs, uint32_t n_segs, const uint2 *prev,
+                     const uint2 *rec, const uint64_t *bitmap, SpecEvent *logs, SpecHeader *hdrs, hipStream_t st) {
     if (!n_segs) return;
-    hipLaunchKernelGGL(enc_spec_kernel, dim3((n_segs + 63) / 64), dim3(64), 0, st, streams, segs, n_segs, rec, bitmap, logs, hdrs);
+    hipLaunchKernelGGL(enc_spec_kernel, dim3((n_segs + 63) / 64), dim3(64), 0, st, src, streams, segs, n_segs, prev, rec, bitmap, logs,
+                       hdrs);
 }
-void launch_enc_stitch(const uint8_t *src, const EncStream *streams, uint32_t ns, const uint32_t *prev, const uint2 *rec,
+void launch_enc_stitch(const uint8_t *src, const EncStream *streams, uint32_t ns, const uint2 *prev, const uint2 *rec,
                        const uint64_t *bitmap, const SpecEvent *logs, const SpecHeader *hdrs, RangeRec *ranges, MatchRec *gaps,
                        EncStreamOut *outs, hipStream_t st) {
     hipLaunchKernelGGL(enc_stitch_kernel, dim3(ns), dim3(64), 0, st, src, streams, ns, prev, rec, bitmap, logs, hdrs, ranges, gaps, outs);

@@ -23,11 +23,11 @@ def gpu_candidates(ctx, raw):
     f.restype = C.c_int
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     a = np.frombuffer(raw, dtype=np.uint8)
-    prev = np.zeros(a.size - 3, dtype=np.uint32)
+    prev = np.zeros((a.size - 3, 2), dtype=np.uint32)  # {prev, value} pairs
     rec = np.zeros((a.size - 3, 2), dtype=np.uint32)
     st = f(ctx._h, a.ctypes.data, a.size, prev.ctypes.data, rec.ctypes.data)
     assert st == 0
-    return prev, rec
+    return prev[:, 0], rec
 
 
 def synth_cases():
