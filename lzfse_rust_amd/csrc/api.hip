@@ -334,6 +334,15 @@ int lzfse_mi_decode_batch_device(lzfse_mi_ctx *c, size_t count, const void *d_sr
     HIP_TRY(hipMemcpyAsync(h_sres.data(), c->d_sres.p, ns * sizeof(StreamResult), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (hipGetLastError() != hipSuccess) return LZFSE_MI_IO;
+    if (getenv("LZFSE_MI_LZ_STATS")) {
+        for (uint32_t i = 0; i < ns && i < 16; i++) {
+            const StreamResult &q = h_sres[i];
+            fprintf(stderr, "lz[%u] out=%llu groups=%u dep=%u long=%u cyc scan=%llu short=%llu long=%llu dep=%llu wb=%llu total=%llu\n", i,
+                    (unsigned long long)q.out_len, q.groups, q.n_dep, q.n_long, (unsigned long long)q.cyc[0],
+                    (unsigned long long)q.cyc[1], (unsigned long long)q.cyc[2], (unsigned long long)q.cyc[3],
+                    (unsigned long long)q.cyc[4], (unsigned long long)q.cyc[5]);
+        }
+    }
     for (uint32_t i = 0; i < ns; i++) {
         if (h_plan[i].skip) continue;
         statuses[i] = h_sres[i].status;

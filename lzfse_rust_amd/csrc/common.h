@@ -66,7 +66,9 @@ struct BlockResult {
 struct StreamResult {
     uint64_t out_len;
     int32_t status;
-    uint32_t pad;
+    uint32_t groups;       // diagnostics: LZ groups processed, dependent matches, long copies
+    uint32_t n_dep, n_long;
+    uint64_t cyc[6];       // diagnostics: cycles per LZ phase (scan, short copies, long copies, dependent, write-back, total)
 };
 
 // Decoded LMD record handed from the entropy stage to the LZ stage: l | m << 16, d

@@ -568,6 +568,9 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
     uint8_t *dst = dst_all + in.dst_off;
     uint64_t out_pos = 0;  // bytes produced so far in this stream
     int status = 0;
+    uint64_t cy0 = 0, cy1 = 0, cy2 = 0, cy3 = 0, cy4 = 0;
+    uint32_t dg_groups = 0, dg_dep = 0, dg_long = 0;
+    const uint64_t t_start = __builtin_amdgcn_s_memtime();
     if (tid == 0) s_status = 0;
     __syncthreads();
 
@@ -603,6 +606,7 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
         const uint8_t *blit = lits + d.lit_base;
         uint32_t lit_run = 0;
         for (uint32_t g0 = 0; g0 < d.n_lmd && !status;) {
+            const uint64_t ta = __builtin_amdgcn_s_memtime();
             const uint32_t idx = g0 + tid;
             const bool valid = idx < d.n_lmd;
             LmdRec r = valid ? bl[idx] : make_uint2(0, 0);
@@ -626,6 +630,7 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
             const uint32_t pad = (uint32_t)((uintptr_t)(dst + tile_base) & 15);  // LDS/global co-alignment
             uint8_t *t = tile + pad;
 
+            const uint64_t tb = __builtin_amdgcn_s_memtime();
             // ---- classify + short copies by the owning lane ----
             const uint64_t p_match = tile_base + ex_s + l;  // stream-relative position of the match
             bool bad_d = part && m != 0 && (dd == 0 || (uint64_t)dd > p_match);  // lz/writer.rs:156-178
@@ -634,8 +639,14 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
                 s_off[tid] = ex_s; s_lm[tid] = r.x; s_d[tid] = dd; s_lit[tid] = lit_run + ex_l;
                 if (l) {
                     if (l <= SHORT_COPY) {
+                        // three 8-byte loads in flight, then byte stores into the tile (the literal
+                        // scratch has 256 bytes of slack behind its last byte)
                         const uint8_t *ls = blit + lit_run + ex_l;
-                        for (uint32_t k = 0; k < l; k++) t[ex_s + k] = ls[k];
+                        uint64_t w0 = ld_u64(ls), w1 = l > 8 ? ld_u64(ls + 8) : 0, w2 = l > 16 ? ld_u64(ls + 16) : 0;
+                        for (uint32_t k = 0; k < l; k++) {
+                            uint64_t w = k < 8 ? w0 : (k < 16 ? w1 : w2);
+                            t[ex_s + k] = (uint8_t)(w >> (8 * (k & 7)));
+                        }
                     } else lit_long = true;
                 }
                 if (m) {
@@ -644,22 +655,32 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
                     if (dd >= m && p_match - dd + slen <= tile_base) {
                         if (m <= SHORT_COPY) {
                             const uint8_t *ms = dst + (p_match - dd);
-                            for (uint32_t k = 0; k < m; k++) t[ex_s + l + k] = ms[k];
+                            if (p_match - dd + 24 <= tile_base) {  // 24 readable bytes of finished output
+                                uint64_t w0 = ld_u64(ms), w1 = m > 8 ? ld_u64(ms + 8) : 0, w2 = m > 16 ? ld_u64(ms + 16) : 0;
+                                for (uint32_t k = 0; k < m; k++) {
+                                    uint64_t w = k < 8 ? w0 : (k < 16 ? w1 : w2);
+                                    t[ex_s + l + k] = (uint8_t)(w >> (8 * (k & 7)));
+                                }
+                            } else {
+                                for (uint32_t k = 0; k < m; k++) t[ex_s + l + k] = ms[k];
+                            }
                         } else far_long = true;
                     } else dep = true;
                 }
             }
-            // ordered compaction of dependent matches and of long copies
             unsigned long long bb = __ballot(bad_d);
             if (bb && lane == 0) atomicOr((int *)&s_status, LZFSE_MI_BAD_D_VALUE);
+            // compaction of the long copies; s_dep becomes the per-slot "match not written yet" flag
             uint32_t nl = (lit_long ? 1u : 0u) + (far_long ? 1u : 0u);
             uint32_t ex_dep, ex_long, tot_dep, tot_long;
             block_excl_scan2<NT>(dep ? 1u : 0u, nl, ex_dep, ex_long, tot_dep, tot_long, s_scan);
-            if (dep) s_dep[ex_dep] = tid;
+            s_dep[tid] = dep ? 1u : 0u;
             if (lit_long) s_long[ex_long++] = tid * 2;
             if (far_long) s_long[ex_long] = tid * 2 + 1;
             __syncthreads();
             if (s_status) { status = s_status; break; }
+            const uint64_t tc = __builtin_amdgcn_s_memtime();
+            dg_groups++; dg_dep += tot_dep; dg_long += tot_long;
             // ---- long copies: one wave per segment, 64 bytes per step ----
             for (uint32_t q = wave; q < tot_long; q += NW) {
                 uint32_t e = s_long[q], slot = e >> 1;
@@ -673,30 +694,77 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
                     for (uint32_t k = lane; k < ll; k += 64) t[o + k] = ls[k];
                 }
             }
-            __syncthreads();
-            // ---- dependent matches: in order, one wave, LDS-resident (lz/object.rs:27-74 semantics:
-            //      out[p + k] = out[p + k - d], overlap allowed) ----
-            if (wave == 0) {
-                for (uint32_t q = 0; q < tot_dep; q++) {
-                    uint32_t slot = s_dep[q];
-                    uint32_t o = s_off[slot], lm = s_lm[slot], ddq = s_d[slot];
-                    uint32_t ll = lm & 0xFFFF, mm = lm >> 16;
-                    uint32_t mo = o + ll;                      // tile offset of the match
-                    int64_t so = (int64_t)mo - (int64_t)ddq;   // tile offset of the source (may be < 0)
+            const uint64_t td = __builtin_amdgcn_s_memtime();
+            // ---- matches that read the tile (lz/object.rs:27-74 semantics: out[p + k] = out[p + k - d],
+            //      overlap allowed): rounds. A match is ready when no unwritten match lies in its
+            //      source range; ready short matches are copied by their lane, ready long ones by a wave.
+            uint32_t sl_a = 0, sl_b = 0;
+            const uint32_t mo = ex_s + l;                              // tile offset of the match
+            const int64_t so = (int64_t)mo - (int64_t)dd;              // tile offset of its source (may be < 0)
+            if (dep) {
+                // slots covering the in-tile part of the source [max(so, 0), so + min(m, d))
+                const uint32_t x0 = so > 0 ? (uint32_t)so : 0u;
+                const uint32_t x1 = (uint32_t)(so + (int64_t)(m < dd ? m : dd)) - 1;  // last source byte (>= 0, < mo)
+                uint32_t lo = 0, hi = tid;  // largest slot t <= tid with s_off[t] <= x
+                while (lo < hi) { uint32_t mid = (lo + hi + 1) >> 1; if (s_off[mid] <= x0) lo = mid; else hi = mid - 1; }
+                sl_a = lo;
+                lo = sl_a; hi = tid;
+                while (lo < hi) { uint32_t mid = (lo + hi + 1) >> 1; if (s_off[mid] <= x1) lo = mid; else hi = mid - 1; }
+                sl_b = lo;
+                if (sl_b == (uint32_t)tid) sl_b = tid ? tid - 1 : 0;      // own slot: only its literals can be read
+            }
+            bool pending = dep;
+            for (;;) {
+                __syncthreads();  // flags and tile bytes of the previous round (or phase) are visible
+                if (tid == 0) s_cnt[3] = 0;
+                bool ready = false;
+                if (pending) {
+                    ready = true;
+                    for (uint32_t q = sl_a; q <= sl_b; q++) if (q != (uint32_t)tid && s_dep[q]) { ready = false; break; }
+                }
+                __syncthreads();
+                const bool rs = ready && m <= SHORT_COPY;
+                if (rs) {
+                    if (dd >= m && so >= 0) {
+                        // non-overlapping, in the tile: loads first, then stores
+                        uint8_t buf[SHORT_COPY];
+#pragma unroll
+                        for (uint32_t k = 0; k < SHORT_COPY; k++) if (k < m) buf[k] = t[so + k];
+#pragma unroll
+                        for (uint32_t k = 0; k < SHORT_COPY; k++) if (k < m) t[mo + k] = buf[k];
+                    } else {
+                        for (uint32_t k = 0; k < m; k++) {
+                            int64_t sp = so + k;
+                            t[mo + k] = sp >= 0 ? t[sp] : dst[(int64_t)tile_base + sp];
+                        }
+                    }
+                } else if (ready) {
+                    s_long[atomicAdd(&s_cnt[3], 1u)] = tid;
+                }
+                __syncthreads();
+                const uint32_t nq = s_cnt[3];
+                for (uint32_t q = wave; q < nq; q += NW) {
+                    const uint32_t slot = s_long[q];
+                    const uint32_t lm = s_lm[slot], ddq = s_d[slot];
+                    const uint32_t ll = lm & 0xFFFF, mm = lm >> 16;
+                    const uint32_t mq = s_off[slot] + ll;
+                    const int64_t sq = (int64_t)mq - (int64_t)ddq;
                     for (uint32_t c = 0; c < mm; c += 64) {
                         uint32_t k = c + lane;
                         if (k < mm) {
                             uint32_t kk = ddq < 64 ? k % ddq : k;
-                            int64_t sp = so + kk;
+                            int64_t sp = sq + kk;
                             uint8_t v = sp >= 0 ? t[sp] : dst[(int64_t)tile_base + sp];
-                            t[mo + k] = v;
+                            t[mq + k] = v;
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                     }
                 }
+                if (ready) { pending = false; s_dep[tid] = 0; }
+                if (!__syncthreads_or(pending)) break;
             }
-            __syncthreads();
+            const uint64_t te = __builtin_amdgcn_s_memtime();
             // ---- write the tile back: head bytes, 16-byte body, tail bytes ----
             {
                 uint8_t *g = dst + tile_base;
@@ -717,11 +785,16 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
             lit_run += s_cnt[2];
             g0 += cnt;
             __syncthreads();
+            const uint64_t tf = __builtin_amdgcn_s_memtime();
+            cy0 += tb - ta; cy1 += tc - tb; cy2 += td - tc; cy3 += te - td; cy4 += tf - te;
         }
     }
     if (tid == 0) {
         StreamResult r;
-        r.out_len = out_pos; r.status = status; r.pad = 0;
+        r.out_len = out_pos; r.status = status;
+        r.groups = dg_groups; r.n_dep = dg_dep; r.n_long = dg_long;
+        r.cyc[0] = cy0; r.cyc[1] = cy1; r.cyc[2] = cy2; r.cyc[3] = cy3; r.cyc[4] = cy4;
+        r.cyc[5] = __builtin_amdgcn_s_memtime() - t_start;
         sres[s] = r;
     }
 }
