@@ -59,7 +59,7 @@ struct lzfse_mi_ctx {
     // batch descriptors / results
     DevBuf d_streams, d_walk, d_plan, d_blocks, d_bres, d_sres;
     // decode scratch
-    DevBuf d_lmds, d_lits;
+    DevBuf d_lmds, d_lits, d_origin, d_jerr;
     // encode scratch (encode.hip)
     EncScratch enc;
     // host-pointer API staging
@@ -191,7 +191,7 @@ void lzfse_mi_destroy(lzfse_mi_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->d_streams, &c->d_walk, &c->d_plan, &c->d_blocks, &c->d_bres, &c->d_sres,
-                      &c->d_lmds, &c->d_lits, &c->d_in, &c->d_out})
+                      &c->d_lmds, &c->d_lits, &c->d_origin, &c->d_jerr, &c->d_in, &c->d_out})
         b->release();
     enc_scratch_release(c->enc);
     c->h_in.release();
@@ -294,20 +294,33 @@ int lzfse_mi_decode_batch_device(lzfse_mi_ctx *c, size_t count, const void *d_sr
     HIP_TRY(hipMemcpyAsync(h_walk.data(), c->d_walk.p, ns * sizeof(StreamWalk), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     std::vector<StreamPlan> h_plan(ns);
-    uint64_t nb = 0, nl = 0, nu = 0;
+    uint64_t nb = 0, nl = 0, nu = 0, nj = 0;
+    int jump_mode = -1;  // -1: by stream size, 0: never, 1: always (diagnostics)
+    if (const char *ev = getenv("LZFSE_MI_LZ_JUMP")) jump_mode = atoi(ev);
     for (uint32_t i = 0; i < ns; i++) {
         StreamPlan &p = h_plan[i];
         p.blk_base = nb; p.lmd_base = nl; p.lit_base = nu; p.n_blocks = h_walk[i].n_blocks; p.skip = 0;
+        p.jbase = 0; p.jump = 0; p.pad = 0;
         statuses[i] = LZFSE_MI_OK;
         out_lens[i] = 0;
         if (h_walk[i].status) { statuses[i] = h_walk[i].status; p.skip = 1; p.n_blocks = 0; continue; }
         if (h_walk[i].raw_total > dst_cap[i]) { statuses[i] = LZFSE_MI_BUFFER_OVERFLOW; p.skip = 1; p.n_blocks = 0; continue; }
         nb += h_walk[i].n_blocks; nl += h_walk[i].n_lmds; nu += h_walk[i].n_lits;
+        // large streams: LZ stage by pointer jumping (origin indices are 32-bit over the whole batch)
+        const bool big = jump_mode < 0 ? h_walk[i].raw_total >= (2ull << 20) : jump_mode > 0;
+        if (big && h_walk[i].n_vxn == 0 && nj + h_walk[i].raw_total + 8 < 0xFFFFFFF0ull && h_walk[i].raw_total > 0) {
+            p.jump = 1; p.jbase = nj;
+            nj += (h_walk[i].raw_total + 3) & ~3ull;
+        }
     }
     if (nb > 0x7FFFFFFFull) return LZFSE_MI_UNSUPPORTED;
     if (!c->d_blocks.ensure((nb + 1) * sizeof(BlockDesc)) || !c->d_bres.ensure((nb + 1) * sizeof(BlockResult)) ||
-        !c->d_lmds.ensure((nl + 64) * sizeof(LmdRec)) || !c->d_lits.ensure(nu + 256))
+        !c->d_lmds.ensure((nl + 64) * sizeof(LmdRec)) || !c->d_lits.ensure(nu + 256) || !c->d_origin.ensure((nj + 16) * 4) ||
+        !c->d_jerr.ensure((size_t)ns * 4 + 64 * 4))
         return LZFSE_MI_IO;
+    uint32_t *d_jerr = (uint32_t *)c->d_jerr.p, *d_jflags = d_jerr + ns;
+    HIP_TRY(hipMemsetAsync(d_jerr, 0xFF, (size_t)ns * 4, st));
+    HIP_TRY(hipMemsetAsync(d_jflags, 0, 64 * 4, st));
     HIP_TRY(hipMemcpyAsync(c->d_plan.p, h_plan.data(), ns * sizeof(StreamPlan), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(c->d_bres.p, 0, (nb + 1) * sizeof(BlockResult), st));
     HIP_TRY(hipMemsetAsync(c->d_sres.p, 0, ns * sizeof(StreamResult), st));
@@ -329,6 +342,12 @@ int lzfse_mi_decode_batch_device(lzfse_mi_ctx *c, size_t count, const void *d_sr
                       (const StreamPlan *)c->d_plan.p, ns, (const BlockDesc *)c->d_blocks.p,
                       (const BlockResult *)c->d_bres.p, (const LmdRec *)c->d_lmds.p, (const uint8_t *)c->d_lits.p,
                       (uint8_t *)d_dst, (StreamResult *)c->d_sres.p, st);
+    }
+    if (nj) {
+        launch_dec_jump((const uint8_t *)d_src, (const StreamIn *)c->d_streams.p, (const StreamPlan *)c->d_plan.p,
+                        (const StreamWalk *)c->d_walk.p, ns, (const BlockDesc *)c->d_blocks.p, (uint32_t)nb,
+                        (const BlockResult *)c->d_bres.p, (const LmdRec *)c->d_lmds.p, (const uint8_t *)c->d_lits.p, (uint8_t *)d_dst,
+                        (uint32_t *)c->d_origin.p, nj, d_jerr, d_jflags, (StreamResult *)c->d_sres.p, c, st);
     }
     std::vector<StreamResult> h_sres(ns);
     HIP_TRY(hipMemcpyAsync(h_sres.data(), c->d_sres.p, ns * sizeof(StreamResult), hipMemcpyDeviceToHost, st));

@@ -38,7 +38,7 @@ struct StreamWalk {
     uint32_t n_blocks;
     int32_t status;      // first header-level error (0 = walk reached bvx$ cleanly)
     uint32_t err_block;  // block index at which `status` was raised
-    uint32_t pad;
+    uint32_t n_vxn;      // number of bvxn blocks (decoded serially by the tile LZ kernel)
 };
 
 // Per-stream bases assigned by the host after the counting walk.
@@ -46,6 +46,9 @@ struct StreamPlan {
     uint64_t blk_base, lmd_base, lit_base;
     uint32_t n_blocks;
     int32_t skip;  // != 0: stream not decoded (status already final)
+    uint64_t jbase;  // pointer-jumping LZ path: first entry of the stream in the origin array
+    int32_t jump;    // != 0: LZ stage by pointer jumping (large streams), else by the tile kernel
+    int32_t pad;
 };
 
 struct BlockDesc {

@@ -12,7 +12,9 @@
 // (one LDS table fetch + a DPP prefix sum over bit counts per step). The LZ stage runs one
 // workgroup per stream, stages a tile of output in LDS, resolves near matches there and
 // writes the tile back with coalesced 16-byte stores.
-#include "common.h"
+#include <algorithm>
+
+#include "internal.h"
 
 namespace lzmi {
 
@@ -59,7 +61,7 @@ __global__ void dec_walk_kernel(const uint8_t *__restrict__ src, const StreamIn 
     const uint8_t *base = src + in.src_off;
     uint64_t n = in.src_len, pos = 0;
     StreamWalk w;
-    w.n_lmds = 0; w.n_lits = 0; w.raw_total = 0; w.n_blocks = 0; w.status = 0; w.err_block = 0; w.pad = 0;
+    w.n_lmds = 0; w.n_lits = 0; w.raw_total = 0; w.n_blocks = 0; w.status = 0; w.err_block = 0; w.n_vxn = 0;
     uint64_t blk_i = 0, lmd_i = 0, lit_i = 0;
     if (EMIT) { blk_i = plan[s].blk_base; lmd_i = plan[s].lmd_base; lit_i = plan[s].lit_base; }
     uint32_t max_blocks = EMIT ? plan[s].n_blocks : 0xFFFFFFFFu;
@@ -92,6 +94,7 @@ __global__ void dec_walk_kernel(const uint8_t *__restrict__ src, const StreamIn 
             if (avail < 12) st = LZFSE_MI_PAYLOAD_UNDERFLOW;
             else {
                 d.kind = KIND_VXN;
+                w.n_vxn++;
                 d.n_raw = ld_u32(base + pos + 4);
                 d.payload = ld_u32(base + pos + 8);
                 skip = 12ull + d.payload;
@@ -563,7 +566,7 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
     const uint32_t s = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const StreamPlan pl = plan[s];
-    if (pl.skip) return;
+    if (pl.skip || pl.jump) return;
     const StreamIn in = streams[s];
     uint8_t *dst = dst_all + in.dst_off;
     uint64_t out_pos = 0;  // bytes produced so far in this stream
@@ -799,6 +802,143 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------------------------ LZ stage by pointer jumping
+//
+// For few, large streams one workgroup per stream is far too serial. Every output byte gets an
+// origin: itself for a literal, its position minus D for a match byte (lz/writer.rs:144-180 is
+// out[p + k] = out[p + k - D]). origin[q] always names a byte with the same final value, so
+// origin[q] <- origin[origin[q]] may be applied in any order, in place, until every origin is a
+// literal; chains of length n collapse in O(log n) rounds. The last pass gathers the bytes.
+
+constexpr int JUMP_THREADS = 256;
+
+// one workgroup per block: literals (and raw blocks) are written, origins initialised
+__global__ __launch_bounds__(JUMP_THREADS) void dec_jump_init_kernel(
+    const uint8_t *__restrict__ src, const StreamIn *__restrict__ streams, const StreamPlan *__restrict__ plan,
+    const BlockDesc *__restrict__ blocks, uint32_t n_blocks, const BlockResult *__restrict__ bres,
+    const LmdRec *__restrict__ lmds, const uint8_t *__restrict__ lits, uint8_t *dst_all, uint32_t *__restrict__ origin,
+    uint32_t *__restrict__ jerr) {
+    __shared__ uint32_t sh[2 * (JUMP_THREADS / 64) + 2];
+    const uint32_t b = blockIdx.x;
+    if (b >= n_blocks) return;
+    const BlockDesc d = blocks[b];
+    const StreamPlan pl = plan[d.stream];
+    if (pl.skip || !pl.jump) return;
+    const StreamIn in = streams[d.stream];
+    uint8_t *dst = dst_all + in.dst_off;
+    uint32_t *org = origin + pl.jbase;
+    const uint32_t jb = (uint32_t)pl.jbase;
+    const uint32_t bi = b - (uint32_t)pl.blk_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t o0 = (uint32_t)d.dst_rel;
+    if (d.kind == KIND_RAW) {
+        const uint8_t *p = src + d.src_pos + 8;
+        for (uint32_t i = tid; i < d.n_raw; i += JUMP_THREADS) { dst[o0 + i] = p[i]; org[o0 + i] = jb + o0 + i; }
+        return;
+    }
+    const BlockResult br = bres[b];
+    if (br.status) { if (tid == 0) atomicMin(&jerr[d.stream], (bi << 8) | (uint32_t)br.status); return; }
+    const LmdRec *bl = lmds + d.lmd_base;
+    const uint8_t *blit = lits + d.lit_base;
+    uint32_t run_lit = 0, run_out = 0;
+    bool bad = false;
+    for (uint32_t g0 = 0; g0 < d.n_lmd; g0 += JUMP_THREADS) {
+        const uint32_t idx = g0 + tid;
+        const bool valid = idx < d.n_lmd;
+        const LmdRec r = valid ? bl[idx] : make_uint2(0, 0);
+        const uint32_t l = r.x & 0xFFFF, m = r.x >> 16, dd = r.y;
+        uint32_t ex_l, ex_s, tot_l, tot_s;
+        block_excl_scan2<JUMP_THREADS>(l, l + m, ex_l, ex_s, tot_l, tot_s, sh);
+        const uint32_t o = o0 + run_out + ex_s;       // stream-relative position of the LMD's first byte
+        const uint32_t p = o + l;                     // ... of its match
+        const bool bad_d = valid && m != 0 && (dd == 0 || dd > p);  // lz/writer.rs:156-178
+        bad |= bad_d;
+        const uint8_t *ls = blit + run_lit + ex_l;
+        const bool l_long = l > 32, m_long = m > 32 && !bad_d;
+        if (!l_long) for (uint32_t k = 0; k < l; k++) { dst[o + k] = ls[k]; org[o + k] = jb + o + k; }
+        if (!m_long && !bad_d) for (uint32_t k = 0; k < m; k++) org[p + k] = jb + p + k - dd;
+        // long runs: the whole wave works on one lane's run at a time
+        uint64_t ql = __ballot(l_long);
+        while (ql) {
+            const int L = __builtin_ctzll(ql); ql &= ql - 1;
+            const uint32_t qo = read_lane(o, L), qn = read_lane(l, L);
+            const uint64_t qs = ((uint64_t)read_lane((uint32_t)((uintptr_t)ls >> 32), L) << 32) | read_lane((uint32_t)(uintptr_t)ls, L);
+            const uint8_t *q_ls = (const uint8_t *)(uintptr_t)qs;
+            for (uint32_t k = lane; k < qn; k += 64) { dst[qo + k] = q_ls[k]; org[qo + k] = jb + qo + k; }
+        }
+        uint64_t qm = __ballot(m_long);
+        while (qm) {
+            const int L = __builtin_ctzll(qm); qm &= qm - 1;
+            const uint32_t qp = read_lane(p, L), qn = read_lane(m, L), qd = read_lane(dd, L);
+            for (uint32_t k = lane; k < qn; k += 64) org[qp + k] = jb + qp + k - qd;
+        }
+        run_lit += tot_l; run_out += tot_s;
+    }
+    if (__any(bad) && lane == 0) atomicMin(&jerr[d.stream], (bi << 8) | (uint32_t)LZFSE_MI_BAD_D_VALUE);
+    (void)wave;
+}
+
+// one jumping round over all origins; exits at once when the previous round changed nothing
+__global__ __launch_bounds__(256) void dec_jump_round_kernel(uint32_t *__restrict__ origin, uint64_t total, uint32_t *__restrict__ flags,
+                                                             uint32_t round) {
+    if (round > 0 && flags[round - 1] == 0) return;
+    bool changed = false;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
+        const uint32_t o = origin[q];
+        if (o == (uint32_t)q) continue;
+        uint32_t o1 = origin[o];
+        if (o1 == o) continue;
+        uint32_t o2 = origin[o1];
+        uint32_t o3 = origin[o2];
+        origin[q] = o3;
+        changed = true;
+    }
+    if (__any(changed) && (threadIdx.x & 63) == 0) flags[round] = 1;
+}
+
+// gather: 4 bytes per thread
+__global__ __launch_bounds__(JUMP_THREADS) void dec_jump_apply_kernel(const StreamIn *__restrict__ streams, const StreamPlan *__restrict__ plan,
+                                                                      const BlockDesc *__restrict__ blocks, uint32_t n_blocks,
+                                                                      const BlockResult *__restrict__ bres, uint8_t *dst_all,
+                                                                      const uint32_t *__restrict__ origin, const uint32_t *__restrict__ jerr) {
+    const uint32_t b = blockIdx.x;
+    if (b >= n_blocks) return;
+    const BlockDesc d = blocks[b];
+    const StreamPlan pl = plan[d.stream];
+    if (pl.skip || !pl.jump || d.kind == KIND_RAW) return;
+    if (jerr[d.stream] != 0xFFFFFFFFu) return;
+    const StreamIn in = streams[d.stream];
+    uint8_t *dst = dst_all + in.dst_off;
+    const uint32_t *org = origin + pl.jbase;
+    const uint32_t jb = (uint32_t)pl.jbase;
+    const uint32_t o0 = (uint32_t)d.dst_rel, n = d.n_raw;
+    for (uint32_t i = threadIdx.x * 4; i < n; i += JUMP_THREADS * 4) {
+        const uint32_t q = o0 + i;
+        uint32_t w = 0;
+        const uint32_t cnt = n - i < 4 ? n - i : 4;
+        for (uint32_t k = 0; k < cnt; k++) w |= (uint32_t)dst[org[q + k] - jb] << (8 * k);
+        if (cnt == 4) __builtin_memcpy(dst + q, &w, 4);
+        else for (uint32_t k = 0; k < cnt; k++) dst[q + k] = (uint8_t)(w >> (8 * k));
+    }
+}
+
+__global__ void dec_jump_finish_kernel(const StreamPlan *__restrict__ plan, const StreamWalk *__restrict__ walk, uint32_t n_streams,
+                                       const uint32_t *__restrict__ jerr, StreamResult *__restrict__ sres) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_streams) return;
+    const StreamPlan pl = plan[s];
+    if (pl.skip || !pl.jump) return;
+    StreamResult r;
+    const uint32_t e = jerr[s];
+    r.status = e == 0xFFFFFFFFu ? 0 : (int32_t)(e & 0xFF);
+    r.out_len = r.status ? 0 : walk[s].raw_total;
+    r.groups = 0; r.n_dep = 0; r.n_long = 0;
+    for (int k = 0; k < 6; k++) r.cyc[k] = 0;
+    sres[s] = r;
+}
+
 // ------------------------------------------------------------------------------------ launchers
 
 void launch_dec_walk(bool emit, const uint8_t *src, const StreamIn *streams, uint32_t n_streams,
@@ -825,6 +965,31 @@ void launch_dec_lz(int variant, const uint8_t *src, const StreamIn *streams, con
     else
         hipLaunchKernelGGL((dec_lz_kernel<1024, 49152>), dim3(n_streams), dim3(1024), 0, st, src, streams, plan,
                            blocks, bres, lmds, lits, dst, sres);
+}
+
+void launch_dec_jump(const uint8_t *src, const StreamIn *streams, const StreamPlan *plan, const StreamWalk *walk, uint32_t n_streams,
+                     const BlockDesc *blocks, uint32_t n_blocks, const BlockResult *bres, const LmdRec *lmds, const uint8_t *lits,
+                     uint8_t *dst, uint32_t *origin, uint64_t total, uint32_t *jerr, uint32_t *flags, StreamResult *sres,
+                     lzfse_mi_ctx *c, hipStream_t st) {
+    if (!n_blocks || !total) return;
+    {
+        StageTimer t(c, "dec_jump_init");
+        hipLaunchKernelGGL(dec_jump_init_kernel, dim3(n_blocks), dim3(JUMP_THREADS), 0, st, src, streams, plan, blocks, n_blocks, bres, lmds,
+                           lits, dst, origin, jerr);
+    }
+    {
+        StageTimer t(c, "dec_jump_rounds");
+        uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256ull * 16);
+        // every round collapses chains by 4x (three dependent hops): 4^16 covers any stream below 4 GiB
+        for (uint32_t r = 0; r < 17; r++)
+            hipLaunchKernelGGL(dec_jump_round_kernel, dim3(grid), dim3(256), 0, st, origin, total, flags, r);
+    }
+    {
+        StageTimer t(c, "dec_jump_apply");
+        hipLaunchKernelGGL(dec_jump_apply_kernel, dim3(n_blocks), dim3(JUMP_THREADS), 0, st, streams, plan, blocks, n_blocks, bres, dst,
+                           origin, jerr);
+        hipLaunchKernelGGL(dec_jump_finish_kernel, dim3((n_streams + 63) / 64), dim3(64), 0, st, plan, walk, n_streams, jerr, sres);
+    }
 }
 
 }  // namespace lzmi

@@ -24,6 +24,11 @@ void launch_dec_lz(int variant, const uint8_t *src, const StreamIn *streams, con
                    uint32_t n_streams, const BlockDesc *blocks, const BlockResult *bres, const LmdRec *lmds,
                    const uint8_t *lits, uint8_t *dst, StreamResult *sres, hipStream_t st);
 
+void launch_dec_jump(const uint8_t *src, const StreamIn *streams, const StreamPlan *plan, const StreamWalk *walk, uint32_t n_streams,
+                     const BlockDesc *blocks, uint32_t n_blocks, const BlockResult *bres, const LmdRec *lmds, const uint8_t *lits,
+                     uint8_t *dst, uint32_t *origin, uint64_t total, uint32_t *jerr, uint32_t *flags, StreamResult *sres,
+                     lzfse_mi_ctx *c, hipStream_t st);
+
 // ---- encode.hip ----
 struct EncScratch {
     void *bufs[32] = {};

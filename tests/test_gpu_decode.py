@@ -102,3 +102,36 @@ def test_decode_capacity_too_small(ctx, oracle, snappy_raw):
     enc = oracle.encode(snappy_raw["html"])
     outs, st = ctx.decode_batch([enc], caps=[1000])
     assert st[0] == 6
+
+
+def test_decode_pointer_jumping_path(ctx, oracle, golden_dir, snappy_raw):
+    """The LZ stage for large streams (origin pointer jumping) forced on for every stream."""
+    fs = _fixture_files(golden_dir)
+    srcs = [open(f, "rb").read() for f in fs]
+    raws = [bytes(700000), b"abc" * 300000, seq_masked(4, 0x01010101, 3 << 20), bytes(range(256)) * 9000,
+            snappy_raw["html_x_4"] * 6]
+    encs = [oracle.encode(r) for r in raws]
+    os.environ["LZFSE_MI_LZ_JUMP"] = "1"
+    try:
+        outs, st = ctx.decode_batch(srcs + encs)
+        # malformed input through the same path
+        base = bytearray(open(os.path.join(golden_dir, "mutate", "vx2.lzfse"), "rb").read())
+        cases = []
+        rng = np.random.default_rng(5)
+        for i in rng.choice(len(base), size=200, replace=False):
+            m = bytearray(base)
+            m[i] ^= 1 << int(rng.integers(0, 8))
+            cases.append(bytes(m))
+        outs2, st2 = ctx.decode_batch(cases, caps=[1 << 20] * len(cases))
+    finally:
+        del os.environ["LZFSE_MI_LZ_JUMP"]
+    for f, s, o, e in zip(fs, srcs, outs, st):
+        assert e == 0, f
+        assert hashlib.sha256(o.tobytes()).digest() == open(f[:-6] + ".hash", "rb").read(), f
+    for r, o, e in zip(raws, outs[len(fs):], st[len(fs):]):
+        assert e == 0 and o.tobytes() == r
+    for c, o, e in zip(cases, outs2, st2):
+        es = oracle.decode_status(c, 1 << 20)
+        assert (e == 0) == (es == 0), (e, es)
+        if e == 0:
+            assert o.tobytes() == oracle.decode(c, cap=1 << 20)
