@@ -95,13 +95,14 @@ __host__ __device__ inline uint32_t stage_need(uint32_t n_lit, uint32_t n_lmd) {
 // encode_parse.hip
 void launch_enc_spec(const uint8_t *src, const EncStream *streams, const uint2 *segs, uint32_t n_segs, const uint2 *prev,
                      const uint2 *rec, const uint64_t *bitmap, SpecEvent *logs, SpecHeader *hdrs, hipStream_t st);
-void launch_enc_stitch(const uint8_t *src, const EncStream *streams, uint32_t ns, const uint2 *prev, const uint2 *rec,
-                       const uint64_t *bitmap, const SpecEvent *logs, const SpecHeader *hdrs, RangeRec *ranges, MatchRec *gaps,
-                       EncStreamOut *outs, hipStream_t st);
-void launch_enc_compact(const EncStream *streams, const uint32_t *slot_stream, uint32_t n_slots, const EncStreamOut *outs,
-                        const RangeRec *ranges, const SpecEvent *logs, const MatchRec *gaps, MatchRec *matches, hipStream_t st);
-void launch_enc_segment(const EncStream *streams, uint32_t ns, const MatchRec *matches, uint32_t *pc, uint32_t *pl, uint2 *lmds,
-                        EncBlock *blocks, EncStreamOut *outs, hipStream_t st);
+void launch_enc_stitch(const uint8_t *src, const EncStream *streams, uint32_t ns, const uint2 *segs, uint32_t n_segs, const uint2 *prev,
+                       const uint2 *rec, const uint64_t *bitmap, const SpecEvent *logs, const SpecHeader *hdrs, uint4 *sync,
+                       RangeRec *ranges, MatchRec *gaps, EncStreamOut *outs, hipStream_t st);
+void launch_enc_compact(const EncStream *streams, const uint32_t *slot_stream, uint32_t n_slots, uint32_t ns, const EncStreamOut *outs,
+                        const RangeRec *ranges, const SpecEvent *logs, const MatchRec *gaps, MatchRec *matches, uint32_t *pc,
+                        uint32_t *pl, uint2 *rsum, hipStream_t st);
+void launch_enc_segment(const EncStream *streams, uint32_t ns, const MatchRec *matches, const uint32_t *pc, const uint32_t *pl,
+                        uint2 *lmds, EncBlock *blocks, EncStreamOut *outs, hipStream_t st);
 void launch_enc_lmd(const EncStream *streams, const uint32_t *slot_stream, uint32_t n_slots, const EncStreamOut *outs,
                     const EncBlock *blocks, const MatchRec *matches, const uint32_t *pc, uint2 *lmds, hipStream_t st);
 

@@ -981,46 +981,57 @@ __global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *_
 
 // ------------------------------------------------------------------------------------ pack
 
-// One workgroup per stream: concatenates the blocks' three staged segments and appends bvx$.
-__global__ __launch_bounds__(256) void enc_pack_kernel(const EncStream *__restrict__ streams, uint32_t n_streams,
+// One workgroup per block slot: the block's three staged segments go to their final position (sum of
+// the sizes of the stream's earlier blocks); the last block appends bvx$ and reports the length.
+__global__ __launch_bounds__(256) void enc_pack_kernel(const EncStream *__restrict__ streams, const uint32_t *__restrict__ slot_stream,
                                                        const EncBlock *__restrict__ blocks, const uint8_t *__restrict__ stage,
                                                        uint8_t *__restrict__ dst, EncStreamOut *__restrict__ outs) {
-    const uint32_t si = blockIdx.x;
-    if (si >= n_streams) return;
+    __shared__ unsigned long long sh_sum[4];
+    const uint32_t slot = blockIdx.x;
+    const uint32_t si = slot_stream[slot];
     const EncStream st = streams[si];
-    EncStreamOut so = outs[si];
-    if (so.status) return;
+    const uint32_t bi = slot - st.blk_base;
+    const EncStreamOut so = outs[si];
+    if (so.status || bi >= so.n_blocks) return;
     const int tid = threadIdx.x;
-    uint8_t *d = dst + st.dst_off;
-    uint64_t pos = 0;
-    bool overflow = false;
-    for (uint32_t b = 0; b < so.n_blocks; b++) {
-        const EncBlock blk = blocks[st.blk_base + b];
-        const uint8_t *sg = stage + blk.stage_off;
-        uint64_t need = (uint64_t)blk.hdr_len + blk.lit_len + blk.lmd_len;
-        if (pos + need + 4 > st.dst_cap) { overflow = true; break; }
-        for (uint32_t i = tid; i < blk.hdr_len; i += 256) d[pos + i] = sg[i];
-        pos += blk.hdr_len;
-        const uint8_t *ls = sg + stage_lit_off();
-        for (uint32_t i = tid; i < blk.lit_len; i += 256) d[pos + i] = ls[i];
-        pos += blk.lit_len;
-        const uint8_t *ms = sg + stage_lmd_off(blk.n_lit);
-        for (uint32_t i = tid; i < blk.lmd_len; i += 256) d[pos + i] = ms[i];
-        pos += blk.lmd_len;
+    unsigned long long part = 0;
+    for (uint32_t b = tid; b < bi; b += 256) {
+        const EncBlock e = blocks[st.blk_base + b];
+        part += (unsigned long long)e.hdr_len + e.lit_len + e.lmd_len;
     }
-    if (!overflow && pos + 4 > st.dst_cap) overflow = true;
-    if (!overflow && tid < 4) d[pos + tid] = (uint8_t)(MAGIC_EOS >> (8 * tid));
-    if (tid == 0) {
-        so.status = overflow ? LZFSE_MI_BUFFER_OVERFLOW : 0;
-        so.out_len = overflow ? 0 : pos + 4;
-        outs[si] = so;
+    for (int d2 = 32; d2 > 0; d2 >>= 1) part += __shfl_down(part, d2);
+    if ((tid & 63) == 0) sh_sum[tid >> 6] = part;
+    __syncthreads();
+    const uint64_t pos0 = sh_sum[0] + sh_sum[1] + sh_sum[2] + sh_sum[3];
+    const EncBlock blk = blocks[slot];
+    const uint64_t need = (uint64_t)blk.hdr_len + blk.lit_len + blk.lmd_len;
+    const bool last = bi + 1 == so.n_blocks;
+    const bool fits = pos0 + need + 4 <= st.dst_cap;
+    if (fits) {
+        uint8_t *d = dst + st.dst_off + pos0;
+        const uint8_t *sg = stage + blk.stage_off;
+        for (uint32_t i = tid; i < blk.hdr_len; i += 256) d[i] = sg[i];
+        d += blk.hdr_len;
+        const uint8_t *ls = sg + stage_lit_off();
+        for (uint32_t i = tid; i < blk.lit_len; i += 256) d[i] = ls[i];
+        d += blk.lit_len;
+        const uint8_t *ms = sg + stage_lmd_off(blk.n_lit);
+        for (uint32_t i = tid; i < blk.lmd_len; i += 256) d[i] = ms[i];
+        if (last && tid < 4) d[blk.lmd_len + tid] = (uint8_t)(MAGIC_EOS >> (8 * tid));
+    }
+    if (last && tid == 0) {
+        // earlier blocks fit whenever the last one does (positions are increasing)
+        EncStreamOut o = so;
+        o.status = fits ? 0 : LZFSE_MI_BUFFER_OVERFLOW;
+        o.out_len = fits ? pos0 + need + 4 : 0;
+        outs[si] = o;
     }
 }
 
 // ------------------------------------------------------------------------------------ host side
 
 enum { EB_STREAMS, EB_TILES, EB_PREV, EB_SUMMARY, EB_REC, EB_LMDS, EB_BLOCKS, EB_OUTS, EB_STAGE, EB_SLOTS,
-       EB_BITMAP, EB_SEGS, EB_LOGS, EB_HDRS, EB_RANGES, EB_GAPS, EB_MATCHES, EB_PC, EB_PL, EB_RSLOTS, EB_N };
+       EB_BITMAP, EB_SEGS, EB_LOGS, EB_HDRS, EB_RANGES, EB_GAPS, EB_MATCHES, EB_PC, EB_PL, EB_RSLOTS, EB_SYNC, EB_RSUM, EB_N };
 static_assert(EB_N <= 32, "EncScratch slots");
 
 static bool eb_ensure(EncScratch &s, int i, size_t n) {
@@ -1117,7 +1128,8 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
          !eb_ensure(S, EB_HDRS, (size_t)nseg * sizeof(SpecHeader)) || !eb_ensure(S, EB_RANGES, (size_t)range_total * sizeof(RangeRec)) ||
          !eb_ensure(S, EB_GAPS, match_total * sizeof(MatchRec)) || !eb_ensure(S, EB_MATCHES, match_total * sizeof(MatchRec)) ||
          !eb_ensure(S, EB_PC, match_total * 4) || !eb_ensure(S, EB_PL, match_total * 4) ||
-         !eb_ensure(S, EB_RSLOTS, (size_t)range_total * 4)))
+         !eb_ensure(S, EB_RSLOTS, (size_t)range_total * 4) || !eb_ensure(S, EB_SYNC, (size_t)nseg * sizeof(uint4)) ||
+         !eb_ensure(S, EB_RSUM, (size_t)range_total * sizeof(uint2))))
         return LZFSE_MI_IO;
     EncStream *d_streams = (EncStream *)S.bufs[EB_STREAMS];
     EncTile *d_tiles = (EncTile *)S.bufs[EB_TILES];
@@ -1165,11 +1177,13 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         }
         {
             StageTimer t(c, "enc_stitch");
-            launch_enc_stitch(d_src, d_streams, ns, d_prev, d_rec, d_bitmap, d_logs, d_hdrs, d_ranges, d_gaps, d_outs, stq);
+            launch_enc_stitch(d_src, d_streams, ns, d_segs, nseg, d_prev, d_rec, d_bitmap, d_logs, d_hdrs, (uint4 *)S.bufs[EB_SYNC], d_ranges, d_gaps,
+                              d_outs, stq);
         }
         {
             StageTimer t(c, "enc_compact");
-            launch_enc_compact(d_streams, d_rslots, range_total, d_outs, d_ranges, d_logs, d_gaps, d_matches, stq);
+            launch_enc_compact(d_streams, d_rslots, range_total, ns, d_outs, d_ranges, d_logs, d_gaps, d_matches, d_pc, d_pl,
+                               (uint2 *)S.bufs[EB_RSUM], stq);
         }
         {
             StageTimer t(c, "enc_segment");
@@ -1187,7 +1201,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     }
     {
         StageTimer t(c, "enc_pack");
-        hipLaunchKernelGGL(enc_pack_kernel, dim3(ns), dim3(256), 0, stq, d_streams, ns, d_blocks, d_stage, d_dst, d_outs);
+        hipLaunchKernelGGL(enc_pack_kernel, dim3(blk_total), dim3(256), 0, stq, d_streams, d_slots, d_blocks, d_stage, d_dst, d_outs);
     }
     std::vector<EncStreamOut> ho(ns);
     E_TRY(hipMemcpyAsync(ho.data(), d_outs, ns * sizeof(EncStreamOut), hipMemcpyDeviceToHost, stq));

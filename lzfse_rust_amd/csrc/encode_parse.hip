@@ -227,6 +227,30 @@ __device__ __forceinline__ uint32_t ev_lower_bound(const SpecEvent *ev, uint32_t
     return lo;
 }
 
+// One thread per segment boundary: the first pair of events of log k (from the start of segment
+// k + 1 on) and log k + 1 whose state-after is identical. Independent of every other boundary.
+__global__ __launch_bounds__(64) void enc_sync_kernel(const EncStream *__restrict__ streams, const uint2 *__restrict__ segs,
+                                                      uint32_t n_segs, const SpecEvent *__restrict__ logs,
+                                                      const SpecHeader *__restrict__ hdrs, uint4 *__restrict__ sync) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_segs) return;
+    const uint2 sg = segs[g];
+    uint4 out = make_uint4(0, 0, 0, 0);
+    if (sg.y + 1 < streams[sg.x].n_seg) {
+        const uint32_t nk = hdrs[g].n_events, nk1 = hdrs[g + 1].n_events;
+        const SpecEvent *Lk = logs + (uint64_t)g * SEG_EV_CAP, *Lk1 = Lk + SEG_EV_CAP;
+        uint32_t i = ev_lower_bound(Lk, nk, (sg.y + 1) * SEG), j = 0;
+        while (i < nk && j < nk1) {
+            const uint32_t ia = Lk[i].index_after, ja = Lk1[j].index_after;
+            if (ia < ja) i++;
+            else if (ia > ja) j++;
+            else if (ev_state_eq(Lk[i], Lk1[j])) { out = make_uint4(1, i, j, 0); break; }
+            else { i++; j++; }
+        }
+    }
+    sync[g] = out;
+}
+
 struct Stitch {
     RangeRec *ranges;
     uint32_t n_ranges, range_cap;
@@ -269,8 +293,8 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
                                                         uint32_t n_streams, const uint2 *__restrict__ prev,
                                                         const uint2 *__restrict__ rec, const uint64_t *__restrict__ bitmap,
                                                         const SpecEvent *__restrict__ logs, const SpecHeader *__restrict__ hdrs,
-                                                        RangeRec *__restrict__ ranges, MatchRec *__restrict__ gaps,
-                                                        EncStreamOut *__restrict__ outs) {
+                                                        const uint4 *__restrict__ sync, RangeRec *__restrict__ ranges,
+                                                        MatchRec *__restrict__ gaps, EncStreamOut *__restrict__ outs) {
     const uint32_t si = blockIdx.x;
     if (si >= n_streams) return;
     const EncStream &es = streams[si];
@@ -298,17 +322,10 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
             const SpecEvent *Lk = L0 + (uint64_t)k * SEG_EV_CAP;
             bool found = false;
             if (k + 1 < K) {
-                const uint32_t nk1 = H0[k + 1].n_events;
-                const SpecEvent *Lk1 = Lk + SEG_EV_CAP;
-                uint32_t i = ev_lower_bound(Lk, hk.n_events, (k + 1) * SEG), j = 0;
-                while (i < hk.n_events && j < nk1) {
-                    const SpecEvent ei = Lk[i], ej = Lk1[j];
-                    if (ei.index_after < ej.index_after) i++;
-                    else if (ei.index_after > ej.index_after) j++;
-                    else if (ev_state_eq(ei, ej)) { found = true; break; }
-                    else { i++; j++; }
-                }
-                if (found) {
+                const uint4 sy = sync[es.seg_base + k];  // enc_sync_kernel: (found, i, j)
+                if (sy.x) {
+                    found = true;
+                    const uint32_t i = sy.y, j = sy.z;
                     // logs run in lock-step from (i, j) on; hand over no earlier than event a - 1
                     uint32_t i_eff = (a > 0 && i + 1 < a) ? a - 1 : i;
                     uint32_t j_eff = j + (i_eff - i);
@@ -418,11 +435,13 @@ __device__ __forceinline__ uint32_t lmd_count_of(uint32_t l, uint32_t m) {
     return a + b;
 }
 
-// one wave per range slot
+// one wave per range slot: copies the range's events into the ordered match list and leaves the
+// range-local inclusive prefix sums of (LMD count, literal count) in pc / pl plus the range totals
 __global__ __launch_bounds__(64) void enc_compact_kernel(const EncStream *__restrict__ streams, const uint32_t *__restrict__ slot_stream,
                                                          const EncStreamOut *__restrict__ outs, const RangeRec *__restrict__ ranges,
                                                          const SpecEvent *__restrict__ logs, const MatchRec *__restrict__ gaps,
-                                                         MatchRec *__restrict__ matches) {
+                                                         MatchRec *__restrict__ matches, uint32_t *__restrict__ pc,
+                                                         uint32_t *__restrict__ pl, uint2 *__restrict__ rsum) {
     const uint32_t slot = blockIdx.x;
     const uint32_t si = slot_stream[slot];
     const EncStream &es = streams[si];
@@ -431,24 +450,92 @@ __global__ __launch_bounds__(64) void enc_compact_kernel(const EncStream *__rest
     if (so.status || ri >= so.n_ranges) return;
     const RangeRec rg = ranges[slot];
     MatchRec *out = matches + es.match_base + rg.out_off;
+    uint32_t *PC = pc + es.match_base + rg.out_off, *PL = pl + es.match_base + rg.out_off;
     const int lane = e_lane();
-    if (rg.kind == 0) {
-        const SpecEvent *ev = logs + rg.begin;
-        for (uint32_t q = lane; q < rg.count; q += 64) {
-            const SpecEvent e = ev[q];
-            MatchRec m;
-            m.lit_pos = e.e_lit; m.l = e.e_idx - e.e_lit; m.m = e.e_len; m.d = e.e_dist;
+    const SpecEvent *ev = logs + rg.begin;
+    const MatchRec *g = gaps + es.match_base + rg.begin;
+    uint32_t carry_c = 0, carry_l = 0;
+    for (uint32_t q0 = 0; q0 < rg.count; q0 += 64) {
+        const uint32_t q = q0 + lane;
+        MatchRec m = {0, 0, 0, 0};
+        uint32_t c = 0;
+        if (q < rg.count) {
+            if (rg.kind == 0) {
+                const SpecEvent e = ev[q];
+                m.lit_pos = e.e_lit; m.l = e.e_idx - e.e_lit; m.m = e.e_len; m.d = e.e_dist;
+            } else {
+                m = g[q];
+            }
             out[q] = m;
+            c = lmd_count_of(m.l, m.m);
         }
-    } else {
-        const MatchRec *g = gaps + es.match_base + rg.begin;
-        for (uint32_t q = lane; q < rg.count; q += 64) out[q] = g[q];
+        uint32_t ic = c, il = m.l;
+#pragma unroll
+        for (int d2 = 1; d2 < 64; d2 <<= 1) {
+            uint32_t xx = __shfl_up(ic, d2), yy = __shfl_up(il, d2);
+            if (lane >= d2) { ic += xx; il += yy; }
+        }
+        if (q < rg.count) { PC[q] = carry_c + ic; PL[q] = carry_l + il; }
+        carry_c += e_readlane(ic, 63);
+        carry_l += e_readlane(il, 63);
     }
+    if (lane == 0) rsum[slot] = make_uint2(carry_c, carry_l);
+}
+
+// one workgroup per stream: exclusive scan of the range totals
+__global__ __launch_bounds__(1024) void enc_rscan_kernel(const EncStream *__restrict__ streams, uint32_t n_streams,
+                                                         const EncStreamOut *__restrict__ outs, uint2 *__restrict__ rsum) {
+    __shared__ uint32_t sh[2 * 16 + 2];
+    const uint32_t si = blockIdx.x;
+    if (si >= n_streams) return;
+    const EncStream &es = streams[si];
+    const EncStreamOut so = outs[si];
+    if (so.status) return;
+    uint2 *rs = rsum + es.range_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t carry_c = 0, carry_l = 0;
+    for (uint32_t g0 = 0; g0 < so.n_ranges; g0 += 1024) {
+        const uint32_t j = g0 + tid;
+        const uint2 v = j < so.n_ranges ? rs[j] : make_uint2(0, 0);
+        uint32_t ic = v.x, il = v.y;
+#pragma unroll
+        for (int d2 = 1; d2 < 64; d2 <<= 1) {
+            uint32_t xx = __shfl_up(ic, d2), yy = __shfl_up(il, d2);
+            if (lane >= d2) { ic += xx; il += yy; }
+        }
+        if (lane == 63) { sh[wave] = ic; sh[16 + wave] = il; }
+        __syncthreads();
+        uint32_t oc = 0, ol = 0, tc = 0, tl = 0;
+        for (int w = 0; w < 16; w++) {
+            uint32_t xx = sh[w], yy = sh[16 + w];
+            if (w < wave) { oc += xx; ol += yy; }
+            tc += xx; tl += yy;
+        }
+        if (j < so.n_ranges) rs[j] = make_uint2(carry_c + oc + ic - v.x, carry_l + ol + il - v.y);  // exclusive
+        carry_c += tc; carry_l += tl;
+        __syncthreads();
+    }
+}
+
+// one wave per range slot: range-local prefix sums -> stream-wide prefix sums
+__global__ __launch_bounds__(64) void enc_papply_kernel(const EncStream *__restrict__ streams, const uint32_t *__restrict__ slot_stream,
+                                                        const EncStreamOut *__restrict__ outs, const RangeRec *__restrict__ ranges,
+                                                        const uint2 *__restrict__ rsum, uint32_t *__restrict__ pc, uint32_t *__restrict__ pl) {
+    const uint32_t slot = blockIdx.x;
+    const uint32_t si = slot_stream[slot];
+    const EncStream &es = streams[si];
+    const uint32_t ri = slot - es.range_base;
+    const EncStreamOut so = outs[si];
+    if (so.status || ri >= so.n_ranges) return;
+    const RangeRec rg = ranges[slot];
+    const uint2 off = rsum[slot];
+    uint32_t *PC = pc + es.match_base + rg.out_off, *PL = pl + es.match_base + rg.out_off;
+    for (uint32_t q = e_lane(); q < rg.count; q += 64) { PC[q] += off.x; PL[q] += off.y; }
 }
 
 // ------------------------------------------------------------------------------------ block segmentation
 
-constexpr int SEGM_THREADS = 1024;
+constexpr int SEGM_THREADS = 64;
 
 struct Emit {  // serial LMD emitter used for the (rare) events that straddle a block boundary
     uint2 *lmds;
@@ -495,48 +582,20 @@ __device__ bool em_buffer_push(Emit &w, uint32_t &n_lit, uint32_t &match_len, ui
     return true;
 }
 
-// One workgroup per stream: prefix sums of per-event LMD and literal counts, then thread 0 cuts
-// the event list into bvx2 blocks.
+// One thread per stream cuts the event list into bvx2 blocks, using the stream-wide inclusive prefix
+// sums of per-event LMD and literal counts (enc_compact / enc_rscan / enc_papply).
 __global__ __launch_bounds__(SEGM_THREADS) void enc_segment_kernel(const EncStream *__restrict__ streams, uint32_t n_streams,
-                                                                  const MatchRec *__restrict__ matches, uint32_t *__restrict__ pc,
-                                                                  uint32_t *__restrict__ pl, uint2 *__restrict__ lmds,
+                                                                  const MatchRec *__restrict__ matches, const uint32_t *__restrict__ pc,
+                                                                  const uint32_t *__restrict__ pl, uint2 *__restrict__ lmds,
                                                                   EncBlock *__restrict__ blocks, EncStreamOut *__restrict__ outs) {
-    __shared__ uint32_t sh[2 * (SEGM_THREADS / 64) + 2];
-    const uint32_t si = blockIdx.x;
+    const uint32_t si = blockIdx.x * blockDim.x + threadIdx.x;
     if (si >= n_streams) return;
     const EncStream &es = streams[si];
     EncStreamOut so = outs[si];
     if (so.status) return;
     const uint32_t E = so.n_matches;
     const MatchRec *mt = matches + es.match_base;
-    uint32_t *PC = pc + es.match_base, *PL = pl + es.match_base;  // inclusive prefix sums
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t carry_c = 0, carry_l = 0;
-    for (uint32_t g0 = 0; g0 < E; g0 += SEGM_THREADS) {
-        uint32_t j = g0 + tid;
-        uint32_t c = 0, l = 0;
-        if (j < E) { MatchRec m = mt[j]; c = lmd_count_of(m.l, m.m); l = m.l; }
-        uint32_t ic = c, il = l;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t xx = __shfl_up(ic, d), yy = __shfl_up(il, d);
-            if (lane >= d) { ic += xx; il += yy; }
-        }
-        if (lane == 63) { sh[wave] = ic; sh[SEGM_THREADS / 64 + wave] = il; }
-        __syncthreads();
-        uint32_t oc = 0, ol = 0, tc = 0, tl = 0;
-        for (int w = 0; w < SEGM_THREADS / 64; w++) {
-            uint32_t xx = sh[w], yy = sh[SEGM_THREADS / 64 + w];
-            if (w < wave) { oc += xx; ol += yy; }
-            tc += xx; tl += yy;
-        }
-        if (j < E) { PC[j] = carry_c + oc + ic; PL[j] = carry_l + ol + il; }
-        carry_c += tc; carry_l += tl;
-        __syncthreads();
-    }
-    __threadfence_block();
-    __syncthreads();
-    if (tid != 0) return;
+    const uint32_t *PC = pc + es.match_base, *PL = pl + es.match_base;  // inclusive prefix sums
     // ---- serial over blocks ----
     Emit w;
     w.lmds = lmds + es.lmd_base; w.lmd_cap = es.lmd_cap; w.lmd_count = 0;
@@ -657,19 +716,26 @@ void launch_enc_spec(const uint8_t *src, const EncStream *streams, const uint2 *
     hipLaunchKernelGGL(enc_spec_kernel, dim3((n_segs + 63) / 64), dim3(64), 0, st, src, streams, segs, n_segs, prev, rec, bitmap, logs,
                        hdrs);
 }
-void launch_enc_stitch(const uint8_t *src, const EncStream *streams, uint32_t ns, const uint2 *prev, const uint2 *rec,
-                       const uint64_t *bitmap, const SpecEvent *logs, const SpecHeader *hdrs, RangeRec *ranges, MatchRec *gaps,
-                       EncStreamOut *outs, hipStream_t st) {
-    hipLaunchKernelGGL(enc_stitch_kernel, dim3(ns), dim3(64), 0, st, src, streams, ns, prev, rec, bitmap, logs, hdrs, ranges, gaps, outs);
+void launch_enc_stitch(const uint8_t *src, const EncStream *streams, uint32_t ns, const uint2 *segs, uint32_t n_segs, const uint2 *prev,
+                       const uint2 *rec, const uint64_t *bitmap, const SpecEvent *logs, const SpecHeader *hdrs, uint4 *sync,
+                       RangeRec *ranges, MatchRec *gaps, EncStreamOut *outs, hipStream_t st) {
+    hipLaunchKernelGGL(enc_sync_kernel, dim3((n_segs + 63) / 64), dim3(64), 0, st, streams, segs, n_segs, logs, hdrs, sync);
+    hipLaunchKernelGGL(enc_stitch_kernel, dim3(ns), dim3(64), 0, st, src, streams, ns, prev, rec, bitmap, logs, hdrs, sync, ranges, gaps,
+                       outs);
 }
-void launch_enc_compact(const EncStream *streams, const uint32_t *slot_stream, uint32_t n_slots, const EncStreamOut *outs,
-                        const RangeRec *ranges, const SpecEvent *logs, const MatchRec *gaps, MatchRec *matches, hipStream_t st) {
+void launch_enc_compact(const EncStream *streams, const uint32_t *slot_stream, uint32_t n_slots, uint32_t ns, const EncStreamOut *outs,
+                        const RangeRec *ranges, const SpecEvent *logs, const MatchRec *gaps, MatchRec *matches, uint32_t *pc,
+                        uint32_t *pl, uint2 *rsum, hipStream_t st) {
     if (!n_slots) return;
-    hipLaunchKernelGGL(enc_compact_kernel, dim3(n_slots), dim3(64), 0, st, streams, slot_stream, outs, ranges, logs, gaps, matches);
+    hipLaunchKernelGGL(enc_compact_kernel, dim3(n_slots), dim3(64), 0, st, streams, slot_stream, outs, ranges, logs, gaps, matches, pc, pl,
+                       rsum);
+    hipLaunchKernelGGL(enc_rscan_kernel, dim3(ns), dim3(1024), 0, st, streams, ns, outs, rsum);
+    hipLaunchKernelGGL(enc_papply_kernel, dim3(n_slots), dim3(64), 0, st, streams, slot_stream, outs, ranges, rsum, pc, pl);
 }
-void launch_enc_segment(const EncStream *streams, uint32_t ns, const MatchRec *matches, uint32_t *pc, uint32_t *pl, uint2 *lmds,
-                        EncBlock *blocks, EncStreamOut *outs, hipStream_t st) {
-    hipLaunchKernelGGL(enc_segment_kernel, dim3(ns), dim3(SEGM_THREADS), 0, st, streams, ns, matches, pc, pl, lmds, blocks, outs);
+void launch_enc_segment(const EncStream *streams, uint32_t ns, const MatchRec *matches, const uint32_t *pc, const uint32_t *pl,
+                        uint2 *lmds, EncBlock *blocks, EncStreamOut *outs, hipStream_t st) {
+    hipLaunchKernelGGL(enc_segment_kernel, dim3((ns + SEGM_THREADS - 1) / SEGM_THREADS), dim3(SEGM_THREADS), 0, st, streams, ns, matches,
+                       pc, pl, lmds, blocks, outs);
 }
 void launch_enc_lmd(const EncStream *streams, const uint32_t *slot_stream, uint32_t n_slots, const EncStreamOut *outs,
                     const EncBlock *blocks, const MatchRec *matches, const uint32_t *pc, uint2 *lmds, hipStream_t st) {
