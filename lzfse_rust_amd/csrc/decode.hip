@@ -127,85 +127,80 @@ __global__ void dec_walk_kernel(const uint8_t *__restrict__ src, const StreamIn 
 
 // ------------------------------------------------------------------------------------ FSE stage
 
-// Backward bit reader (bits/bit_reader.rs:11-72) for one wave. The payload is streamed through
-// a 512-byte LDS ring (two 256-byte halves) that all 64 lanes refill with coalesced dword loads
-// ahead of the cursor; the 64-bit window itself lives in registers.
+// Backward bit reader (bits/bit_reader.rs:11-72) for one wave, restated on bit positions: the
+// stream is one little-endian integer read from its top; after c bits have been pulled the next
+// pull(n) returns bits [rem - n, rem) with rem = 8 len - off - c. The reference's 64-bit accumulator
+// and byte-wise flush are an implementation of exactly this, and its final under-run test
+// (accum_bits + 8 idx < 64) is rem < 64 (the 8 pad bytes must stay untouched).
+//
+// All positions are in bits relative to the 4-byte aligned address A <= base. The payload is
+// streamed through a linear 128-dword LDS buffer holding dwords [cb, cb + 128) of A-space; when the
+// cursor gets near the bottom the lower half moves up and a half prefetched 64 steps earlier drops in.
 struct BitWindow {
-    uint64_t acc;
-    int32_t avail;   // accum_bits
-    int64_t pos;     // idx relative to the reader base (the 8 pad bytes)
-    // ring state
-    const uint8_t *gbase;     // address of reader base in global memory
+    int32_t rem;              // bits remaining, A-space (uniform)
+    int32_t base_bit;         // 8 * (base - A)
+    int32_t cb;               // A-space dword index of buf[0] (uniform, may be negative)
+    uint32_t *buf;            // 128 dwords in LDS
+    const uint8_t *ga;        // A
     const uint8_t *glo, *ghi; // readable range of the source buffer
-    uint32_t *ring;           // 128 dwords in LDS
-    int64_t cb;               // absolute dword index (address / 4) of the lowest dword held
-    uint32_t pend;            // prefetched dword for the half below cb
-    int has_pend;
+    uint32_t pend;            // prefetched dword (cb - 64 + lane)
 };
 
-__device__ __forceinline__ uint32_t bw_gload(const BitWindow &w, int64_t dw) {
-    const uint8_t *a = (const uint8_t *)(uintptr_t)((uint64_t)dw << 2);
+__device__ __forceinline__ uint32_t bw_gload(const BitWindow &w, int32_t dw) {
+    const uint8_t *a = w.ga + (int64_t)dw * 4;
     return (a >= w.glo && a + 4 <= w.ghi) ? *(const uint32_t *)a : 0u;
 }
 
+// the 64 bits below `rem`: bits [rem - 64, rem)
 __device__ __forceinline__ uint64_t bw_window(const BitWindow &w) {
-    if (w.pos < 0) return 0;  // bit_src.rs:36-45
-    uint64_t a = (uint64_t)(uintptr_t)w.gbase + (uint64_t)w.pos;
-    int64_t dw = (int64_t)(a >> 2);
-    uint32_t sh = (uint32_t)(a & 3) * 8;
-    uint32_t d0 = w.ring[(dw) & 127], d1 = w.ring[(dw + 1) & 127], d2 = w.ring[(dw + 2) & 127];
-    uint64_t lo = (uint64_t)d0 | ((uint64_t)d1 << 32);
-    return sh ? ((lo >> sh) | ((uint64_t)d2 << (64 - sh))) : lo;
+    const int32_t lo = w.rem - 64;
+    const int32_t slot = (lo >> 5) - w.cb;      // 0 <= slot <= 125 by the rotation invariant
+    const uint32_t sh = (uint32_t)lo & 31;
+    const uint32_t d0 = w.buf[slot], d1 = w.buf[slot + 1], d2 = w.buf[slot + 2];
+    const uint32_t x0 = __builtin_amdgcn_alignbit(d1, d0, sh), x1 = __builtin_amdgcn_alignbit(d2, d1, sh);
+    return (uint64_t)x0 | ((uint64_t)x1 << 32);
 }
 
-// init: pos = len - 8 (bit_reader.rs:20-30). Returns BadBitStream per the reference check.
-__device__ inline int bw_init(BitWindow &w, const uint8_t *gbase, uint32_t len, uint32_t off,
-                              const uint8_t *glo, const uint8_t *ghi, uint32_t *ring) {
-    w.gbase = gbase; w.glo = glo; w.ghi = ghi; w.ring = ring;
-    w.pos = (int64_t)len - 8;
-    uint64_t a = (uint64_t)(uintptr_t)gbase + (uint64_t)w.pos;
-    int64_t dw = (int64_t)(a >> 2);
-    w.cb = dw & ~63ll;
-    int l = lane_id();
-    // hold [cb, cb+128); the window needs dw .. dw+2 < cb + 66
-    ring[(w.cb + l) & 127] = bw_gload(w, w.cb + l);
-    ring[(w.cb + 64 + l) & 127] = bw_gload(w, w.cb + 64 + l);
+// bit_reader.rs:20-30; len counts the 8 pad bytes in front of the payload
+__device__ inline int bw_init(BitWindow &w, const uint8_t *base, uint32_t len, uint32_t off, const uint8_t *glo,
+                              const uint8_t *ghi, uint32_t *buf) {
+    const uintptr_t b = (uintptr_t)base;
+    w.ga = (const uint8_t *)(b & ~(uintptr_t)3);
+    w.base_bit = (int32_t)(b & 3) * 8;
+    w.glo = glo; w.ghi = ghi; w.buf = buf;
+    w.rem = w.base_bit + (int32_t)(8 * len) - (int32_t)off;
+    const int32_t t0 = (w.rem - 64) >> 5;
+    w.cb = (t0 - 32) & ~63;
+    const int l = lane_id();
+    buf[l] = bw_gload(w, w.cb + l);
+    buf[64 + l] = bw_gload(w, w.cb + 64 + l);
     w.pend = bw_gload(w, w.cb - 64 + l);
-    w.has_pend = 1;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    w.acc = bw_window(w);
-    w.avail = 64 - (int32_t)off;
-    if (off != 0 && (w.acc >> w.avail) != 0) return LZFSE_MI_BAD_BIT_STREAM;
+    // the unused top `off` bits of the last byte must be zero (Error::BadBitStream)
+    if (off != 0 && (base[len - 1] >> (8 - off)) != 0) return LZFSE_MI_BAD_BIT_STREAM;
     return 0;
 }
 
-// flush (bit_reader.rs:39-51) + ring maintenance
-__device__ __forceinline__ void bw_flush(BitWindow &w) {
-    int32_t nbytes = (64 - w.avail) >> 3;
-    w.pos -= nbytes;
-    w.avail += nbytes * 8;
-    uint64_t a = (uint64_t)(uintptr_t)w.gbase + (uint64_t)(w.pos < 0 ? 0 : w.pos);
-    int64_t dw = (int64_t)(a >> 2);
-    if (dw < w.cb + 32) {
-        // cursor is in the lower quarter: drop the upper half, install the prefetched half
-        // [cb-64, cb) and start prefetching the one below it.
-        int l = lane_id();
-        w.ring[(w.cb - 64 + l) & 127] = w.pend;
+// consume `total` bits; keeps dwords [t, t + 2] of the next window inside the buffer
+__device__ __forceinline__ void bw_advance(BitWindow &w, uint32_t total) {
+    w.rem -= (int32_t)total;
+    const int32_t t = (w.rem - 64) >> 5;
+    if (t - w.cb < 16) {
+        const int l = lane_id();
+        const uint32_t low = w.buf[l];
+        w.buf[64 + l] = low;
+        w.buf[l] = w.pend;
         w.cb -= 64;
         w.pend = bw_gload(w, w.cb - 64 + l);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    w.acc = bw_window(w);
 }
 
-// finalize (bit_reader.rs:64-71)
-__device__ __forceinline__ int bw_finalize(BitWindow &w) {
-    int32_t nbytes = (64 - w.avail) >> 3;
-    int64_t pos = w.pos - nbytes;
-    int32_t avail = w.avail + nbytes * 8;
-    return ((int64_t)avail + pos * 8 < 64) ? LZFSE_MI_PAYLOAD_UNDERFLOW : 0;
+// bit_reader.rs:64-71
+__device__ __forceinline__ int bw_finalize(const BitWindow &w) {
+    return (w.rem - w.base_bit < 64) ? LZFSE_MI_PAYLOAD_UNDERFLOW : 0;
 }
 
 constexpr int FSE_THREADS = 128;
@@ -379,25 +374,25 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
         uint32_t rec = 0;
         uint8_t *out = lit_out + d.lit_base;
         const uint32_t n_groups = e ? 0u : h.lit_num >> 2;
+        uint64_t win = bw_window(w);
         for (uint32_t g = 0; g < n_groups; g++) {
-            uint32_t ent = u_tab[state];
-            uint32_t k = ent & 0xFF;
-            uint32_t sym = (ent >> 8) & 0xFF;
-            int32_t delta = (int32_t)(int16_t)(ent >> 16);
+            const uint32_t ent = u_tab[state];
+            const uint32_t k = ent & 0xFF;
+            const uint32_t sym = (ent >> 8) & 0xFF;
+            const int32_t delta = (int32_t)(int16_t)(ent >> 16);
             uint32_t pre = k;
             pre += dpp_shr<1>(pre);
             pre += dpp_shr<2>(pre);  // inclusive prefix over lanes 0..3
-            uint32_t bits = (uint32_t)(w.acc >> ((w.avail - (int32_t)pre) & 63)) & mask32(k);
+            const uint32_t bits = (uint32_t)(win >> ((64 - pre) & 63)) & ((1u << k) - 1u);  // pre == 0 only with k == 0
             state = (uint32_t)((int32_t)bits + delta) & 1023u;
-            uint32_t total = read_lane(pre, 3);
-            uint32_t word = sym << (8 * (lane & 3));
+            uint32_t word = sym << (8 * q4);
             word |= dpp_shr<1>(word);
             word |= dpp_shr<2>(word);  // lane 3 holds the four symbols
+            bw_advance(w, read_lane(pre, 3));
+            win = bw_window(w);
             word = read_lane(word, 3);
             if (lane == (int)(g & 63)) rec = word;
             if ((g & 63) == 63) ((uint32_t *)out)[(g & ~63u) + lane] = rec;
-            w.avail -= (int32_t)total;
-            bw_flush(w);
         }
         if (n_groups & 63) {
             if (lane < (int)(n_groups & 63)) ((uint32_t *)out)[(n_groups & ~63u) + lane] = rec;
@@ -416,39 +411,40 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
         const uint32_t smask = li == 2 ? 255u : 63u;
         uint2 rec = make_uint2(0, 0);
         LmdRec *out = lmd_out + d.lmd_base;
-        uint32_t sum_l = 0, sum_m = 0, prev_d = 0;
+        uint32_t acc_sum = 0;   // lane 0: sum of L, lane 1: sum of M
+        uint32_t prev_d = 0;    // lane 2
         const uint32_t n = e ? 0u : h.lmd_num;
+        uint64_t win = bw_window(w);
         for (uint32_t i = 0; i < n; i++) {
-            uint2 ent = v_tab[tbase + state];
-            uint32_t k = ent.x & 0xFF, vb = (ent.x >> 8) & 0xFF;
-            int32_t delta = (int32_t)(int16_t)(ent.x >> 16);
-            uint32_t nb = k + vb;
-            uint32_t pre = nb;
+            const uint2 ent = v_tab[tbase + state];
+            const uint32_t k = ent.x & 0xFF, vb = (ent.x >> 8) & 0xFF;
+            const int32_t delta = (int32_t)(int16_t)(ent.x >> 16);
+            uint32_t pre = k + vb;
             pre += dpp_shr<1>(pre);
             pre += dpp_shr<2>(pre);
-            uint64_t x = w.acc >> ((w.avail - (int32_t)pre) & 63);
-            uint32_t extra = (uint32_t)x & mask32(vb);
-            uint32_t sb = (uint32_t)(x >> vb) & mask32(k);
+            const uint64_t x = win >> ((64 - pre) & 63);  // pre == 0 only when k = vb = 0 below
+            const uint32_t extra = (uint32_t)x & ((1u << vb) - 1u);
+            const uint32_t sb = (uint32_t)(x >> vb) & ((1u << k) - 1u);
             state = (uint32_t)((int32_t)sb + delta) & smask;
-            uint32_t val = ent.y + extra;
-            uint32_t total = read_lane(pre, 2);
-            uint32_t l = read_lane(val, 0), m = read_lane(val, 1), dd = read_lane(val, 2);
-            if (dd != 0) prev_d = dd;  // lmd_type.rs:153-160
-            sum_l += l;
-            sum_m += m;
-            if (sum_l > LITERALS_PER_BLOCK && !e) e = LZFSE_MI_FSE_BAD_LMD_PAYLOAD;  // fse_core.rs:119-128
-            if (lane == (int)(i & 63)) rec = make_uint2(l | (m << 16), prev_d);
+            const uint32_t val = ent.y + extra;
+            bw_advance(w, read_lane(pre, 2));
+            win = bw_window(w);
+            acc_sum += val;
+            if (val != 0) prev_d = val;                               // lane 2: lmd_type.rs:153-160
+            const uint32_t lm = dpp_shr<2>(val) | (dpp_shr<1>(val) << 16);  // lane 2: l | m << 16
+            const uint32_t r0 = read_lane(lm, 2), r1 = read_lane(prev_d, 2);
+            if (lane == (int)(i & 63)) rec = make_uint2(r0, r1);
             if ((i & 63) == 63) out[(i & ~63u) + lane] = rec;
-            w.avail -= (int32_t)total;
-            bw_flush(w);
         }
         if (n & 63) {
             if (lane < (int)(n & 63)) out[(n & ~63u) + lane] = rec;
         }
         if (!e) e = bw_finalize(w);
+        const uint32_t sum_l = read_lane(acc_sum, 0), sum_m = read_lane(acc_sum, 1);
         uint32_t s0 = read_lane(state, 0) | read_lane(state, 1) | read_lane(state, 2);
-        if (!e && !(sum_l <= h.lit_num && sum_l + sum_m == h.n_raw && s0 == 0))
-            e = LZFSE_MI_FSE_BAD_LMD_PAYLOAD;  // fse_core.rs:132-140
+        // fse_core.rs:119-140: the running literal_index > 40 000 test is monotone, so it is applied to the sum
+        if (!e && !(sum_l <= h.lit_num && sum_l <= LITERALS_PER_BLOCK && sum_l + sum_m == h.n_raw && s0 == 0))
+            e = LZFSE_MI_FSE_BAD_LMD_PAYLOAD;
         if (lane == 0) { sh_status[0] = e; sh_sums[0] = sum_l; sh_sums[1] = sum_m; }
     }
     __syncthreads();
