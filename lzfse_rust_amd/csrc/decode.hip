@@ -553,7 +553,7 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
     __shared__ uint32_t s_lm[NT];    // l | m << 16
     __shared__ uint32_t s_d[NT];
     __shared__ uint32_t s_lit[NT];   // literal offset inside the block's literal buffer
-    __shared__ uint32_t s_dep[NT];   // ordered list of LMD slots whose match reads the tile
+    __shared__ uint16_t s_org[TILE];  // per-byte origin inside the tile (pointer jumping)
     __shared__ uint32_t s_long[2 * NT];
     __shared__ uint32_t s_scan[2 * NW + 2];
     __shared__ uint32_t s_cnt[4];
@@ -673,7 +673,6 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
             uint32_t nl = (lit_long ? 1u : 0u) + (far_long ? 1u : 0u);
             uint32_t ex_dep, ex_long, tot_dep, tot_long;
             block_excl_scan2<NT>(dep ? 1u : 0u, nl, ex_dep, ex_long, tot_dep, tot_long, s_scan);
-            s_dep[tid] = dep ? 1u : 0u;
             if (lit_long) s_long[ex_long++] = tid * 2;
             if (far_long) s_long[ex_long] = tid * 2 + 1;
             __syncthreads();
@@ -695,74 +694,58 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
             }
             const uint64_t td = __builtin_amdgcn_s_memtime();
             // ---- matches that read the tile (lz/object.rs:27-74 semantics: out[p + k] = out[p + k - d],
-            //      overlap allowed): rounds. A match is ready when no unwritten match lies in its
-            //      source range; ready short matches are copied by their lane, ready long ones by a wave.
-            uint32_t sl_a = 0, sl_b = 0;
+            //      overlap allowed): byte-level pointer jumping inside LDS. Every byte of the tile gets an
+            //      origin (itself when it is already final); origin <- origin[origin] until all origins are
+            //      final bytes, then one gather. Chains of any length collapse in O(log) rounds.
             const uint32_t mo = ex_s + l;                              // tile offset of the match
             const int64_t so = (int64_t)mo - (int64_t)dd;              // tile offset of its source (may be < 0)
-            if (dep) {
-                // slots covering the in-tile part of the source [max(so, 0), so + min(m, d))
-                const uint32_t x0 = so > 0 ? (uint32_t)so : 0u;
-                const uint32_t x1 = (uint32_t)(so + (int64_t)(m < dd ? m : dd)) - 1;  // last source byte (>= 0, < mo)
-                uint32_t lo = 0, hi = tid;  // largest slot t <= tid with s_off[t] <= x
-                while (lo < hi) { uint32_t mid = (lo + hi + 1) >> 1; if (s_off[mid] <= x0) lo = mid; else hi = mid - 1; }
-                sl_a = lo;
-                lo = sl_a; hi = tid;
-                while (lo < hi) { uint32_t mid = (lo + hi + 1) >> 1; if (s_off[mid] <= x1) lo = mid; else hi = mid - 1; }
-                sl_b = lo;
-                if (sl_b == (uint32_t)tid) sl_b = tid ? tid - 1 : 0;      // own slot: only its literals can be read
-            }
-            bool pending = dep;
-            for (;;) {
-                __syncthreads();  // flags and tile bytes of the previous round (or phase) are visible
+            if (tot_dep) {
+                for (uint32_t b = tid; b < tile_len; b += NT) s_org[b] = (uint16_t)b;
                 if (tid == 0) s_cnt[3] = 0;
-                bool ready = false;
-                if (pending) {
-                    ready = true;
-                    for (uint32_t q = sl_a; q <= sl_b; q++) if (q != (uint32_t)tid && s_dep[q]) { ready = false; break; }
-                }
                 __syncthreads();
-                const bool rs = ready && m <= SHORT_COPY;
-                if (rs) {
-                    if (dd >= m && so >= 0) {
-                        // non-overlapping, in the tile: loads first, then stores
-                        uint8_t buf[SHORT_COPY];
-#pragma unroll
-                        for (uint32_t k = 0; k < SHORT_COPY; k++) if (k < m) buf[k] = t[so + k];
-#pragma unroll
-                        for (uint32_t k = 0; k < SHORT_COPY; k++) if (k < m) t[mo + k] = buf[k];
-                    } else {
+                if (dep) {
+                    if (m <= SHORT_COPY) {
                         for (uint32_t k = 0; k < m; k++) {
-                            int64_t sp = so + k;
-                            t[mo + k] = sp >= 0 ? t[sp] : dst[(int64_t)tile_base + sp];
+                            const int64_t sp = so + k;
+                            if (sp >= 0) s_org[mo + k] = (uint16_t)sp;
+                            else t[mo + k] = dst[(int64_t)tile_base + sp];   // finished output of earlier tiles
                         }
+                    } else {
+                        s_long[atomicAdd(&s_cnt[3], 1u)] = tid;
                     }
-                } else if (ready) {
-                    s_long[atomicAdd(&s_cnt[3], 1u)] = tid;
                 }
                 __syncthreads();
                 const uint32_t nq = s_cnt[3];
                 for (uint32_t q = wave; q < nq; q += NW) {
                     const uint32_t slot = s_long[q];
                     const uint32_t lm = s_lm[slot], ddq = s_d[slot];
-                    const uint32_t ll = lm & 0xFFFF, mm = lm >> 16;
-                    const uint32_t mq = s_off[slot] + ll;
+                    const uint32_t mq = s_off[slot] + (lm & 0xFFFF), mm = lm >> 16;
                     const int64_t sq = (int64_t)mq - (int64_t)ddq;
-                    for (uint32_t c = 0; c < mm; c += 64) {
-                        uint32_t k = c + lane;
-                        if (k < mm) {
-                            uint32_t kk = ddq < 64 ? k % ddq : k;
-                            int64_t sp = sq + kk;
-                            uint8_t v = sp >= 0 ? t[sp] : dst[(int64_t)tile_base + sp];
-                            t[mq + k] = v;
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
+                    for (uint32_t k = lane; k < mm; k += 64) {
+                        const int64_t sp = sq + k;
+                        if (sp >= 0) s_org[mq + k] = (uint16_t)sp;
+                        else t[mq + k] = dst[(int64_t)tile_base + sp];
                     }
                 }
-                if (ready) { pending = false; s_dep[tid] = 0; }
-                if (!__syncthreads_or(pending)) break;
+                for (;;) {
+                    __syncthreads();
+                    bool changed = false;
+                    for (uint32_t b = tid; b < tile_len; b += NT) {
+                        const uint32_t o = s_org[b];
+                        if (o == b) continue;
+                        const uint32_t o1 = s_org[o];
+                        if (o1 == o) continue;
+                        s_org[b] = s_org[s_org[o1]];
+                        changed = true;
+                    }
+                    if (!__syncthreads_or(changed)) break;
+                }
+                for (uint32_t b = tid; b < tile_len; b += NT) {
+                    const uint32_t o = s_org[b];
+                    if (o != b) t[b] = t[o];
+                }
             }
+            __syncthreads();
             const uint64_t te = __builtin_amdgcn_s_memtime();
             // ---- write the tile back: head bytes, 16-byte body, tail bytes ----
             {
@@ -956,10 +939,10 @@ void launch_dec_lz(int variant, const uint8_t *src, const StreamIn *streams, con
                    const uint8_t *lits, uint8_t *dst, StreamResult *sres, hipStream_t st) {
     if (!n_streams) return;
     if (variant == 0)
-        hipLaunchKernelGGL((dec_lz_kernel<256, 16384>), dim3(n_streams), dim3(256), 0, st, src, streams, plan,
+        hipLaunchKernelGGL((dec_lz_kernel<256, 8192>), dim3(n_streams), dim3(256), 0, st, src, streams, plan,
                            blocks, bres, lmds, lits, dst, sres);
     else
-        hipLaunchKernelGGL((dec_lz_kernel<1024, 49152>), dim3(n_streams), dim3(1024), 0, st, src, streams, plan,
+        hipLaunchKernelGGL((dec_lz_kernel<1024, 32768>), dim3(n_streams), dim3(1024), 0, st, src, streams, plan,
                            blocks, bres, lmds, lits, dst, sres);
 }
 
