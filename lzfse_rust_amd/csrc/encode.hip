@@ -689,13 +689,35 @@ __global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *_
                 tl += a; ts += b2;
             }
             uint32_t ex_l = ol + il - l, ex_s = os + is - (l + m);
+            const uint8_t *ls = s + run_src + ex_s;
+            uint8_t *ld = lit + run_lit + ex_l;
+            const bool l_long = valid && l > 24;
             if (valid) {
-                const uint8_t *ls = s + run_src + ex_s;
-                uint8_t *ld = lit + run_lit + ex_l;
-                for (uint32_t k = 0; k < l; k++) ld[k] = ls[k];
+                if (!l_long && l) {
+                    // three 8-byte loads in flight, then byte stores (the run is followed by >= 4 match or
+                    // literal bytes of the same stream, except at its very end)
+                    const bool wide = run_src + ex_s + 24 <= st.n;
+                    if (wide) {
+                        uint64_t w0 = ld_u64(ls), w1 = l > 8 ? ld_u64(ls + 8) : 0, w2 = l > 16 ? ld_u64(ls + 16) : 0;
+                        for (uint32_t k = 0; k < l; k++) {
+                            uint64_t w = k < 8 ? w0 : (k < 16 ? w1 : w2);
+                            ld[k] = (uint8_t)(w >> (8 * (k & 7)));
+                        }
+                    } else {
+                        for (uint32_t k = 0; k < l; k++) ld[k] = ls[k];
+                    }
+                }
                 atomicAdd(&hist[l_sym_of(l)], 1u);
                 atomicAdd(&hist[20 + m_sym_of(m)], 1u);
                 atomicAdd(&hist[40 + d_sym_of(d)], 1u);
+            }
+            // long runs: the whole wave copies one lane's run at a time
+            uint64_t ql = __ballot(l_long);
+            while (ql) {
+                const int L = __builtin_ctzll(ql);
+                ql &= ql - 1;
+                const uint32_t q_src = e_readlane(run_src + ex_s, L), q_dst = e_readlane(run_lit + ex_l, L), q_n = e_readlane(l, L);
+                for (uint32_t k = lane; k < q_n; k += 64) lit[q_dst + k] = s[q_src + k];
             }
             run_lit += tl; run_src += ts;
             __syncthreads();
@@ -836,9 +858,24 @@ __global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *_
                 }
             }
             __syncthreads();
-            // ---- A: serial state chains ----
+            // ---- A: serial state chains (entries are fetched 8 steps ahead of the recurrence) ----
             if (wave == 0 && lane < 4) {
-                for (uint32_t k = lane; k < lcnt; k += 4) {
+                uint32_t k = lane;
+                for (; k + 28 < lcnt; k += 32) {
+                    uint32_t e[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) e[u] = cl[k + 4 * u];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        int32_t tk = (int32_t)(int16_t)(e[u] & 0xFFFF), tw = (int32_t)(int16_t)(e[u] >> 16);
+                        uint32_t nb = (uint32_t)(tk + (int32_t)cstate) >> 10;
+                        e[u] = (cstate & ((1u << nb) - 1u)) | (nb << 16);
+                        cstate = (uint32_t)(tw + (int32_t)(cstate >> nb));
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) cl[k + 4 * u] = e[u];
+                }
+                for (; k < lcnt; k += 4) {
                     uint32_t e = cl[k];
                     int32_t tk = (int32_t)(int16_t)(e & 0xFFFF), tw = (int32_t)(int16_t)(e >> 16);
                     uint32_t nb = (uint32_t)(tk + (int32_t)cstate) >> 10;
@@ -846,7 +883,23 @@ __global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *_
                     cstate = (uint32_t)(tw + (int32_t)(cstate >> nb));
                 }
             } else if (wave == 1 && lane < 3) {
-                for (uint32_t k = lane; k < 3 * mcnt; k += 3) {
+                uint32_t k = lane;
+                const uint32_t n3 = 3 * mcnt;
+                for (; k + 21 < n3; k += 24) {
+                    uint32_t e[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) e[u] = ce[k + 3 * u];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        int32_t tk = (int32_t)(int16_t)(e[u] & 0xFFFF), tw = (int32_t)(int16_t)(e[u] >> 16);
+                        uint32_t nb = (uint32_t)(tk + (int32_t)cstate) >> 10;
+                        e[u] = (cstate & ((1u << nb) - 1u)) | (nb << 16);
+                        cstate = (uint32_t)(tw + (int32_t)(cstate >> nb));
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) ce[k + 3 * u] = e[u];
+                }
+                for (; k < n3; k += 3) {
                     uint32_t e = ce[k];
                     int32_t tk = (int32_t)(int16_t)(e & 0xFFFF), tw = (int32_t)(int16_t)(e >> 16);
                     uint32_t nb = (uint32_t)(tk + (int32_t)cstate) >> 10;
