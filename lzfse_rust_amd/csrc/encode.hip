@@ -169,7 +169,7 @@ constexpr uint32_t CAND_C1 = 64;
 
 __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
                                                        const EncTile *__restrict__ tiles, const uint2 *__restrict__ prev,
-                                                       uint2 *__restrict__ rec, uint64_t *__restrict__ bitmap) {
+                                                       uint2 *__restrict__ rec, uint64_t *__restrict__ bitmap, int dbg) {
     const uint32_t t = blockIdx.y;
     const EncTile tl = tiles[t];
     const EncStream st = streams[tl.stream];
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
     bool alive = valid;
     uint32_t c = self.x;
 #pragma unroll 1
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < ((dbg & 4) ? 1 : 4); q++) {
         if (!__any(alive)) break;
         uint32_t dist = 0, len = 0;
         bool eq = false;
@@ -203,9 +203,9 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
                 else { rc = pv[c]; eq = rc.y == v; }    // one 8-byte gather per hop: next link + value
             }
         }
-        if (alive && eq) len = lcp_fwd(s, i, c, 4, c1);
+        if (alive && eq) len = (dbg & 1) ? 4 : lcp_fwd(s, i, c, 4, (dbg & 16) ? (c1 < 12 ? c1 : 12) : c1);
         // ---- runs of lanes still equal after CAND_C1 bytes ----
-        const bool more = alive && eq && len == CAND_C1 && CAND_C1 < cap_total;
+        const bool more = !(dbg & 8) && alive && eq && len == CAND_C1 && CAND_C1 < cap_total;
         const uint64_t mm = __ballot(more);
         if (mm) {
             const uint32_t dist_lo = __shfl_up(dist, 1);
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
     if (valid) {
         if (best_len) {
             uint32_t bmax = best_idx < BCAP ? best_idx : BCAP;
-            uint32_t bw = lcs_bwd(s, i, best_idx, bmax);
+            uint32_t bw = (dbg & 2) ? 0 : lcs_bwd(s, i, best_idx, bmax);
             r.x = (i - best_idx) | (bw << 18) | (capped ? REC_CAPPED : 0u);
             r.y = best_len;
         }
@@ -1210,7 +1210,8 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     }
     {
         StageTimer t(c, "enc_cand");
-        hipLaunchKernelGGL(enc_cand_kernel, dim3((TILE_POS + 255) / 256, nt), dim3(256), 0, stq, d_src, d_streams, d_tiles, d_prev, d_rec, d_bitmap);
+        hipLaunchKernelGGL(enc_cand_kernel, dim3((TILE_POS + 255) / 256, nt), dim3(256), 0, stq, d_src, d_streams, d_tiles, d_prev, d_rec, d_bitmap,
+                           getenv("LZFSE_MI_CAND_DEBUG") ? atoi(getenv("LZFSE_MI_CAND_DEBUG")) : 0);
     }
     if (serial_walk) {
         StageTimer t(c, "enc_walk");
@@ -1299,7 +1300,7 @@ extern "C" int lzfse_mi_debug_candidates(lzfse_mi_ctx *c, const uint8_t *h_src, 
     hipLaunchKernelGGL(enc_link_kernel, dim3((TILE_POS + 255) / 256, nt), dim3(256), 0, stq, d_src, (EncStream *)S.bufs[EB_STREAMS],
                        (EncTile *)S.bufs[EB_TILES], nt, (uint2 *)S.bufs[EB_PREV], (uint32_t *)S.bufs[EB_SUMMARY]);
     hipLaunchKernelGGL(enc_cand_kernel, dim3((TILE_POS + 255) / 256, nt), dim3(256), 0, stq, d_src, (EncStream *)S.bufs[EB_STREAMS],
-                       (EncTile *)S.bufs[EB_TILES], (uint2 *)S.bufs[EB_PREV], (uint2 *)S.bufs[EB_REC], (uint64_t *)S.bufs[EB_BITMAP]);
+                       (EncTile *)S.bufs[EB_TILES], (uint2 *)S.bufs[EB_PREV], (uint2 *)S.bufs[EB_REC], (uint64_t *)S.bufs[EB_BITMAP], 0);
     E_TRY(hipMemcpyAsync(h_prev, S.bufs[EB_PREV], (n - 3) * 8, hipMemcpyDeviceToHost, stq));  // {prev, value} pairs
     E_TRY(hipMemcpyAsync(h_rec_xy, S.bufs[EB_REC], (n - 3) * 8, hipMemcpyDeviceToHost, stq));
     E_TRY(hipStreamSynchronize(stq));
