@@ -207,6 +207,17 @@ def main():
         dom = max(kern_ms, key=kern_ms.get)
         dom_avg_ms = kern_ms[dom] / max(kern_n[dom], 1)
         is_dec = dom.startswith("dec")
+        # HBM traffic of that kernel per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE runs of this same default workload, profiles/r01_pmc_traffic.json; KiB -> bytes, raw figures)
+        traffic = None
+        try:
+            if args.workload == "snappy" and args.replicas == 64:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                key = [k for k in pm if k.startswith(dom + "_kernel")]
+                if key:
+                    traffic = int(sum(pm[k]["hbm_bytes_raw"] * pm[k]["launches"] for k in key) / sum(pm[k]["launches"] for k in key))
+        except Exception:
+            traffic = None
         alg_bytes = comp_total + raw_total  # B_dec = compressed_in + raw_out ; B_enc = raw_in + compressed_out
         achieved = alg_bytes / (dom_avg_ms * 1e-3) / 1e9
         out = {
@@ -228,7 +239,7 @@ def main():
             "decode_MBps": round(raw_total * world * args.steps / td / 1e6, 2),
             "kernel_ms_per_step": {k: round(v / args.steps, 4) for k, v in sorted(kern_ms.items())},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_avg_ms, 4),
                          "direction": "decode" if is_dec else "encode"},
         }

@@ -1,0 +1,28 @@
+"""Aggregates rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE csv output into per-kernel HBM bytes per launch.
+FETCH_SIZE / WRITE_SIZE are in KiB (MI355X_MICROARCH.md, HBM section); on gfx950 FETCH_SIZE reads one half
+of the bytes of wide (16 B/lane) coalesced streaming reads - both the raw and the x2-corrected read
+figure are kept, the corrected one only applies to streaming kernels."""
+import csv, glob, json, sys, collections
+
+def collect(d, counter):
+    out = collections.defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row.get('Counter_Name') != counter:
+                continue
+            name = row['Kernel_Name'].split('(')[0].replace('void ', '').replace('lzmi::', '')
+            v = out[name]
+            v[0] += float(row['Counter_Value']); v[1] += 1
+    return {k: (v[0] / v[1], v[1]) for k, v in out.items()}
+
+fetch = collect(sys.argv[1], 'FETCH_SIZE')
+write = collect(sys.argv[2], 'WRITE_SIZE')
+res = {}
+for k in sorted(set(fetch) | set(write)):
+    f = fetch.get(k, (0, 0)); w = write.get(k, (0, 0))
+    res[k] = {"launches": max(f[1], w[1]), "fetch_bytes_raw": f[0] * 1024, "fetch_bytes_x2": f[0] * 2048,
+              "write_bytes": w[0] * 1024, "hbm_bytes_raw": (f[0] + w[0]) * 1024}
+json.dump(res, open(sys.argv[3], 'w'), indent=1)
+for k, v in res.items():
+    if k.startswith(('enc_', 'dec_')):
+        print(f"{k:28s} launches {v['launches']:4d} fetch {v['fetch_bytes_raw']/1e6:9.1f} MB write {v['write_bytes']/1e6:9.1f} MB")
