@@ -90,6 +90,12 @@ int lzfse_mi_encode(lzfse_mi_ctx *ctx, const uint8_t *src, size_t n, uint8_t *ds
 int lzfse_mi_decode(lzfse_mi_ctx *ctx, const uint8_t *src, size_t n, uint8_t *dst, size_t cap,
                     size_t *out_len);
 
+/* The size classes the reference keeps on the host CPU (encode/frontend_bytes.rs:63-111): n <= 20 -> one bvx-
+ * block, 21..=4096 -> one bvxn block (or bvx- when not smaller), then bvx$. Pure host code, no context needed;
+ * lzfse_mi_encode / _batch / _batch_device route inputs of this size class here themselves. n > 4096 is
+ * LZFSE_MI_BAD_ARGUMENT (those inputs are bvx2 and belong to the device path). */
+int lzfse_mi_encode_small(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *out_len);
+
 /* Header walk on the host: sum of n_raw_bytes of all blocks. */
 int lzfse_mi_decode_size(const uint8_t *src, size_t n, uint64_t *raw_len);
 

@@ -18,7 +18,7 @@ _SYMBOLS = [
     "lzfse_mi_create", "lzfse_mi_destroy", "lzfse_mi_status_string", "lzfse_mi_version", "lzfse_mi_set_stream",
     "lzfse_mi_encode_bound", "lzfse_mi_encode", "lzfse_mi_decode", "lzfse_mi_decode_size",
     "lzfse_mi_encode_batch", "lzfse_mi_decode_batch", "lzfse_mi_decode_batch_device",
-    "lzfse_mi_encode_batch_device", "lzfse_mi_enable_timing", "lzfse_mi_get_timings",
+    "lzfse_mi_encode_batch_device", "lzfse_mi_enable_timing", "lzfse_mi_get_timings", "lzfse_mi_encode_small",
 ]
 
 
@@ -49,6 +49,8 @@ def lib():
         f = getattr(L, name)
         f.restype = C.c_int
         f.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
+    L.lzfse_mi_encode_small.restype = C.c_int
+    L.lzfse_mi_encode_small.argtypes = [vp, sz, vp, sz, C.POINTER(sz)]
     L.lzfse_mi_decode_size.restype = C.c_int
     L.lzfse_mi_decode_size.argtypes = [vp, sz, u64p]
     for name in ("lzfse_mi_encode_batch", "lzfse_mi_decode_batch"):

@@ -6,7 +6,7 @@ import subprocess
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, "csrc")
 LIB_PATH = os.path.join(_PKG, "liblzfse_mi.so")
-SOURCES = ["api.hip", "decode.hip", "encode.hip", "encode_parse.hip"]
+SOURCES = ["api.hip", "decode.hip", "encode.hip", "encode_parse.hip", "host_small.cpp"]
 HEADERS = ["common.h", "internal.h", "enc_common.h", os.path.join("..", "..", "include", "lzfse_mi.h")]
 
 

@@ -111,6 +111,15 @@ class Context:
                                   dst_cap)
 
 
+def encode_small(src):
+    """Host-side size classes (n <= 4096): raw / LZVN blocks, exactly as the reference's CPU path."""
+    a = np.frombuffer(bytes(src), dtype=np.uint8)
+    out = np.empty(a.size + 64, dtype=np.uint8)
+    n = C.c_size_t(0)
+    _check(_native.lib().lzfse_mi_encode_small(a.ctypes.data if a.size else None, a.size, out.ctypes.data, out.size, C.byref(n)))
+    return out[: n.value].tobytes()
+
+
 def encode_bound(n):
     return _native.lib().lzfse_mi_encode_bound(int(n))
 

@@ -383,7 +383,24 @@ int lzfse_mi_encode_batch_device(lzfse_mi_ctx *c, size_t count, const void *d_sr
     int r = enc_batch_device(c, (uint32_t)count, (const uint8_t *)d_src, src_off, src_len, (uint8_t *)d_dst,
                              dst_off, dst_cap, out_lens, statuses);
     timing_end(c);
-    return r;
+    if (r) return r;
+    // inputs <= 4096 bytes: the reference's host-side size classes (raw / LZVN), encoded on the host
+    uint8_t in[4096], out[4096 + 64];
+    for (size_t i = 0; i < count; i++) {
+        if (src_len[i] > VN_CUTOFF) continue;
+        if (src_len[i]) HIP_TRY(hipMemcpyAsync(in, (const uint8_t *)d_src + src_off[i], src_len[i], hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        size_t n = 0;
+        statuses[i] = lzfse_mi_encode_small(in, (size_t)src_len[i], out, sizeof out, &n);
+        if (statuses[i] == 0 && n > dst_cap[i]) statuses[i] = LZFSE_MI_BUFFER_OVERFLOW;
+        out_lens[i] = 0;
+        if (statuses[i] == 0) {
+            HIP_TRY(hipMemcpyAsync((uint8_t *)d_dst + dst_off[i], out, n, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            out_lens[i] = n;
+        }
+    }
+    return LZFSE_MI_OK;
 }
 
 // ---------------------------------------------------------------------------- host-pointer API

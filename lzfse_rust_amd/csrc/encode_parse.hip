@@ -319,7 +319,6 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
     while (!done && !x.status) {
         if (!walking) {
             const SpecHeader hk = H0[k];
-            const SpecEvent *Lk = L0 + (uint64_t)k * SEG_EV_CAP;
             bool found = false;
             if (k + 1 < K) {
                 const uint4 sy = sync[es.seg_base + k];  // enc_sync_kernel: (found, i, j)

@@ -79,3 +79,24 @@ def test_product_never_touches_oracle():
 def test_status_strings(lib):
     assert lib.lzfse_mi_status_string(0) == b"ok"
     assert b"LMD payload" in lib.lzfse_mi_status_string(22)
+
+
+def test_small_size_classes_match_oracle(lib, oracle):
+    """n <= 4096: raw / LZVN host path (frontend_bytes.rs:63-111) is bit-exact vs the oracle for every size
+    on several byte distributions, and carries the reference's KATs (frontend_bytes.rs:455-510)."""
+    import lzfse_rust_amd as m
+    from oracle_py import rng_gen_vec, seq_masked
+    rng = np.random.default_rng(2)
+    words = [bytes(rng.integers(97, 123, size=int(rng.integers(2, 9)), dtype=np.uint8)) for _ in range(200)]
+    text = b" ".join(words[int(i)] for i in rng.integers(0, 200, size=2000))
+    sources = [bytes(4096), text, seq_masked(7, 0x03030303, 4096), rng_gen_vec(1, 4096), b"ab" * 2048,
+               bytes(range(256)) * 16, rng.integers(0, 3, size=4096, dtype=np.uint8).tobytes()]
+    sizes = list(range(0, 80)) + list(range(250, 300)) + [511, 512, 1023, 1024, 2047, 2048, 4000, 4094, 4095, 4096]
+    for s in sources:
+        for n in sizes:
+            got = m.encode_small(s[:n])
+            assert got == oracle.encode(s[:n]), n
+            assert oracle.decode(got) == s[:n]
+    assert m.encode_small(b"test") == bytes([0x62, 0x76, 0x78, 0x2d, 4, 0, 0, 0, 0x74, 0x65, 0x73, 0x74, 0x62, 0x76, 0x78, 0x24])
+    with pytest.raises(m.LzfseError):
+        m.encode_small(bytes(4097))

@@ -123,3 +123,19 @@ def test_encode_api_appends(ctx, oracle, snappy_raw):
     dst = bytearray(b"xy")
     n = enc.encode_bytes(snappy_raw["html"], dst)
     assert bytes(dst[2:]) == oracle.encode(snappy_raw["html"]) and n == len(dst) - 2
+
+
+def test_encode_all_size_classes_through_api(ctx, oracle):
+    """raw / LZVN / bvx2 size classes in one batch (frontend_bytes.rs:63-77), KATs of :455-531 included."""
+    from test_oracle import ZERO_4097
+    base = synth_cases()["text"]
+    raws = [bytes(n) for n in (0, 1, 20, 21, 4096, 4097)] + [base[:n] for n in (5, 100, 3000, 4096, 4097, 9000)]
+    outs, st = ctx.encode_batch(raws)
+    for r, o, e in zip(raws, outs, st):
+        assert e == 0
+        assert o.tobytes() == oracle.encode(r), len(r)
+    assert outs[5].tobytes() == ZERO_4097
+    dec, st2 = ctx.decode_batch([o.tobytes() for o in outs])
+    assert all(e == 0 for e in st2)
+    for r, o in zip(raws, dec):
+        assert o.tobytes() == r
