@@ -53,31 +53,49 @@ __global__ __launch_bounds__(64) void enc_chain_kernel(const uint8_t *__restrict
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    uint32_t p0 = tl.start;
-    uint32_t v_next = (p0 + lane < t_end) ? ld_u32(s + p0 + lane) : 0u;
-    for (; p0 < t_end; p0 += 64) {
-        const uint32_t p = p0 + lane;
-        const bool valid = p < t_end;
-        const uint32_t v = v_next;
-        if (p0 + 64 < t_end) v_next = (p + 64 < t_end) ? ld_u32(s + p + 64) : 0u;
-        const uint32_t key = bucket_of(v);
-        const uint32_t old = last[key];
-        uint64_t same = __ballot(valid);
+    // 16 steps (1024 positions) per batch: the source values of a batch are loaded together, so the wave
+    // waits for memory once per batch instead of once per step (a wait also drains the link stores)
+    constexpr int CH_STEPS = 16;
+    for (uint32_t pb = tl.start; pb < t_end; pb += 64 * CH_STEPS) {
+        uint32_t vv[CH_STEPS];
 #pragma unroll
-        for (int b = 0; b < (int)HASH_BITS; b++) {
-            uint64_t bb = __ballot((key >> b) & 1);
-            same &= ((key >> b) & 1) ? bb : ~bb;
+        for (int j = 0; j < CH_STEPS; j++) {
+            const uint32_t q = pb + 64 * j + lane;
+            vv[j] = q < t_end ? ld_u32(s + q) : 0u;
         }
-        const uint64_t lower = same & lt_mask;
-        uint32_t pr;
-        if (lower) pr = p0 + (63 - __builtin_clzll(lower));
-        else pr = old ? (tl.start + old - 1) : NONE_TILE;
-        if (valid) {
-            pv[p] = make_uint2(pr, v);
-            if ((same >> lane) >> 1 == 0) last[key] = (uint16_t)(p - tl.start + 1);  // newest of its bucket
+#pragma unroll
+        for (int j = 0; j < CH_STEPS; j++) {
+            const uint32_t p0 = pb + 64 * j;
+            if (p0 >= t_end) break;
+            const uint32_t p = p0 + lane;
+            const bool valid = p < t_end;
+            const uint32_t v = vv[j];
+            const uint32_t key = bucket_of(v);
+            const uint32_t old = last[key];
+            const uint32_t mine = p - tl.start + 1;
+            // fast path: every lane writes its own entry and reads it back; if all read their own value no
+            // two lanes of this step share a bucket and the entry read before the write is the link
+            if (valid) last[key] = (uint16_t)mine;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t chk = last[key];
+            uint32_t pr = old ? (tl.start + old - 1) : NONE_TILE;
+            if (__ballot(valid && chk != mine)) {
+                // some lanes collide: find the nearest lower lane with the same bucket by 14 ballots
+                uint64_t same = __ballot(valid);
+#pragma unroll
+                for (int b = 0; b < (int)HASH_BITS; b++) {
+                    uint64_t bb = __ballot((key >> b) & 1);
+                    same &= ((key >> b) & 1) ? bb : ~bb;
+                }
+                const uint64_t lower = same & lt_mask;
+                if (lower) pr = p0 + (63 - __builtin_clzll(lower));
+                if (valid && (same >> lane) >> 1 == 0) last[key] = (uint16_t)mine;  // newest of its bucket wins
+            }
+            if (valid) pv[p] = make_uint2(pr, v);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     }
     uint32_t *sm = summary + (uint64_t)t * (1u << HASH_BITS);
     for (uint32_t k = lane; k < (1u << HASH_BITS); k += 64) {
