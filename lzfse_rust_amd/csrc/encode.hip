@@ -184,16 +184,22 @@ __device__ uint32_t cand_wave_lcp(const uint8_t *s, uint32_t a, uint32_t b, uint
 // (the inside of one long match): only the head of a run is extended, by the whole wave, and the
 // followers derive LCP(i + t, c + t) = LCP(i, c) - t. Repetitive data costs O(1) per position.
 constexpr uint32_t CAND_C1 = 64;
+constexpr uint32_t CAND_BPT = (TILE_POS + 255) / 256;  // workgroups per tile
 
 __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
-                                                       const EncTile *__restrict__ tiles, const uint2 *__restrict__ prev,
+                                                       const EncTile *__restrict__ tiles, uint32_t n_tiles, const uint2 *__restrict__ prev,
                                                        uint2 *__restrict__ rec, uint64_t *__restrict__ bitmap, int dbg) {
-    const uint32_t t = blockIdx.y;
+    // Workgroups are handed to the 8 XCDs round-robin. All workgroups of one tile go to the same XCD, so the
+    // link records and source bytes a tile gathers from (its own 0.5 MB + the 2 MB window before it) stay in
+    // that XCD's 4 MB L2 instead of being spread over all eight.
+    const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const uint32_t t = (slot / CAND_BPT) * 8 + xcd, bx = slot % CAND_BPT;
+    if (t >= n_tiles) return;
     const EncTile tl = tiles[t];
     const EncStream st = streams[tl.stream];
-    const uint32_t i = tl.start + blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = tl.start + bx * blockDim.x + threadIdx.x;
     const uint32_t n = st.n, n_pos = n - 3;
-    if (tl.start + blockIdx.x * blockDim.x >= n_pos) return;  // block-uniform
+    if (tl.start + bx * blockDim.x >= n_pos) return;  // block-uniform
     const bool valid = i < n_pos && i < tl.start + TILE_POS;
     const uint8_t *s = src + st.src_off;
     const uint2 *pv = prev + st.pos_base;
@@ -1228,7 +1234,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     }
     {
         StageTimer t(c, "enc_cand");
-        hipLaunchKernelGGL(enc_cand_kernel, dim3((TILE_POS + 255) / 256, nt), dim3(256), 0, stq, d_src, d_streams, d_tiles, d_prev, d_rec, d_bitmap,
+        hipLaunchKernelGGL(enc_cand_kernel, dim3(((nt + 7) / 8) * 8 * CAND_BPT), dim3(256), 0, stq, d_src, d_streams, d_tiles, nt, d_prev, d_rec, d_bitmap,
                            getenv("LZFSE_MI_CAND_DEBUG") ? atoi(getenv("LZFSE_MI_CAND_DEBUG")) : 0);
     }
     if (serial_walk) {
@@ -1317,8 +1323,8 @@ extern "C" int lzfse_mi_debug_candidates(lzfse_mi_ctx *c, const uint8_t *h_src, 
                        (uint2 *)S.bufs[EB_PREV], (uint32_t *)S.bufs[EB_SUMMARY]);
     hipLaunchKernelGGL(enc_link_kernel, dim3((TILE_POS + 255) / 256, nt), dim3(256), 0, stq, d_src, (EncStream *)S.bufs[EB_STREAMS],
                        (EncTile *)S.bufs[EB_TILES], nt, (uint2 *)S.bufs[EB_PREV], (uint32_t *)S.bufs[EB_SUMMARY]);
-    hipLaunchKernelGGL(enc_cand_kernel, dim3((TILE_POS + 255) / 256, nt), dim3(256), 0, stq, d_src, (EncStream *)S.bufs[EB_STREAMS],
-                       (EncTile *)S.bufs[EB_TILES], (uint2 *)S.bufs[EB_PREV], (uint2 *)S.bufs[EB_REC], (uint64_t *)S.bufs[EB_BITMAP], 0);
+    hipLaunchKernelGGL(enc_cand_kernel, dim3(((nt + 7) / 8) * 8 * CAND_BPT), dim3(256), 0, stq, d_src, (EncStream *)S.bufs[EB_STREAMS],
+                       (EncTile *)S.bufs[EB_TILES], nt, (uint2 *)S.bufs[EB_PREV], (uint2 *)S.bufs[EB_REC], (uint64_t *)S.bufs[EB_BITMAP], 0);
     E_TRY(hipMemcpyAsync(h_prev, S.bufs[EB_PREV], (n - 3) * 8, hipMemcpyDeviceToHost, stq));  // {prev, value} pairs
     E_TRY(hipMemcpyAsync(h_rec_xy, S.bufs[EB_REC], (n - 3) * 8, hipMemcpyDeviceToHost, stq));
     E_TRY(hipStreamSynchronize(stq));
