@@ -131,6 +131,12 @@ __global__ void enc_link_kernel(const uint8_t *__restrict__ src, const EncStream
 
 // ------------------------------------------------------------------------------------ candidates
 
+__device__ __forceinline__ uint4 ld_u128(const uint8_t *p) {
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+
 // forward common length of src[a..] and src[b..] (b < a), starting at `len`, bounded by max
 __device__ __forceinline__ uint32_t lcp_fwd(const uint8_t *s, uint32_t a, uint32_t b, uint32_t len, uint32_t max) {
     while (len + 8 <= max) {
@@ -209,27 +215,66 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
     const uint32_t max_total = valid ? n - i : 0;
     const uint32_t cap_total = max_total < FCAP ? max_total : FCAP;
     const uint32_t c1 = cap_total < CAND_C1 ? cap_total : CAND_C1;
-    uint32_t best_len = 0, best_idx = 0;
-    bool capped = false;
-    bool alive = valid;
-    uint32_t c = self.x;
-#pragma unroll 1
-    for (int q = 0; q < ((dbg & 4) ? 1 : 4); q++) {
-        if (!__any(alive)) break;
-        uint32_t dist = 0, len = 0;
-        bool eq = false;
-        uint2 rc = make_uint2(NONE, 0);
-        if (alive) {
-            if (c == NONE) alive = false;
-            else {
-                dist = i - c;
-                if (dist > MAX_D_VALUE) alive = false;  // frontend_bytes.rs:222-224: stop, not skip
-                else { rc = pv[c]; eq = rc.y == v; }    // one 8-byte gather per hop: next link + value
+    // ---- phase 1: follow the chain (<= 4 dependent 8-byte gathers: next link + value) ----
+    uint32_t cc[4] = {NONE, NONE, NONE, NONE};
+    uint32_t ln[4] = {0, 0, 0, 0};
+    {
+        bool alive = valid;
+        uint32_t c = self.x;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (alive) {
+                if (c == NONE || i - c > MAX_D_VALUE) alive = false;  // frontend_bytes.rs:222-224: stop, not skip
+                else {
+                    const uint2 rc = pv[c];
+                    if (rc.y == v) { cc[q] = c; ln[q] = 4; }
+                    c = rc.x;
+                }
             }
         }
-        if (alive && eq) len = (dbg & 1) ? 4 : lcp_fwd(s, i, c, 4, (dbg & 16) ? (c1 < 12 ? c1 : 12) : c1);
-        // ---- runs of lanes still equal after CAND_C1 bytes ----
-        const bool more = !(dbg & 8) && alive && eq && len == CAND_C1 && CAND_C1 < cap_total;
+    }
+    // ---- phase 2: forward lengths of all equal candidates together, 16 bytes per candidate and step, so the
+    // loads of a step are in flight at the same time (the kernel is bound by dependent-load latency) ----
+    if (!(dbg & 1)) {
+        bool act[4], tail[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { act[k] = ln[k] != 0 && c1 > 4; tail[k] = false; }
+#pragma unroll 1
+        for (uint32_t off = 4; off < CAND_C1; off += 16) {
+            if (!__any(act[0] || act[1] || act[2] || act[3])) break;
+            const bool room = off + 16 <= max_total;
+            uint4 a = make_uint4(0, 0, 0, 0);
+            if ((act[0] || act[1] || act[2] || act[3]) && room) a = ld_u128(s + i + off);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (act[k]) {
+                    if (!room) { tail[k] = true; act[k] = false; }
+                    else {
+                        const uint4 bq = ld_u128(s + cc[k] + off);
+                        const uint64_t lo = ((uint64_t)(a.y ^ bq.y) << 32) | (a.x ^ bq.x);
+                        const uint64_t hi = ((uint64_t)(a.w ^ bq.w) << 32) | (a.z ^ bq.z);
+                        uint32_t m = 16;
+                        if (lo) m = (uint32_t)(__builtin_ctzll(lo) >> 3);
+                        else if (hi) m = 8 + (uint32_t)(__builtin_ctzll(hi) >> 3);
+                        ln[k] = off + m;
+                        if (m < 16) act[k] = false;
+                        if (ln[k] >= c1) { ln[k] = c1; act[k] = false; }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (tail[k]) ln[k] = lcp_fwd(s, i, cc[k], ln[k], c1);  // within 80 bytes of the stream's end
+    }
+    // ---- phase 3: runs of lanes still equal after CAND_C1 bytes ----
+    uint32_t best_len = 0, best_idx = 0;
+    bool capped = false;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t len = ln[k];
+        const uint32_t c = cc[k], dist = i - c;
+        const bool more = !(dbg & 8) && len == CAND_C1 && CAND_C1 < cap_total;
         const uint64_t mm = __ballot(more);
         if (mm) {
             const uint32_t dist_lo = __shfl_up(dist, 1);
@@ -250,11 +295,10 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
             }
             if (more && len > cap_total) len = cap_total;
         }
-        if (alive && eq) {
+        if (len) {
             if (len == cap_total && cap_total < max_total) capped = true;
             if (len > best_len) { best_len = len; best_idx = c; }  // ties keep the newest (:226)
         }
-        c = rc.x;
     }
     uint2 r = make_uint2(0, 0);
     if (valid) {
