@@ -223,6 +223,7 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
         uint32_t c = self.x;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
+            if ((dbg & 4) && q >= 1) alive = false;
             if (alive) {
                 if (c == NONE || i - c > MAX_D_VALUE) alive = false;  // frontend_bytes.rs:222-224: stop, not skip
                 else {
@@ -233,12 +234,24 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
             }
         }
     }
-    // ---- phase 2: forward lengths of all equal candidates together, 16 bytes per candidate and step, so the
-    // loads of a step are in flight at the same time (the kernel is bound by dependent-load latency) ----
-    if (!(dbg & 1)) {
+    // ---- runs: consecutive positions inside one match see the same distance in the same chain slot, and
+    // LCP(i + t, c + t) = LCP(i, c) - t. Only the first lane of such a run (its head) compares bytes; the
+    // followers derive their length from the head's. The kernel is bound by the number of cache lines its
+    // divergent loads touch, and on compressible data most equal candidates are followers. ----
+    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    bool fol[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t dk = ln[k] ? i - cc[k] : NONE;
+        const uint32_t dlo = __shfl_up(dk, 1);
+        fol[k] = ln[k] != 0 && lane > 0 && dlo == dk;
+    }
+    // ---- phase 2: forward lengths of all heads together, 16 bytes per candidate and step, so the loads of a
+    // step are in flight at the same time ----
+    {
         bool act[4], tail[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) { act[k] = ln[k] != 0 && c1 > 4; tail[k] = false; }
+        for (int k = 0; k < 4; k++) { act[k] = ln[k] != 0 && !fol[k] && c1 > 4 && !(dbg & 1); tail[k] = false; }
 #pragma unroll 1
         for (uint32_t off = 4; off < CAND_C1; off += 16) {
             if (!__any(act[0] || act[1] || act[2] || act[3])) break;
@@ -267,48 +280,61 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
         for (int k = 0; k < 4; k++)
             if (tail[k]) ln[k] = lcp_fwd(s, i, cc[k], ln[k], c1);  // within 80 bytes of the stream's end
     }
-    // ---- phase 3: runs of lanes still equal after CAND_C1 bytes ----
+    // ---- phase 3: heads still equal after CAND_C1 bytes are extended by the whole wave (up to FCAP + 64, so
+    // that 63 followers stay exact up to FCAP); then the followers take head - t ----
     uint32_t best_len = 0, best_idx = 0;
     bool capped = false;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         uint32_t len = ln[k];
-        const uint32_t c = cc[k], dist = i - c;
-        const bool more = !(dbg & 8) && len == CAND_C1 && CAND_C1 < cap_total;
-        const uint64_t mm = __ballot(more);
-        if (mm) {
-            const uint32_t dist_lo = __shfl_up(dist, 1);
-            const bool head = more && !(lane > 0 && ((mm >> (lane - 1)) & 1) && dist_lo == dist);
-            const uint64_t hm = __ballot(head);
-            uint64_t it = hm;
-            while (it) {
-                const int h = __builtin_ctzll(it);
-                it &= it - 1;
-                const uint32_t i_h = e_readlane(i, h), c_h = e_readlane(c, h);
-                const uint32_t maxh = n - i_h;
-                const uint32_t limh = maxh < FCAP + 64 ? maxh : FCAP + 64;
-                const uint32_t hl = cand_wave_lcp(s, i_h, c_h, CAND_C1, limh);
-                const uint64_t upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1);     // lanes 0 .. lane
-                const uint64_t above_h = (h == 63) ? 0ull : ~((2ull << h) - 1);        // lanes h+1 .. 63
-                const bool mine = more && lane >= h && (hm & above_h & upto) == 0;     // no other head in (h, lane]
-                if (mine) len = hl - (uint32_t)(lane - h);
-            }
-            if (more && len > cap_total) len = cap_total;
+        const uint32_t c = cc[k];
+        const bool head = len != 0 && !fol[k];
+        uint64_t it = __ballot(head && len == CAND_C1 && CAND_C1 < cap_total);
+        while (it) {
+            const int h = __builtin_ctzll(it);
+            it &= it - 1;
+            const uint32_t i_h = e_readlane(i, h), c_h = e_readlane(c, h);
+            const uint32_t maxh = n - i_h;
+            const uint32_t limh = maxh < FCAP + 64 ? maxh : FCAP + 64;
+            const uint32_t hl = cand_wave_lcp(s, i_h, c_h, CAND_C1, limh);
+            if (lane == h) len = hl;
+        }
+        const uint64_t hm = __ballot(head);
+        if (__any(fol[k])) {
+            const uint64_t below = hm & lt_mask;
+            const int h = below ? 63 - __builtin_clzll(below) : 0;
+            const uint32_t hl = __shfl(len, h);
+            if (fol[k]) len = hl - (uint32_t)(lane - h);
         }
         if (len) {
+            if (len > cap_total) len = cap_total;
             if (len == cap_total && cap_total < max_total) capped = true;
             if (len > best_len) { best_len = len; best_idx = c; }  // ties keep the newest (:226)
         }
     }
+    // backward extension: the same run structure, LCS(i + t, c + t) = LCS(i, c) + t (up to the cap)
     uint2 r = make_uint2(0, 0);
-    if (valid) {
-        if (best_len) {
-            uint32_t bmax = best_idx < BCAP ? best_idx : BCAP;
-            uint32_t bw = (dbg & 2) ? 0 : lcs_bwd(s, i, best_idx, bmax);
-            r.x = (i - best_idx) | (bw << 18) | (capped ? REC_CAPPED : 0u);
-            r.y = best_len;
+    {
+        const uint32_t bd = best_len ? i - best_idx : NONE;
+        const uint32_t bd_lo = __shfl_up(bd, 1);
+        const bool bfol = best_len != 0 && lane > 0 && bd_lo == bd;
+        const uint32_t bmax = best_idx < BCAP ? best_idx : BCAP;
+        uint32_t bw = 0;
+        if (best_len && !bfol && !(dbg & 2)) bw = lcs_bwd(s, i, best_idx, bmax);
+        const uint64_t hm = __ballot(best_len != 0 && !bfol);
+        if (__any(bfol)) {
+            const uint64_t below = hm & lt_mask;
+            const int h = below ? 63 - __builtin_clzll(below) : 0;
+            const uint32_t hb = __shfl(bw, h);
+            if (bfol) { bw = hb + (uint32_t)(lane - h); if (bw > bmax) bw = bmax; }
         }
-        rec[st.pos_base + i] = r;
+        if (valid) {
+            if (best_len) {
+                r.x = (i - best_idx) | (bw << 18) | (capped ? REC_CAPPED : 0u);
+                r.y = best_len;
+            }
+            rec[st.pos_base + i] = r;
+        }
     }
     // has-match bitmap: tile starts are multiples of 64, so a wave covers exactly one word
     const uint64_t bits = __ballot(valid && r.y != 0);
