@@ -255,25 +255,33 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
 #pragma unroll 1
         for (uint32_t off = 4; off < CAND_C1; off += 16) {
             if (!__any(act[0] || act[1] || act[2] || act[3])) break;
+            // All five loads of a step are issued before the first use: each sits alone in its branch (idle
+            // lanes issue nothing) and the lengths are updated without branches afterwards. A load next to its
+            // use inside a branch would be waited for there, one candidate after the other.
             const bool room = off + 16 <= max_total;
-            uint4 a = make_uint4(0, 0, 0, 0);
-            if ((act[0] || act[1] || act[2] || act[3]) && room) a = ld_u128(s + i + off);
+            bool go[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) go[k] = act[k] && room;
+            const uint4 zero4 = make_uint4(0, 0, 0, 0);
+            uint4 a = zero4, bq[4] = {zero4, zero4, zero4, zero4};
+            if (go[0] || go[1] || go[2] || go[3]) a = ld_u128(s + i + off);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (go[k]) bq[k] = ld_u128(s + cc[k] + off);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                if (act[k]) {
-                    if (!room) { tail[k] = true; act[k] = false; }
-                    else {
-                        const uint4 bq = ld_u128(s + cc[k] + off);
-                        const uint64_t lo = ((uint64_t)(a.y ^ bq.y) << 32) | (a.x ^ bq.x);
-                        const uint64_t hi = ((uint64_t)(a.w ^ bq.w) << 32) | (a.z ^ bq.z);
-                        uint32_t m = 16;
-                        if (lo) m = (uint32_t)(__builtin_ctzll(lo) >> 3);
-                        else if (hi) m = 8 + (uint32_t)(__builtin_ctzll(hi) >> 3);
-                        ln[k] = off + m;
-                        if (m < 16) act[k] = false;
-                        if (ln[k] >= c1) { ln[k] = c1; act[k] = false; }
-                    }
-                }
+                const uint64_t lo = ((uint64_t)(a.y ^ bq[k].y) << 32) | (a.x ^ bq[k].x);
+                const uint64_t hi = ((uint64_t)(a.w ^ bq[k].w) << 32) | (a.z ^ bq[k].z);
+                // both halves are always consumed, so that neither load can be deferred into a branch
+                const uint32_t mlo = lo ? (uint32_t)(__builtin_ctzll(lo | (1ull << 63)) >> 3) : 16u;
+                const uint32_t mhi = hi ? 8 + (uint32_t)(__builtin_ctzll(hi | (1ull << 63)) >> 3) : 16u;
+                const uint32_t m = mlo < mhi ? mlo : mhi;
+                uint32_t nl = off + m;
+                const bool stop = m < 16 || nl >= c1;
+                nl = nl < c1 ? nl : c1;
+                tail[k] = tail[k] || (act[k] && !room);
+                ln[k] = go[k] ? nl : ln[k];
+                act[k] = go[k] && !stop;
             }
         }
 #pragma unroll
