@@ -190,6 +190,7 @@ __device__ uint32_t cand_wave_lcp(const uint8_t *s, uint32_t a, uint32_t b, uint
 // (the inside of one long match): only the head of a run is extended, by the whole wave, and the
 // followers derive LCP(i + t, c + t) = LCP(i, c) - t. Repetitive data costs O(1) per position.
 constexpr uint32_t CAND_C1 = 64;
+constexpr int CAND_GL = 8;  // lanes per group of the long-match work list
 constexpr uint32_t CAND_BPT = (TILE_POS + 255) / 256;  // workgroups per tile
 
 __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
@@ -198,6 +199,8 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
     // Workgroups are handed to the 8 XCDs round-robin. All workgroups of one tile go to the same XCD, so the
     // link records and source bytes a tile gathers from (its own 0.5 MB + the 2 MB window before it) stay in
     // that XCD's 4 MB L2 instead of being spread over all eight.
+    __shared__ uint32_t q_i[4][256], q_c[4][256];  // per-wave work list of phase 3: position, candidate
+    __shared__ uint16_t q_id[4][256], q_res[4][256];
     const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const uint32_t t = (slot / CAND_BPT) * 8 + xcd, bx = slot % CAND_BPT;
     if (t >= n_tiles) return;
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
         for (int k = 0; k < 4; k++) { act[k] = ln[k] != 0 && !fol[k] && c1 > 4 && !(dbg & 1); tail[k] = false; }
 #pragma unroll 1
         for (uint32_t off = 4; off < CAND_C1; off += 16) {
-            if (!__any(act[0] || act[1] || act[2] || act[3])) break;
+            if (!__any(act[0] || act[1] || act[2] || act[3]) || ((dbg & 16) && off > 4)) break;
             // All five loads of a step are issued before the first use: each sits alone in its branch (idle
             // lanes issue nothing) and the lengths are updated without branches afterwards. A load next to its
             // use inside a branch would be waited for there, one candidate after the other.
@@ -288,8 +291,84 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
         for (int k = 0; k < 4; k++)
             if (tail[k]) ln[k] = lcp_fwd(s, i, cc[k], ln[k], c1);  // within 80 bytes of the stream's end
     }
-    // ---- phase 3: heads still equal after CAND_C1 bytes are extended by the whole wave (up to FCAP + 64, so
-    // that 63 followers stay exact up to FCAP); then the followers take head - t ----
+    // ---- phase 3: heads still equal after CAND_C1 bytes go to a per-wave work list and are extended by groups
+    // of CAND_GL lanes, 16 bytes per lane and step, several heads at a time (up to FCAP + 64, so that 63
+    // followers stay exact up to FCAP); then the followers take head - t ----
+    {
+        const int wv = threadIdx.x >> 6;
+        bool more[4];
+        uint32_t total = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            more[k] = ln[k] == CAND_C1 && !fol[k] && CAND_C1 < cap_total && !(dbg & 8);
+            const uint64_t mk = __ballot(more[k]);
+            if (more[k]) {
+                const uint32_t q = total + (uint32_t)__popcll(mk & lt_mask);
+                q_i[wv][q] = i; q_c[wv][q] = cc[k]; q_id[wv][q] = (uint16_t)(k * 64 + lane);
+            }
+            total += (uint32_t)__popcll(mk);
+        }
+        if (total) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int g = lane / CAND_GL, sub = lane % CAND_GL;
+            const uint64_t gmask = ((1ull << CAND_GL) - 1) << (g * CAND_GL);
+            const uint64_t before = (1ull << (g * CAND_GL)) - 1;
+            uint32_t next = 0, it_i = 0, it_c = 0, it_lim = 0, it_off = 0, it_id = 0;
+            bool busy = false;
+            for (;;) {
+                const uint64_t idle = __ballot(!busy && sub == 0);
+                if (next < total && idle) {
+                    const uint32_t q = next + (uint32_t)__popcll(idle & before);
+                    if (!busy && q < total) {
+                        busy = true;
+                        it_i = q_i[wv][q]; it_c = q_c[wv][q]; it_id = q_id[wv][q];
+                        it_off = CAND_C1;
+                        const uint32_t maxh = n - it_i;
+                        it_lim = maxh < FCAP + 64 ? maxh : FCAP + 64;
+                    }
+                    next += (uint32_t)__popcll(idle);
+                }
+                if (!__any(busy)) break;
+                const uint32_t o = it_off + 16 * sub;
+                uint64_t xl = 0, xh = 0;
+                if (busy && o < it_lim) {
+                    if (it_i + o + 16 <= n) {
+                        const uint4 a = ld_u128(s + it_i + o), bq = ld_u128(s + it_c + o);
+                        xl = ((uint64_t)(a.y ^ bq.y) << 32) | (a.x ^ bq.x);
+                        xh = ((uint64_t)(a.w ^ bq.w) << 32) | (a.z ^ bq.z);
+                    } else {
+                        for (uint32_t t = 0; it_i + o + t < n; t++) {
+                            const uint64_t x = (uint64_t)(s[it_i + o + t] ^ s[it_c + o + t]);
+                            if (t < 8) xl |= x << (8 * t); else xh |= x << (8 * (t - 8));
+                        }
+                    }
+                }
+                const bool bad = (xl | xh) != 0;
+                const uint32_t r = o + (xl ? (uint32_t)(__builtin_ctzll(xl) >> 3) : 8 + (uint32_t)(__builtin_ctzll(xh | (1ull << 63)) >> 3));
+                const uint64_t badm = __ballot(bad) & gmask;
+                const uint32_t rr = __shfl(r, badm ? __builtin_ctzll(badm) : lane);
+                if (busy) {
+                    uint32_t res = 0;
+                    bool done = false;
+                    if (badm) { res = rr < it_lim ? rr : it_lim; done = true; }
+                    else {
+                        it_off += 16 * CAND_GL;
+                        if (it_off >= it_lim) { res = it_lim; done = true; }
+                    }
+                    if (done) {
+                        if (sub == 0) q_res[wv][it_id] = (uint16_t)res;
+                        busy = false;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (more[k]) ln[k] = q_res[wv][k * 64 + lane];
+        }
+    }
     uint32_t best_len = 0, best_idx = 0;
     bool capped = false;
 #pragma unroll
@@ -297,16 +376,6 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
         uint32_t len = ln[k];
         const uint32_t c = cc[k];
         const bool head = len != 0 && !fol[k];
-        uint64_t it = __ballot(head && len == CAND_C1 && CAND_C1 < cap_total);
-        while (it) {
-            const int h = __builtin_ctzll(it);
-            it &= it - 1;
-            const uint32_t i_h = e_readlane(i, h), c_h = e_readlane(c, h);
-            const uint32_t maxh = n - i_h;
-            const uint32_t limh = maxh < FCAP + 64 ? maxh : FCAP + 64;
-            const uint32_t hl = cand_wave_lcp(s, i_h, c_h, CAND_C1, limh);
-            if (lane == h) len = hl;
-        }
         const uint64_t hm = __ballot(head);
         if (__any(fol[k])) {
             const uint64_t below = hm & lt_mask;

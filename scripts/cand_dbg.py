@@ -14,11 +14,8 @@ def run(batch, dbg):
         outs, st = ctx.encode_batch(batch)
     t = ctx.timings()
     return {k: round(v[0], 3) for k, v in t.items() if k in ('enc_cand', 'enc_chain', 'enc_link', 'enc_spec', 'enc_block')}
-allb = [r.tobytes() for r in raws] * 64
-for dbg in (0, 1, 2, 3, 7):
-    print('all dbg', dbg, run(allb, dbg))
 for nm, r in zip(names, raws):
+    if nm not in ('html_x_4', 'urls.10K', 'geo.protodata', 'plrabn12.txt'):
+        continue
     b = [r.tobytes()] * 64
-    mb = len(b[0]) * 64 / 1e6
-    t = run(b, 0); t1 = run(b, 3)
-    print(f"{nm:28s} {mb:7.1f} MB cand {t['enc_cand']:.3f} ms = {mb / t['enc_cand']:.1f} GB/s ; noLCP {t1['enc_cand']:.3f} ; chain {t['enc_chain']:.3f} spec {t['enc_spec']:.3f} block {t['enc_block']:.3f}")
+    print(nm, ' '.join(f"dbg{g}={run(b, g)['enc_cand']:.3f}" for g in (0, 8, 16, 24, 1, 3, 2)))
