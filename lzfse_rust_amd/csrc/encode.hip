@@ -201,6 +201,7 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
     // that XCD's 4 MB L2 instead of being spread over all eight.
     __shared__ uint32_t q_i[4][256], q_c[4][256];  // per-wave work list of phase 3: position, candidate
     __shared__ uint16_t q_id[4][256], q_res[4][256];
+    __shared__ uint32_t q_dist[4][256], q_tab[4][64];  // distance of a listed head; first head per distance hash
     const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const uint32_t t = (slot / CAND_BPT) * 8 + xcd, bx = slot % CAND_BPT;
     if (t >= n_tiles) return;
@@ -296,17 +297,48 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
     // followers stay exact up to FCAP); then the followers take head - t ----
     {
         const int wv = threadIdx.x >> 6;
-        bool more[4];
-        uint32_t total = 0;
+        bool more[4], dep[4];
+        uint32_t lead[4];
+        uint64_t any_more = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             more[k] = ln[k] == CAND_C1 && !fol[k] && CAND_C1 < cap_total && !(dbg & 8);
-            const uint64_t mk = __ballot(more[k]);
-            if (more[k]) {
-                const uint32_t q = total + (uint32_t)__popcll(mk & lt_mask);
-                q_i[wv][q] = i; q_c[wv][q] = cc[k]; q_id[wv][q] = (uint16_t)(k * 64 + lane);
+            dep[k] = false; lead[k] = 0;
+            any_more |= __ballot(more[k]);
+        }
+        uint32_t total = 0;
+        if (any_more) {
+            // Heads of the wave with the same distance lie inside one match (they are < 64 positions apart and
+            // each is >= 64 long): LCP(i2, i2 - d) = LCP(i0, i0 - d) + i0 - i2. One of them is measured.
+            q_tab[wv][lane] = 0xFFFFFFFFu;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (more[k]) {
+                    const uint32_t dk = i - cc[k];
+                    q_dist[wv][k * 64 + lane] = dk;
+                    atomicMin(&q_tab[wv][(dk * 0x9E3779B1u) >> 26], (uint32_t)(k * 64 + lane));
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (more[k]) {
+                    const uint32_t dk = i - cc[k];
+                    lead[k] = q_tab[wv][(dk * 0x9E3779B1u) >> 26];
+                    dep[k] = lead[k] != (uint32_t)(k * 64 + lane) && q_dist[wv][lead[k]] == dk;
+                }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool ind = more[k] && !dep[k];
+                const uint64_t mk = __ballot(ind);
+                if (ind) {
+                    const uint32_t q = total + (uint32_t)__popcll(mk & lt_mask);
+                    q_i[wv][q] = i; q_c[wv][q] = cc[k]; q_id[wv][q] = (uint16_t)(k * 64 + lane);
+                }
+                total += (uint32_t)__popcll(mk);
             }
-            total += (uint32_t)__popcll(mk);
         }
         if (total) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -366,7 +398,7 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                if (more[k]) ln[k] = q_res[wv][k * 64 + lane];
+                if (more[k]) ln[k] = dep[k] ? q_res[wv][lead[k]] + (lead[k] & 63) - (uint32_t)lane : q_res[wv][k * 64 + lane];
         }
     }
     uint32_t best_len = 0, best_idx = 0;
