@@ -318,13 +318,16 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
     bool walking = false, done = false;
     while (!done && !x.status) {
         if (!walking) {
-            const SpecHeader hk = H0[k];
-            bool found = false;
-            if (k + 1 < K) {
-                const uint4 sy = sync[es.seg_base + k];  // enc_sync_kernel: (found, i, j)
-                if (sy.x) {
-                    found = true;
-                    const uint32_t i = sy.y, j = sy.z;
+            // following mode: the sync records of the next 64 boundaries are fetched by the 64 lanes at once and
+            // consumed from registers, so the serial hand-over chain costs no memory round trip per boundary
+            const int lane = e_lane();
+            const uint32_t kb = k;
+            uint4 sy_l = make_uint4(0, 0, 0, 0);
+            if (kb + lane + 1 < K) sy_l = sync[es.seg_base + kb + lane];  // enc_sync_kernel: (found, i, j)
+            for (int l = 0; l < 64 && !walking && !x.status; l++) {
+                const uint32_t found = e_readlane(sy_l.x, l);
+                if (found) {
+                    const uint32_t i = e_readlane(sy_l.y, l), j = e_readlane(sy_l.z, l);
                     // logs run in lock-step from (i, j) on; hand over no earlier than event a - 1
                     uint32_t i_eff = (a > 0 && i + 1 < a) ? a - 1 : i;
                     uint32_t j_eff = j + (i_eff - i);
@@ -332,15 +335,15 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
                     k = k + 1;
                     a = j_eff + 1;
                     st_syncs++;
+                } else {
+                    // adopt the rest of log k and continue from its final state
+                    const SpecHeader hk = H0[k];
+                    if (hk.n_events > a) sx_add_range(x, 0, (uint64_t)(es.seg_base + k) * SEG_EV_CAP + a, hk.n_events - a);
+                    T.index = hk.f_index; T.lit = hk.f_lit; T.p_idx = hk.f_pidx; T.p_midx = hk.f_pmidx; T.p_len = hk.f_plen;
+                    walking = true;
+                    st_fallbacks++;
+                    x.gap_open = x.n_gaps;
                 }
-            }
-            if (!found) {
-                // adopt the rest of log k and continue from its final state
-                if (hk.n_events > a) sx_add_range(x, 0, (uint64_t)(es.seg_base + k) * SEG_EV_CAP + a, hk.n_events - a);
-                T.index = hk.f_index; T.lit = hk.f_lit; T.p_idx = hk.f_pidx; T.p_midx = hk.f_pmidx; T.p_len = hk.f_plen;
-                walking = true;
-                st_fallbacks++;
-                x.gap_open = x.n_gaps;
             }
             continue;
         }
