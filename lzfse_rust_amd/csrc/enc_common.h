@@ -5,8 +5,8 @@
 namespace lzmi {
 
 constexpr uint32_t TILE_POS = 65472;        // positions per chain tile: multiple of 64 and of CAND_P, offset + 1 fits u16
-constexpr uint32_t SEG = 4096;              // positions per speculative-parse segment
-constexpr uint32_t OVER = 1024;             // overrun of a segment walker into the next segment
+constexpr uint32_t SEG = 2048;              // positions per speculative-parse segment
+constexpr uint32_t OVER = 512;              // overrun of a segment walker into the next segment
 constexpr uint32_t SEG_EV_CAP = (SEG + OVER) / 4 + 4;  // every emit advances literal_index by >= 4
 constexpr uint32_t NONE = 0xFFFFFFFFu;      // no previous position
 constexpr uint32_t NONE_TILE = 0xFFFFFFFEu; // no previous position inside the tile (link pending)

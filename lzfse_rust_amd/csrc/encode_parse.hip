@@ -124,15 +124,34 @@ __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict_
     WState st;
     st.index = exists ? S : 0; st.lit = S; st.p_idx = 0; st.p_midx = 0; st.p_len = 0;
     uint32_t nev = 0, status = 0;
+    uint32_t cw = NONE - 1;  // word index of w0 (w1 is the following word); nothing cached yet
+    uint64_t w0 = 0, w1 = 0;
     bool running = exists && st.index < stop;
     while (__any(running)) {
         uint32_t p = 0;
         uint2 rr = make_uint2(0, 0);
         bool have = false;
         if (running) {
-            p = next_has(bm, st.index, stop);
+            // the two bitmap words at the walker's position are kept in registers and refreshed together with
+            // the record load, so a step normally costs one memory round trip
+            const uint32_t w = st.index >> 6;
+            const uint64_t from = ~0ull << (st.index & 63);
+            bool hit = false;
+            uint32_t slow = st.index;
+            if (w == cw) {
+                if (w0 & from) { p = (w << 6) + (uint32_t)__builtin_ctzll(w0 & from); hit = true; }
+                else if (w1) { p = ((w + 1) << 6) + (uint32_t)__builtin_ctzll(w1); hit = true; }
+                else slow = (w + 2) << 6;
+            } else if (w == cw + 1) {
+                if (w1 & from) { p = (w << 6) + (uint32_t)__builtin_ctzll(w1 & from); hit = true; }
+                else slow = (w + 1) << 6;
+            }
+            if (!hit) p = slow < stop ? next_has(bm, slow, stop) : stop;
             if (p >= stop) { st.index = stop; running = false; }
-            else { st.index = p; rr = r[p]; have = true; }
+            else {
+                st.index = p; rr = r[p]; have = true;
+                if ((p >> 6) != cw) { cw = p >> 6; w0 = bm[cw]; w1 = bm[cw + 1]; }
+            }
         }
         uint32_t dist = rr.x & 0x3FFFF, bw = (rr.x >> 18) & 0xFF, fwd = rr.y;
         uint32_t midx = p - dist;
