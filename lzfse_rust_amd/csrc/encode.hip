@@ -805,7 +805,62 @@ __device__ __forceinline__ void or_bits(uint32_t *pk, uint32_t o, uint64_t v) {
     if (w2) atomicOr(&pk[wi + 2], w2);
 }
 
-static_assert(CE / BLK_THREADS == 2 && CL / BLK_THREADS == 8, "chunk shapes are baked into enc_block_kernel");
+// ---- FSE state chains, speculatively parallel ----
+// s' = t_w + (s >> nb), nb = (t_k + s) >> 10 (encoder.rs:191-199) forgets s quickly: nb bits of it per step.
+// Lane j of a wave runs steps [8 j, 8 j + 8) of a chain after a warm-up over the CH_WARM steps before them from an
+// arbitrary state; it is right iff its start state equals the end state of lane j - 1, which is checked, and the
+// first wrong lane is re-run from the right state until every lane checks out (lane 0 starts from the carried
+// true state). The result is exactly the serial recurrence.
+constexpr uint32_t CH_WARM = 24;
+constexpr uint32_t CH_LEN = 512;                    // steps of one chain per chunk = 64 lanes x 8
+constexpr uint32_t CH_ROW = CH_LEN + CH_LEN / 32;   // one padding word per 32 steps: lanes 8 steps apart miss each other's bank
+__device__ __forceinline__ uint32_t ch_at(uint32_t t) { return t + (t >> 5); }
+
+__device__ __forceinline__ uint32_t ch_step(uint32_t &s, uint32_t e) {
+    const int32_t tk = (int32_t)(int16_t)(e & 0xFFFF), tw = (int32_t)(int16_t)(e >> 16);
+    const uint32_t nb = (uint32_t)(tk + (int32_t)s) >> 10;
+    const uint32_t out = (s & ((1u << nb) - 1u)) | (nb << 16);
+    s = (uint32_t)(tw + (int32_t)(s >> nb));
+    return out;
+}
+
+// row: the chain's CH_ROW entries (E-table words in, state bits | nb << 16 out); cnt <= CH_LEN steps; returns the end state
+__device__ uint32_t chain_run(uint32_t *row, uint32_t cnt, uint32_t s_true, uint32_t s_any) {
+    const int lane = e_lane();
+    const uint32_t t0 = 8u * lane;
+    const bool mine = t0 < cnt;
+    const uint32_t nst = mine ? (cnt - t0 < 8 ? cnt - t0 : 8) : 0;
+    uint32_t e[8], o[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) e[u] = (uint32_t)u < nst ? row[ch_at(t0 + u)] : 0u;
+    uint32_t start = s_true;
+    if (mine && t0 > CH_WARM) {
+        start = s_any;
+        for (uint32_t t = t0 - CH_WARM; t < t0; t++) ch_step(start, row[ch_at(t)]);
+    } else if (mine && t0 > 0) {
+        for (uint32_t t = 0; t < t0; t++) ch_step(start, row[ch_at(t)]);
+    }
+    uint32_t end = start;
+#pragma unroll
+    for (int u = 0; u < 8; u++) if ((uint32_t)u < nst) o[u] = ch_step(end, e[u]);
+    for (;;) {
+        const uint32_t prev_end = __shfl_up(end, 1);
+        const uint64_t bad = __ballot(mine && lane > 0 && start != prev_end);
+        if (!bad) break;
+        if (lane == __builtin_ctzll(bad)) {
+            start = prev_end; end = start;
+#pragma unroll
+            for (int u = 0; u < 8; u++) if ((uint32_t)u < nst) o[u] = ch_step(end, e[u]);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();  // warm-up reads of the neighbours are done before anything is overwritten
+#pragma unroll
+    for (int u = 0; u < 8; u++) if ((uint32_t)u < nst) row[ch_at(t0 + u)] = o[u];
+    const int last = cnt ? (int)((cnt - 1) >> 3) : 0;
+    return cnt ? e_readlane(end, last) : s_true;
+}
+
+static_assert(CE == CH_LEN && CL == 4 * CH_LEN && CE / BLK_THREADS == 2 && CL / BLK_THREADS == 8, "chunk shapes are baked into enc_block_kernel");
 
 template <int DELTA>
 __device__ __forceinline__ uint32_t e_dpp_shr(uint32_t v) {
@@ -846,8 +901,8 @@ __global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *_
     __shared__ uint32_t wbits[N_WEIGHTS / 4 * 4 + 200];  // weight payload words (<= 630 bytes)
     __shared__ uint32_t scan_sh[3 * (BLK_THREADS / 64) + 2];
     __shared__ uint32_t sh_misc[16];
-    __shared__ uint32_t cl[CL];            // literal chunk: E entry -> (state bits | nb << 16)
-    __shared__ uint32_t ce[3 * CE];        // LMD chunk: D, M, L entries per LMD
+    __shared__ uint32_t cl[4 * CH_ROW];    // literal chunk, one row per state chain: E entry -> (state bits | nb << 16)
+    __shared__ uint32_t ce[3 * CH_ROW];    // LMD chunk: rows D, M, L
     __shared__ uint32_t pk_lit[PK_LIT];    // bit buffers of the current chunk
     __shared__ uint32_t pk_lmd[PK_LMD];
 
@@ -1036,8 +1091,8 @@ __global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *_
         const uint32_t it_lit = (n4 + CL - 1) / CL, it_lmd = (n_lmd + CE - 1) / CE;
         const uint32_t n_it = it_lit > it_lmd ? it_lit : it_lmd;
         uint32_t lit_bits_done = 0, lmd_bits_done = 0;  // bits already emitted (uniform)
-        // chain states: wave 0 lanes 0..3 -> literal state (3 - lane); wave 1 lanes 0..2 -> D, M, L
-        uint32_t cstate = (wave == 0) ? U_STATES : (lane == 0 ? D_STATES : 64u);
+        // chain states (wave-uniform): wave w carries literal state (3 - w) and, for w < 3, the D, M, L state
+        uint32_t lstate = U_STATES, mstate = wave == 0 ? D_STATES : 64u;
         for (uint32_t i = tid; i < PK_LIT; i += BLK_THREADS) pk_lit[i] = 0;
         for (uint32_t i = tid; i < PK_LMD; i += BLK_THREADS) pk_lmd[i] = 0;
         __syncthreads();
@@ -1046,7 +1101,7 @@ __global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *_
             const uint32_t lcnt = le0 < n4 ? (n4 - le0 < CL ? n4 - le0 : CL) : 0;
             const uint32_t mcnt = me0 < n_lmd ? (n_lmd - me0 < CE ? n_lmd - me0 : CE) : 0;
             // ---- A0 ----
-            for (uint32_t k = tid; k < lcnt; k += BLK_THREADS) cl[k] = etab[104 + lit[n4 - 1 - (le0 + k)]];
+            for (uint32_t k = tid; k < lcnt; k += BLK_THREADS) cl[(k & 3) * CH_ROW + ch_at(k >> 2)] = etab[104 + lit[n4 - 1 - (le0 + k)]];
             uint2 mrec[CE / BLK_THREADS];
 #pragma unroll
             for (int u = 0; u < CE / BLK_THREADS; u++) {
@@ -1055,61 +1110,15 @@ __global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *_
                 if (k < mcnt) {
                     uint2 r = bl[n_lmd - 1 - (me0 + k)];
                     mrec[u] = r;
-                    ce[3 * k + 0] = etab[40 + d_sym_of(r.y)];
-                    ce[3 * k + 1] = etab[20 + m_sym_of(r.x >> 16)];
-                    ce[3 * k + 2] = etab[l_sym_of(r.x & 0xFFFF)];
+                    ce[0 * CH_ROW + ch_at(k)] = etab[40 + d_sym_of(r.y)];
+                    ce[1 * CH_ROW + ch_at(k)] = etab[20 + m_sym_of(r.x >> 16)];
+                    ce[2 * CH_ROW + ch_at(k)] = etab[l_sym_of(r.x & 0xFFFF)];
                 }
             }
             __syncthreads();
-            // ---- A: serial state chains (entries are fetched 8 steps ahead of the recurrence) ----
-            if (wave == 0 && lane < 4) {
-                uint32_t k = lane;
-                for (; k + 28 < lcnt; k += 32) {
-                    uint32_t e[8];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) e[u] = cl[k + 4 * u];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        int32_t tk = (int32_t)(int16_t)(e[u] & 0xFFFF), tw = (int32_t)(int16_t)(e[u] >> 16);
-                        uint32_t nb = (uint32_t)(tk + (int32_t)cstate) >> 10;
-                        e[u] = (cstate & ((1u << nb) - 1u)) | (nb << 16);
-                        cstate = (uint32_t)(tw + (int32_t)(cstate >> nb));
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; u++) cl[k + 4 * u] = e[u];
-                }
-                for (; k < lcnt; k += 4) {
-                    uint32_t e = cl[k];
-                    int32_t tk = (int32_t)(int16_t)(e & 0xFFFF), tw = (int32_t)(int16_t)(e >> 16);
-                    uint32_t nb = (uint32_t)(tk + (int32_t)cstate) >> 10;
-                    cl[k] = (cstate & ((1u << nb) - 1u)) | (nb << 16);
-                    cstate = (uint32_t)(tw + (int32_t)(cstate >> nb));
-                }
-            } else if (wave == 1 && lane < 3) {
-                uint32_t k = lane;
-                const uint32_t n3 = 3 * mcnt;
-                for (; k + 21 < n3; k += 24) {
-                    uint32_t e[8];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) e[u] = ce[k + 3 * u];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        int32_t tk = (int32_t)(int16_t)(e[u] & 0xFFFF), tw = (int32_t)(int16_t)(e[u] >> 16);
-                        uint32_t nb = (uint32_t)(tk + (int32_t)cstate) >> 10;
-                        e[u] = (cstate & ((1u << nb) - 1u)) | (nb << 16);
-                        cstate = (uint32_t)(tw + (int32_t)(cstate >> nb));
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; u++) ce[k + 3 * u] = e[u];
-                }
-                for (; k < n3; k += 3) {
-                    uint32_t e = ce[k];
-                    int32_t tk = (int32_t)(int16_t)(e & 0xFFFF), tw = (int32_t)(int16_t)(e >> 16);
-                    uint32_t nb = (uint32_t)(tk + (int32_t)cstate) >> 10;
-                    ce[k] = (cstate & ((1u << nb) - 1u)) | (nb << 16);
-                    cstate = (uint32_t)(tw + (int32_t)(cstate >> nb));
-                }
-            }
+            // ---- A: state chains: wave w runs literal chain w (emissions k = w mod 4), then waves 0..2 run D, M, L ----
+            lstate = chain_run(cl + wave * CH_ROW, (lcnt + 3 - wave) >> 2, lstate, U_STATES);
+            if (wave < 3) mstate = chain_run(ce + wave * CH_ROW, mcnt, mstate, wave == 0 ? D_STATES : 64u);
             __syncthreads();
             // ---- B: widths, prefix sums, bit packing ----
             // literals: thread owns 8 consecutive emissions
@@ -1121,7 +1130,7 @@ __global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *_
                 for (int u = 0; u < (int)(CL / BLK_THREADS); u++) {
                     uint32_t k = k0 + u;
                     if (k < lcnt) {
-                        uint32_t e = cl[k];
+                        uint32_t e = cl[(k & 3) * CH_ROW + ch_at(k >> 2)];
                         uint32_t nb = e >> 16;
                         uint64_t v = e & 0xFFFF;
                         if (lw < 64) { lv0 |= v << lw; if (lw + nb > 64) lv1 |= v >> (64 - lw); }
@@ -1141,7 +1150,7 @@ __global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *_
                     uint2 r = mrec[u];
                     uint32_t vd = r.y, vm = r.x >> 16, vl = r.x & 0xFFFF;
                     uint32_t sd = d_sym_of(vd), sm = m_sym_of(vm), sl = l_sym_of(vl);
-                    uint32_t ed = ce[3 * k], em = ce[3 * k + 1], el = ce[3 * k + 2];
+                    uint32_t ed = ce[ch_at(k)], em = ce[CH_ROW + ch_at(k)], el = ce[2 * CH_ROW + ch_at(k)];
                     uint32_t nxd = d_extra_bits(sd), nxm = m_extra_bits(sm), nxl = l_extra_bits(sl);
                     uint64_t fd = (uint64_t)(vd - d_base_value(sd)) | ((uint64_t)(ed & 0xFFFF) << nxd);
                     uint32_t wd = nxd + (ed >> 16);
@@ -1210,8 +1219,8 @@ __global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *_
             sh_misc[7] = mb + 8;                       // lmd payload bytes incl. pad (lmds.rs:67-69,91)
             sh_misc[8] = mb * 8 - lmd_bits_done;
         }
-        if (wave == 0 && lane < 4) sh_misc[3 + (3 - lane)] = cstate - U_STATES;   // lane r carries state 3 - r
-        if (wave == 1 && lane < 3) sh_misc[lane == 0 ? 11 : (lane == 1 ? 10 : 9)] = cstate - (lane == 0 ? D_STATES : 64u);
+        if (lane == 0) sh_misc[3 + (3 - wave)] = lstate - U_STATES;   // chain r carries state 3 - r
+        if (lane == 0 && wave < 3) sh_misc[wave == 0 ? 11 : (wave == 1 ? 10 : 9)] = mstate - (wave == 0 ? D_STATES : 64u);
     }
     __syncthreads();
     // ---- header (block.rs:168-196) ----
