@@ -794,6 +794,11 @@ __device__ void normalize_m1(uint16_t *w, uint32_t n, uint32_t in_total, uint32_
     }
 }
 
+// Workgroup barrier that orders LDS traffic only. __syncthreads() also waits for every outstanding global load
+// (its workgroup fence drains vmcnt), which would expose the latency of loads issued one pass ahead; the data the
+// workgroup exchanges at these barriers lives in LDS, global memory is only read (inputs) or written (staging).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // OR a <= 64-bit little-endian bit field into a u32 LDS bit buffer at bit offset o
 __device__ __forceinline__ void or_bits(uint32_t *pk, uint32_t o, uint64_t v) {
     uint32_t wi = o >> 5, sh = o & 31;
@@ -824,33 +829,39 @@ __device__ __forceinline__ uint32_t ch_step(uint32_t &s, uint32_t e) {
     return out;
 }
 
-// row: the chain's CH_ROW entries (E-table words in, state bits | nb << 16 out); cnt <= CH_LEN steps; returns the end state
-__device__ uint32_t chain_run(uint32_t *row, uint32_t cnt, uint32_t s_true, uint32_t s_any) {
+// row: the chain's CH_ROW entries (E-table words in, state bits | nb << 16 out); cnt <= CH_LEN steps; returns the end
+// state. s_any = the chain's initial state value T: a valid state, and (-T & 0xFFFF) is an E entry that leaves every
+// state unchanged (nb = 0, t_w = 0), which keeps the step sequence free of branches.
+__device__ __forceinline__ uint32_t chain_run(uint32_t *row, uint32_t cnt, uint32_t s_true, uint32_t s_any) {
     const int lane = e_lane();
     const uint32_t t0 = 8u * lane;
     const bool mine = t0 < cnt;
     const uint32_t nst = mine ? (cnt - t0 < 8 ? cnt - t0 : 8) : 0;
-    uint32_t e[8], o[8];
+    const uint32_t ident = (0u - s_any) & 0xFFFFu;
+    uint32_t e[8], o[8], ew[CH_WARM];
 #pragma unroll
-    for (int u = 0; u < 8; u++) e[u] = (uint32_t)u < nst ? row[ch_at(t0 + u)] : 0u;
-    uint32_t start = s_true;
-    if (mine && t0 > CH_WARM) {
-        start = s_any;
-        for (uint32_t t = t0 - CH_WARM; t < t0; t++) ch_step(start, row[ch_at(t)]);
-    } else if (mine && t0 > 0) {
-        for (uint32_t t = 0; t < t0; t++) ch_step(start, row[ch_at(t)]);
-    }
+    for (int u = 0; u < 8; u++) e[u] = (uint32_t)u < nst ? row[ch_at(t0 + u)] : ident;
+    // warm-up over steps [t0 - CH_WARM, t0): lanes that would reach below step 0 start there with the true state
+#pragma unroll
+    for (int u = 0; u < (int)CH_WARM; u++) ew[u] = (mine && t0 + (uint32_t)u >= CH_WARM) ? row[ch_at(t0 + (uint32_t)u - CH_WARM)] : ident;
+    uint32_t start = (mine && t0 > CH_WARM) ? s_any : s_true;
+#pragma unroll
+    for (int u = 0; u < (int)CH_WARM; u++) ch_step(start, ew[u]);
     uint32_t end = start;
 #pragma unroll
-    for (int u = 0; u < 8; u++) if ((uint32_t)u < nst) o[u] = ch_step(end, e[u]);
+    for (int u = 0; u < 8; u++) o[u] = ch_step(end, e[u]);
     for (;;) {
         const uint32_t prev_end = __shfl_up(end, 1);
         const uint64_t bad = __ballot(mine && lane > 0 && start != prev_end);
         if (!bad) break;
-        if (lane == __builtin_ctzll(bad)) {
-            start = prev_end; end = start;
+        const bool fix = lane == __builtin_ctzll(bad);
+        uint32_t s2 = prev_end, o2[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) if ((uint32_t)u < nst) o[u] = ch_step(end, e[u]);
+        for (int u = 0; u < 8; u++) o2[u] = ch_step(s2, e[u]);
+        if (fix) {
+            start = prev_end; end = s2;
+#pragma unroll
+            for (int u = 0; u < 8; u++) o[u] = o2[u];
         }
     }
     __builtin_amdgcn_wave_barrier();  // warm-up reads of the neighbours are done before anything is overwritten
@@ -893,7 +904,8 @@ __device__ __forceinline__ uint32_t bo_finalize(BitOut &o) {
 __global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
                                                                 uint32_t n_streams, const EncStreamOut *__restrict__ outs,
                                                                 const uint2 *__restrict__ lmds, EncBlock *__restrict__ blocks,
-                                                                const uint32_t *__restrict__ slot_stream, uint8_t *__restrict__ stage) {
+                                                                const uint32_t *__restrict__ slot_stream, uint8_t *__restrict__ stage,
+                                                                unsigned long long *__restrict__ cyc) {
     __shared__ __attribute__((aligned(16))) uint8_t lit[LITERALS_PER_BLOCK + 16];
     __shared__ uint32_t hist[N_WEIGHTS];
     __shared__ uint16_t wts[N_WEIGHTS];
@@ -919,6 +931,11 @@ __global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *_
     const uint2 *bl = lmds + blk.lmd_start;
     uint8_t *sg = stage + blk.stage_off;
 
+    // diagnostics (LZFSE_MI_BLOCK_STATS): cycles per phase, summed over blocks
+    uint64_t tq = cyc ? __builtin_amdgcn_s_memtime() : 0;
+    auto lap = [&](int slot) {
+        if (cyc && tid == 0) { const uint64_t t2 = __builtin_amdgcn_s_memtime(); atomicAdd(&cyc[slot], (unsigned long long)(t2 - tq)); tq = t2; }
+    };
     for (uint32_t i = tid; i < N_WEIGHTS; i += BLK_THREADS) hist[i] = 0;
     for (uint32_t i = tid; i < sizeof(wbits) / 4; i += BLK_THREADS) wbits[i] = 0;
     __syncthreads();
@@ -926,10 +943,12 @@ __global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *_
     // ---- literal gather + LMD symbol histograms ----
     {
         uint32_t run_lit = 0, run_src = blk.src_start;
+        uint2 r_next = (uint32_t)tid < blk.n_lmd ? bl[tid] : make_uint2(0, 0);  // records are fetched one pass ahead
         for (uint32_t g0 = 0; g0 < blk.n_lmd; g0 += BLK_THREADS) {
             uint32_t idx = g0 + tid;
             bool valid = idx < blk.n_lmd;
-            uint2 r = valid ? bl[idx] : make_uint2(0, 0);
+            const uint2 r = r_next;
+            r_next = idx + BLK_THREADS < blk.n_lmd ? bl[idx + BLK_THREADS] : make_uint2(0, 0);
             uint32_t l = r.x & 0xFFFF, m = r.x >> 16, d = r.y;
             // block exclusive scan of l and l + m
             uint32_t il = l, is = l + m;
@@ -939,7 +958,7 @@ __global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *_
                 if (lane >= dd) { il += a; is += b2; }
             }
             if (lane == 63) { scan_sh[wave] = il; scan_sh[BLK_THREADS / 64 + wave] = is; }
-            __syncthreads();
+            lds_barrier();
             uint32_t ol = 0, os = 0, tl = 0, ts = 0;
             for (int wv = 0; wv < BLK_THREADS / 64; wv++) {
                 uint32_t a = scan_sh[wv], b2 = scan_sh[BLK_THREADS / 64 + wv];
@@ -978,10 +997,11 @@ __global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *_
                 for (uint32_t k = lane; k < q_n; k += 64) lit[q_dst + k] = s[q_src + k];
             }
             run_lit += tl; run_src += ts;
-            __syncthreads();
+            lds_barrier();
         }
     }
-    __syncthreads();
+    lds_barrier();
+    lap(0);
     // literals.rs:136-145 pad with literals[0]; weights.rs:56-64 literal histogram (unpadded)
     const uint32_t n_lit = blk.n_lit, n4 = (n_lit + 3) / 4 * 4;
     if (tid < 4) lit[n_lit + tid] = n_lit ? lit[0] : 0;
@@ -989,12 +1009,14 @@ __global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *_
     __syncthreads();
     for (uint32_t i = tid; i < N_WEIGHTS; i += BLK_THREADS) wts[i] = (uint16_t)hist[i];
     __syncthreads();
+    lap(1);
     // ---- normalize (one lane per table) ----
     if (tid == 0 && blk.n_lmd) normalize_m1(wts, 20, blk.n_lmd, L_STATES);
     if (tid == 64 && blk.n_lmd) normalize_m1(wts + 20, 20, blk.n_lmd, M_STATES);
     if (tid == 128 && blk.n_lmd) normalize_m1(wts + 40, 64, blk.n_lmd, D_STATES);
     if (tid == 192 && n_lit) normalize_m1(wts + 104, 256, n_lit, U_STATES);
     __syncthreads();
+    lap(2);
     // ---- weight payload (weight_encoder.rs:23-37, weights.rs:139-163) + E tables (encoder.rs:219-240) ----
     if (wave == 0) {
         uint32_t carry_bits = 0;
@@ -1076,6 +1098,7 @@ __global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *_
     // weight bytes -> staging after the 32-byte header
     for (uint32_t i = tid; i < n_wbytes; i += BLK_THREADS) sg[V2_HEADER_SIZE + i] = (uint8_t)(wbits[i >> 2] >> (8 * (i & 3)));
 
+    lap(3);
     // ---- the two reverse FSE streams (literals.rs:93-133, lmds.rs:62-93) ----
     // Only the state recurrence s' = t_w + (s >> nb), nb = (t_k + s) >> 10 (encoder.rs:191-199) is
     // serial. Per chunk: (A0) all threads look up the E-table entry of every symbol, (A) one lane
@@ -1096,6 +1119,14 @@ __global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *_
         for (uint32_t i = tid; i < PK_LIT; i += BLK_THREADS) pk_lit[i] = 0;
         for (uint32_t i = tid; i < PK_LMD; i += BLK_THREADS) pk_lmd[i] = 0;
         __syncthreads();
+        uint2 mnext[CE / BLK_THREADS];  // LMD records of the next chunk, fetched one pass ahead
+#pragma unroll
+        for (int u = 0; u < CE / BLK_THREADS; u++) {
+            const uint32_t k = tid + u * BLK_THREADS;
+            mnext[u] = k < n_lmd ? bl[n_lmd - 1 - k] : make_uint2(0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < CE / BLK_THREADS; u++) asm volatile("" ::"v"(mnext[u].x), "v"(mnext[u].y));  // see below
         for (uint32_t it = 0; it < n_it; it++) {
             const uint32_t le0 = it * CL, me0 = it * CE;
             const uint32_t lcnt = le0 < n4 ? (n4 - le0 < CL ? n4 - le0 : CL) : 0;
@@ -1106,20 +1137,22 @@ __global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *_
 #pragma unroll
             for (int u = 0; u < CE / BLK_THREADS; u++) {
                 uint32_t k = tid + u * BLK_THREADS;
-                mrec[u] = make_uint2(0, 0);
+                mrec[u] = mnext[u];
+                mnext[u] = me0 + CE + k < n_lmd ? bl[n_lmd - 1 - (me0 + CE + k)] : make_uint2(0, 0);
                 if (k < mcnt) {
-                    uint2 r = bl[n_lmd - 1 - (me0 + k)];
-                    mrec[u] = r;
+                    uint2 r = mrec[u];
                     ce[0 * CH_ROW + ch_at(k)] = etab[40 + d_sym_of(r.y)];
                     ce[1 * CH_ROW + ch_at(k)] = etab[20 + m_sym_of(r.x >> 16)];
                     ce[2 * CH_ROW + ch_at(k)] = etab[l_sym_of(r.x & 0xFFFF)];
                 }
             }
-            __syncthreads();
+            lds_barrier();
+            lap(4);
             // ---- A: state chains: wave w runs literal chain w (emissions k = w mod 4), then waves 0..2 run D, M, L ----
             lstate = chain_run(cl + wave * CH_ROW, (lcnt + 3 - wave) >> 2, lstate, U_STATES);
             if (wave < 3) mstate = chain_run(ce + wave * CH_ROW, mcnt, mstate, wave == 0 ? D_STATES : 64u);
-            __syncthreads();
+            lds_barrier();
+            lap(5);
             // ---- B: widths, prefix sums, bit packing ----
             // literals: thread owns 8 consecutive emissions
             uint64_t lv0 = 0, lv1 = 0;  // up to 80 bits
@@ -1171,7 +1204,7 @@ __global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *_
                 if (lane >= dd) { ia += x; ib += y; ic += z; }
             }
             if (lane == 63) { scan_sh[wave] = ia; scan_sh[4 + wave] = ib; scan_sh[8 + wave] = ic; }
-            __syncthreads();
+            lds_barrier();
             uint32_t oa = 0, ob = 0, oc = 0, ta = 0, tb2 = 0, tc = 0;
             for (int wv = 0; wv < BLK_THREADS / 64; wv++) {
                 uint32_t x = scan_sh[wv], y = scan_sh[4 + wv], z = scan_sh[8 + wv];
@@ -1190,7 +1223,11 @@ __global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *_
                 for (int u = 0; u < (int)(CE / BLK_THREADS); u++)
                     if (mw[u]) or_bits(pk_lmd, (lmd_bits_done & 31) + (u == 0 ? ex_b : ex_c), mv[u]);
             }
-            __syncthreads();
+            lds_barrier();
+            // The records fetched for the next pass are touched here, while nothing younger is in flight: at the
+            // loop's back edge the compiler could only wait for everything, the word stores below included.
+#pragma unroll
+            for (int u = 0; u < CE / BLK_THREADS; u++) asm volatile("" ::"v"(mnext[u].x), "v"(mnext[u].y));
             // store completed words, carry the incomplete one to word 0
             {
                 uint32_t have = (lit_bits_done & 31) + ta, full = have >> 5;
@@ -1201,13 +1238,14 @@ __global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *_
                 uint32_t m0 = lmd_bits_done >> 5;
                 for (uint32_t k = tid; k < full_m; k += BLK_THREADS) lmd_words[m0 + k] = pk_lmd[k];
                 uint32_t carry_m = pk_lmd[full_m];
-                __syncthreads();
+                lds_barrier();
                 for (uint32_t k = tid; k <= full + 3 && k < PK_LIT; k += BLK_THREADS) pk_lit[k] = k == 0 ? carry : 0;
                 for (uint32_t k = tid; k <= full_m + 3 && k < PK_LMD; k += BLK_THREADS) pk_lmd[k] = k == 0 ? carry_m : 0;
                 lit_bits_done += ta;
                 lmd_bits_done += tb2 + tc;
             }
-            __syncthreads();
+            lds_barrier();
+            lap(6);
         }
         // finalize (bit_writer.rs:46-57): the last partial word, unused bits of the last byte
         if (tid == 0) {
@@ -1296,7 +1334,7 @@ __global__ __launch_bounds__(256) void enc_pack_kernel(const EncStream *__restri
 // ------------------------------------------------------------------------------------ host side
 
 enum { EB_STREAMS, EB_TILES, EB_PREV, EB_SUMMARY, EB_REC, EB_LMDS, EB_BLOCKS, EB_OUTS, EB_STAGE, EB_SLOTS,
-       EB_BITMAP, EB_SEGS, EB_LOGS, EB_HDRS, EB_RANGES, EB_GAPS, EB_MATCHES, EB_PC, EB_PL, EB_RSLOTS, EB_SYNC, EB_RSUM, EB_N };
+       EB_BITMAP, EB_SEGS, EB_LOGS, EB_HDRS, EB_RANGES, EB_GAPS, EB_MATCHES, EB_PC, EB_PL, EB_RSLOTS, EB_SYNC, EB_RSUM, EB_DBG, EB_N };
 static_assert(EB_N <= 32, "EncScratch slots");
 
 static bool eb_ensure(EncScratch &s, int i, size_t n) {
@@ -1462,8 +1500,13 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     }
     {
         StageTimer t(c, "enc_block");
+        unsigned long long *d_cyc = nullptr;
+        if (getenv("LZFSE_MI_BLOCK_STATS") && eb_ensure(S, EB_DBG, 64)) {
+            d_cyc = (unsigned long long *)S.bufs[EB_DBG];
+            E_TRY(hipMemsetAsync(d_cyc, 0, 64, stq));
+        }
         hipLaunchKernelGGL(enc_block_kernel, dim3(blk_total), dim3(BLK_THREADS), 0, stq, d_src, d_streams, ns, d_outs, d_lmds,
-                           d_blocks, d_slots, d_stage);
+                           d_blocks, d_slots, d_stage, d_cyc);
     }
     {
         StageTimer t(c, "enc_pack");
@@ -1477,6 +1520,13 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         uint32_t u = hs[i].user_index;
         statuses[u] = ho[i].status;
         out_lens[u] = ho[i].status ? 0 : ho[i].out_len;
+    }
+    if (getenv("LZFSE_MI_BLOCK_STATS") && S.bufs[EB_DBG]) {
+        unsigned long long hc[8];
+        if (hipMemcpy(hc, S.bufs[EB_DBG], 64, hipMemcpyDeviceToHost) == hipSuccess)
+            fprintf(stderr, "enc_block cycles/block: gather %llu lit_hist %llu normalize %llu tables %llu | per chunk pass: lookup %llu chains %llu pack+store %llu (blocks %u)\n",
+                    hc[0] / blk_total, hc[1] / blk_total, hc[2] / blk_total, hc[3] / blk_total, hc[4] / blk_total, hc[5] / blk_total,
+                    hc[6] / blk_total, blk_total);
     }
     if (getenv("LZFSE_MI_WALK_STATS")) {
         for (uint32_t i = 0; i < ns && i < 16; i++)
