@@ -44,6 +44,11 @@ def synth_cases():
         "noise": rng_gen_vec(9, 200000),
         "ramp": bytes(range(256)) * 1500,
         "tail3": text[:4100],
+        # heavily skewed symbol statistics: one FSE symbol takes most of a table, so states lose almost no bits per
+        # step (the speculative state chains of enc_block_kernel must fall back to their exact fix-up path)
+        "skew2": rng.choice(np.array([0x41, 0x42], dtype=np.uint8), p=[0.93, 0.07], size=300000).tobytes(),
+        "skew_geo": np.minimum(rng.geometric(0.4, size=400000) - 1, 255).astype(np.uint8).tobytes(),
+        "skew_sparse": (rng.integers(1, 256, size=500000, dtype=np.uint8) * (rng.random(500000) < 0.05)).astype(np.uint8).tobytes(),
     }
 
 
