@@ -218,7 +218,9 @@ def main():
                     traffic = int(sum(pm[k]["hbm_bytes_raw"] * pm[k]["launches"] for k in key) / sum(pm[k]["launches"] for k in key))
         except Exception:
             traffic = None
-        alg_bytes = comp_total + raw_total  # B_dec = compressed_in + raw_out ; B_enc = raw_in + compressed_out
+        # B_dec = compressed_in + raw_out ; B_enc = raw_in + compressed_out, per step; a batch call may be cut into
+        # sub-batches that run side by side (split batches), so one launch covers bytes-per-step x steps / launches
+        alg_bytes = int((comp_total + raw_total) * args.steps / max(kern_n[dom], 1))
         achieved = alg_bytes / (dom_avg_ms * 1e-3) / 1e9
         out = {
             "metric": "encode+decode MB/s on Snappy corpus",

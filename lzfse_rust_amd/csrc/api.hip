@@ -11,6 +11,9 @@
 #include <cstring>
 #include <new>
 #include <vector>
+#include <thread>
+#include <system_error>
+#include <functional>
 
 #include "common.h"
 #include "internal.h"
@@ -72,6 +75,10 @@ struct lzfse_mi_ctx {
     struct Span { const char *name; hipEvent_t a, b; };
     std::vector<Span> spans;
     lzfse_mi_timings last{};
+    // second lane of a split batch call: own stream, scratch and timers (created on first use)
+    lzfse_mi_ctx *shadow = nullptr;
+    hipEvent_t split_ev = nullptr;
+    bool last_split = false;
 
     hipEvent_t get_event() {
         if (ev_used == ev_pool.size()) {
@@ -188,7 +195,10 @@ int lzfse_mi_create(int device, lzfse_mi_ctx **out) {
 
 void lzfse_mi_destroy(lzfse_mi_ctx *c) {
     if (!c) return;
+    if (c->shadow) lzfse_mi_destroy(c->shadow);
+    c->shadow = nullptr;
     (void)hipSetDevice(c->device);
+    if (c->split_ev) (void)hipEventDestroy(c->split_ev);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->d_streams, &c->d_walk, &c->d_plan, &c->d_blocks, &c->d_bres, &c->d_sres,
                       &c->d_lmds, &c->d_lits, &c->d_origin, &c->d_jerr, &c->d_in, &c->d_out})
@@ -218,6 +228,24 @@ int lzfse_mi_enable_timing(lzfse_mi_ctx *c, int enable) {
 int lzfse_mi_get_timings(lzfse_mi_ctx *c, lzfse_mi_timings *out) {
     if (!c || !out) return LZFSE_MI_BAD_ARGUMENT;
     *out = c->last;
+    if (c->last_split && c->shadow) {
+        // a split call ran two sub-batches side by side: stages are reported with the launches and the device time
+        // of both (the spans of the two lanes overlap on the device)
+        const lzfse_mi_timings &s = c->shadow->last;
+        for (int j = 0; j < s.n_stages; j++) {
+            int k = -1;
+            for (int i = 0; i < out->n_stages; i++)
+                if (out->names[i] == s.names[j]) k = i;
+            if (k < 0) {
+                if (out->n_stages == LZFSE_MI_MAX_STAGES) continue;
+                k = out->n_stages++;
+                out->names[k] = s.names[j];
+                out->ms[k] = 0; out->launches[k] = 0;
+            }
+            out->ms[k] += s.ms[j];
+            out->launches[k] += s.launches[j];
+        }
+    }
     return LZFSE_MI_OK;
 }
 
@@ -263,9 +291,9 @@ int lzfse_mi_decode_size(const uint8_t *src, size_t n, uint64_t *raw_len) {
 
 // ---------------------------------------------------------------------------- decode (device)
 
-int lzfse_mi_decode_batch_device(lzfse_mi_ctx *c, size_t count, const void *d_src, const uint64_t *src_off,
-                                 const uint64_t *src_len, void *d_dst, const uint64_t *dst_off,
-                                 const uint64_t *dst_cap, uint64_t *out_lens, int *statuses) {
+static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_src, const uint64_t *src_off,
+                                   const uint64_t *src_len, void *d_dst, const uint64_t *dst_off,
+                                   const uint64_t *dst_cap, uint64_t *out_lens, int *statuses) {
     if (!c || (count && (!src_off || !src_len || !dst_off || !dst_cap || !out_lens || !statuses)))
         return LZFSE_MI_BAD_ARGUMENT;
     if (count == 0) return LZFSE_MI_OK;
@@ -371,9 +399,9 @@ int lzfse_mi_decode_batch_device(lzfse_mi_ctx *c, size_t count, const void *d_sr
     return LZFSE_MI_OK;
 }
 
-int lzfse_mi_encode_batch_device(lzfse_mi_ctx *c, size_t count, const void *d_src, const uint64_t *src_off,
-                                 const uint64_t *src_len, void *d_dst, const uint64_t *dst_off,
-                                 const uint64_t *dst_cap, uint64_t *out_lens, int *statuses) {
+static int encode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_src, const uint64_t *src_off,
+                                   const uint64_t *src_len, void *d_dst, const uint64_t *dst_off,
+                                   const uint64_t *dst_cap, uint64_t *out_lens, int *statuses) {
     if (!c || (count && (!src_off || !src_len || !dst_off || !dst_cap || !out_lens || !statuses)))
         return LZFSE_MI_BAD_ARGUMENT;
     if (count == 0) return LZFSE_MI_OK;
@@ -403,10 +431,81 @@ int lzfse_mi_encode_batch_device(lzfse_mi_ctx *c, size_t count, const void *d_sr
     return LZFSE_MI_OK;
 }
 
-// ---------------------------------------------------------------------------- host-pointer API
+// ---------------------------------------------------------------------------- split batches
 
 typedef int (*batch_dev_fn)(lzfse_mi_ctx *, size_t, const void *, const uint64_t *, const uint64_t *, void *,
                             const uint64_t *, const uint64_t *, uint64_t *, int *);
+
+// Several stages of both directions are bound by latency or by a serial chain per stream/block and leave most of
+// the chip idle (chains per tile, segment walkers, FSE blocks). A large batch is therefore cut into two halves of
+// about equal size that run side by side: the caller's thread drives one half on the context's stream, a helper
+// thread drives the other on the shadow context's own stream and scratch. Streams are independent, so the results
+// are those of one call. LZFSE_MI_NO_SPLIT=1 turns this off.
+static int split_batch(lzfse_mi_ctx *c, batch_dev_fn one, size_t count, const void *d_src, const uint64_t *src_off,
+                       const uint64_t *src_len, void *d_dst, const uint64_t *dst_off, const uint64_t *dst_cap,
+                       uint64_t *out_lens, int *statuses) {
+    if (!c) return LZFSE_MI_BAD_ARGUMENT;
+    c->last_split = false;
+    uint64_t total = 0;
+    if (count && src_len)
+        for (size_t i = 0; i < count; i++) total += src_len[i];
+    static const bool no_split = getenv("LZFSE_MI_NO_SPLIT") != nullptr;
+    if (no_split || count < 8 || total < (4u << 20) || !src_off || !dst_off || !dst_cap || !out_lens || !statuses)
+        return one(c, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap, out_lens, statuses);
+    if (hipSetDevice(c->device) != hipSuccess) return LZFSE_MI_IO;
+    if (!c->shadow && lzfse_mi_create(c->device, &c->shadow) != LZFSE_MI_OK) c->shadow = nullptr;
+    if (!c->split_ev && hipEventCreateWithFlags(&c->split_ev, hipEventDisableTiming) != hipSuccess) c->split_ev = nullptr;
+    if (!c->shadow || !c->split_ev)
+        return one(c, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap, out_lens, statuses);
+    struct Part {
+        std::vector<size_t> idx;
+        std::vector<uint64_t> so, sl, dof, dc, ol;
+        std::vector<int> st;
+        uint64_t bytes = 0;
+        int rc = 0;
+    } part[2];
+    for (size_t i = 0; i < count; i++) {
+        Part &p = part[part[1].bytes < part[0].bytes ? 1 : 0];
+        p.idx.push_back(i); p.so.push_back(src_off[i]); p.sl.push_back(src_len[i]);
+        p.dof.push_back(dst_off[i]); p.dc.push_back(dst_cap[i]);
+        p.bytes += src_len[i];
+    }
+    for (Part &p : part) { p.ol.assign(p.idx.size(), 0); p.st.assign(p.idx.size(), 0); }
+    // the helper lane starts after everything already queued on the caller's stream
+    if (hipEventRecord(c->split_ev, c->stream) != hipSuccess || hipStreamWaitEvent(c->shadow->stream, c->split_ev, 0) != hipSuccess)
+        return one(c, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap, out_lens, statuses);
+    c->shadow->timing = c->timing;
+    auto run = [&](lzfse_mi_ctx *cx, Part &p) {
+        p.rc = one(cx, p.idx.size(), d_src, p.so.data(), p.sl.data(), d_dst, p.dof.data(), p.dc.data(), p.ol.data(), p.st.data());
+    };
+    bool threaded = true;
+    try {
+        std::thread helper(run, c->shadow, std::ref(part[1]));
+        run(c, part[0]);
+        helper.join();
+    } catch (const std::system_error &) {
+        threaded = false;
+    }
+    if (!threaded) return one(c, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap, out_lens, statuses);
+    for (Part &p : part)
+        for (size_t k = 0; k < p.idx.size(); k++) { out_lens[p.idx[k]] = p.ol[k]; statuses[p.idx[k]] = p.st[k]; }
+    c->last_split = true;
+    return part[0].rc ? part[0].rc : part[1].rc;
+}
+
+int lzfse_mi_decode_batch_device(lzfse_mi_ctx *c, size_t count, const void *d_src, const uint64_t *src_off,
+                                 const uint64_t *src_len, void *d_dst, const uint64_t *dst_off,
+                                 const uint64_t *dst_cap, uint64_t *out_lens, int *statuses) {
+    return split_batch(c, decode_batch_device_one, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap, out_lens, statuses);
+}
+
+int lzfse_mi_encode_batch_device(lzfse_mi_ctx *c, size_t count, const void *d_src, const uint64_t *src_off,
+                                 const uint64_t *src_len, void *d_dst, const uint64_t *dst_off,
+                                 const uint64_t *dst_cap, uint64_t *out_lens, int *statuses) {
+    return split_batch(c, encode_batch_device_one, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap, out_lens, statuses);
+}
+
+// ---------------------------------------------------------------------------- host-pointer API
 
 static int host_batch(lzfse_mi_ctx *c, batch_dev_fn fn, size_t count, const uint8_t *const *srcs,
                       const size_t *lens, uint8_t *const *dsts, const size_t *caps, size_t *out_lens,
