@@ -55,6 +55,8 @@ struct HostBuf {  // pinned staging
 
 }  // namespace
 
+#define LZFSE_MI_MAX_LANES 4
+
 struct lzfse_mi_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -76,9 +78,9 @@ struct lzfse_mi_ctx {
     std::vector<Span> spans;
     lzfse_mi_timings last{};
     // second lane of a split batch call: own stream, scratch and timers (created on first use)
-    lzfse_mi_ctx *shadow = nullptr;
+    lzfse_mi_ctx *shadow[LZFSE_MI_MAX_LANES - 1] = {};
     hipEvent_t split_ev = nullptr;
-    bool last_split = false;
+    int last_split = 0;  // helper lanes used by the last batch call
 
     hipEvent_t get_event() {
         if (ev_used == ev_pool.size()) {
@@ -195,8 +197,7 @@ int lzfse_mi_create(int device, lzfse_mi_ctx **out) {
 
 void lzfse_mi_destroy(lzfse_mi_ctx *c) {
     if (!c) return;
-    if (c->shadow) lzfse_mi_destroy(c->shadow);
-    c->shadow = nullptr;
+    for (auto &s : c->shadow) { if (s) lzfse_mi_destroy(s); s = nullptr; }
     (void)hipSetDevice(c->device);
     if (c->split_ev) (void)hipEventDestroy(c->split_ev);
     (void)hipStreamSynchronize(c->stream);
@@ -228,10 +229,11 @@ int lzfse_mi_enable_timing(lzfse_mi_ctx *c, int enable) {
 int lzfse_mi_get_timings(lzfse_mi_ctx *c, lzfse_mi_timings *out) {
     if (!c || !out) return LZFSE_MI_BAD_ARGUMENT;
     *out = c->last;
-    if (c->last_split && c->shadow) {
-        // a split call ran two sub-batches side by side: stages are reported with the launches and the device time
-        // of both (the spans of the two lanes overlap on the device)
-        const lzfse_mi_timings &s = c->shadow->last;
+    // a split call ran sub-batches side by side: stages are reported with the launches and the device time of all
+    // lanes (the spans of the lanes overlap on the device)
+    for (int lane = 0; lane < c->last_split; lane++) {
+        if (!c->shadow[lane]) continue;
+        const lzfse_mi_timings &s = c->shadow[lane]->last;
         for (int j = 0; j < s.n_stages; j++) {
             int k = -1;
             for (int i = 0; i < out->n_stages; i++)
@@ -437,25 +439,29 @@ typedef int (*batch_dev_fn)(lzfse_mi_ctx *, size_t, const void *, const uint64_t
                             const uint64_t *, const uint64_t *, uint64_t *, int *);
 
 // Several stages of both directions are bound by latency or by a serial chain per stream/block and leave most of
-// the chip idle (chains per tile, segment walkers, FSE blocks). A large batch is therefore cut into two halves of
-// about equal size that run side by side: the caller's thread drives one half on the context's stream, a helper
-// thread drives the other on the shadow context's own stream and scratch. Streams are independent, so the results
-// are those of one call. LZFSE_MI_NO_SPLIT=1 turns this off.
-static int split_batch(lzfse_mi_ctx *c, batch_dev_fn one, size_t count, const void *d_src, const uint64_t *src_off,
+// the chip idle (chains per tile, segment walkers, FSE blocks). A large batch is therefore cut into sub-batches of
+// about equal size that run side by side: the caller's thread drives one on the context's stream, helper threads
+// drive the others on shadow contexts (own stream and scratch each). Streams are independent, so the results are
+// those of one call. Measured best: 2 lanes in both directions (LZFSE_MI_LANES_ENC / _DEC override,
+// LZFSE_MI_NO_SPLIT=1 turns it off).
+static int split_batch(lzfse_mi_ctx *c, batch_dev_fn one, int lanes, size_t count, const void *d_src, const uint64_t *src_off,
                        const uint64_t *src_len, void *d_dst, const uint64_t *dst_off, const uint64_t *dst_cap,
                        uint64_t *out_lens, int *statuses) {
     if (!c) return LZFSE_MI_BAD_ARGUMENT;
-    c->last_split = false;
+    c->last_split = 0;
     uint64_t total = 0;
     if (count && src_len)
         for (size_t i = 0; i < count; i++) total += src_len[i];
     static const bool no_split = getenv("LZFSE_MI_NO_SPLIT") != nullptr;
-    if (no_split || count < 8 || total < (4u << 20) || !src_off || !dst_off || !dst_cap || !out_lens || !statuses)
+    if (lanes > LZFSE_MI_MAX_LANES) lanes = LZFSE_MI_MAX_LANES;
+    while (lanes > 1 && (count < (size_t)4 * lanes || total < ((uint64_t)lanes << 21))) lanes--;
+    if (no_split || lanes < 2 || !src_off || !dst_off || !dst_cap || !out_lens || !statuses)
         return one(c, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap, out_lens, statuses);
     if (hipSetDevice(c->device) != hipSuccess) return LZFSE_MI_IO;
-    if (!c->shadow && lzfse_mi_create(c->device, &c->shadow) != LZFSE_MI_OK) c->shadow = nullptr;
     if (!c->split_ev && hipEventCreateWithFlags(&c->split_ev, hipEventDisableTiming) != hipSuccess) c->split_ev = nullptr;
-    if (!c->shadow || !c->split_ev)
+    for (int k = 0; k + 1 < lanes; k++)
+        if (!c->shadow[k] && lzfse_mi_create(c->device, &c->shadow[k]) != LZFSE_MI_OK) { c->shadow[k] = nullptr; lanes = k + 1; break; }
+    if (lanes < 2 || !c->split_ev)
         return one(c, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap, out_lens, statuses);
     struct Part {
         std::vector<size_t> idx;
@@ -463,46 +469,64 @@ static int split_batch(lzfse_mi_ctx *c, batch_dev_fn one, size_t count, const vo
         std::vector<int> st;
         uint64_t bytes = 0;
         int rc = 0;
-    } part[2];
+    };
+    std::vector<Part> part((size_t)lanes);
     for (size_t i = 0; i < count; i++) {
-        Part &p = part[part[1].bytes < part[0].bytes ? 1 : 0];
+        size_t best = 0;
+        for (size_t k = 1; k < part.size(); k++)
+            if (part[k].bytes < part[best].bytes) best = k;
+        Part &p = part[best];
         p.idx.push_back(i); p.so.push_back(src_off[i]); p.sl.push_back(src_len[i]);
         p.dof.push_back(dst_off[i]); p.dc.push_back(dst_cap[i]);
         p.bytes += src_len[i];
     }
     for (Part &p : part) { p.ol.assign(p.idx.size(), 0); p.st.assign(p.idx.size(), 0); }
-    // the helper lane starts after everything already queued on the caller's stream
-    if (hipEventRecord(c->split_ev, c->stream) != hipSuccess || hipStreamWaitEvent(c->shadow->stream, c->split_ev, 0) != hipSuccess)
-        return one(c, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap, out_lens, statuses);
-    c->shadow->timing = c->timing;
+    // the helper lanes start after everything already queued on the caller's stream
+    bool ok = hipEventRecord(c->split_ev, c->stream) == hipSuccess;
+    for (int k = 0; ok && k + 1 < lanes; k++) {
+        ok = hipStreamWaitEvent(c->shadow[k]->stream, c->split_ev, 0) == hipSuccess;
+        c->shadow[k]->timing = c->timing;
+    }
+    if (!ok) return one(c, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap, out_lens, statuses);
     auto run = [&](lzfse_mi_ctx *cx, Part &p) {
         p.rc = one(cx, p.idx.size(), d_src, p.so.data(), p.sl.data(), d_dst, p.dof.data(), p.dc.data(), p.ol.data(), p.st.data());
     };
-    bool threaded = true;
+    std::vector<std::thread> helpers;
+    size_t started = 0;
     try {
-        std::thread helper(run, c->shadow, std::ref(part[1]));
-        run(c, part[0]);
-        helper.join();
+        for (int k = 0; k + 1 < lanes; k++) { helpers.emplace_back(run, c->shadow[k], std::ref(part[(size_t)k + 1])); started++; }
     } catch (const std::system_error &) {
-        threaded = false;
     }
-    if (!threaded) return one(c, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap, out_lens, statuses);
-    for (Part &p : part)
+    run(c, part[0]);
+    for (auto &h : helpers) h.join();
+    for (size_t k = started + 1; k < part.size(); k++) run(c, part[k]);  // lanes whose thread could not be started
+    int rc = 0;
+    for (Part &p : part) {
         for (size_t k = 0; k < p.idx.size(); k++) { out_lens[p.idx[k]] = p.ol[k]; statuses[p.idx[k]] = p.st[k]; }
-    c->last_split = true;
-    return part[0].rc ? part[0].rc : part[1].rc;
+        if (p.rc && !rc) rc = p.rc;
+    }
+    c->last_split = (int)started;
+    return rc;
+}
+
+static int lanes_of(const char *env, int dflt) {
+    const char *v = getenv(env);
+    int n = v ? atoi(v) : dflt;
+    return n < 1 ? 1 : n;
 }
 
 int lzfse_mi_decode_batch_device(lzfse_mi_ctx *c, size_t count, const void *d_src, const uint64_t *src_off,
                                  const uint64_t *src_len, void *d_dst, const uint64_t *dst_off,
                                  const uint64_t *dst_cap, uint64_t *out_lens, int *statuses) {
-    return split_batch(c, decode_batch_device_one, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap, out_lens, statuses);
+    static const int lanes = lanes_of("LZFSE_MI_LANES_DEC", 2);
+    return split_batch(c, decode_batch_device_one, lanes, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap, out_lens, statuses);
 }
 
 int lzfse_mi_encode_batch_device(lzfse_mi_ctx *c, size_t count, const void *d_src, const uint64_t *src_off,
                                  const uint64_t *src_len, void *d_dst, const uint64_t *dst_off,
                                  const uint64_t *dst_cap, uint64_t *out_lens, int *statuses) {
-    return split_batch(c, encode_batch_device_one, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap, out_lens, statuses);
+    static const int lanes = lanes_of("LZFSE_MI_LANES_ENC", 2);
+    return split_batch(c, encode_batch_device_one, lanes, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap, out_lens, statuses);
 }
 
 // ---------------------------------------------------------------------------- host-pointer API

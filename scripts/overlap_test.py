@@ -5,6 +5,8 @@ import numpy as np, torch
 import lzfse_rust_amd as lz
 dev = torch.device('cuda', 0)
 NW = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+STAG = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
+os.environ['LZFSE_MI_NO_SPLIT'] = '1'
 ctxs = [lz.Context(0) for _ in range(NW)]
 g = os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden', 'snappy')
 fs = sorted(glob.glob(g + '/*.lzfse'))
@@ -40,7 +42,9 @@ def run(parts, what):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ths = [threading.Thread(target=work, args=(ctxs[i], parts[i])) for i in range(len(parts))]
-        for t in ths: t.start()
+        for t in ths:
+            t.start()
+            if STAG: time.sleep(STAG)
         for t in ths: t.join()
         torch.cuda.synchronize()
         best = min(best, time.perf_counter() - t0)
