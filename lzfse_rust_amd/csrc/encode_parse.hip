@@ -337,32 +337,60 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
     bool walking = false, done = false;
     while (!done && !x.status) {
         if (!walking) {
-            // following mode: the sync records of the next 64 boundaries are fetched by the 64 lanes at once and
-            // consumed from registers, so the serial hand-over chain costs no memory round trip per boundary
+            // Following mode, 64 boundaries per step (one per lane). With a = first not yet adopted event of the log
+            // being followed, a boundary synced at (i, j) hands over at i_eff = max(i, a - 1) and leaves
+            // a' = j + (i_eff - i) + 1 = max(j + 1, a + (j - i)): a max-plus map (A, B) = (j + 1, j - i). Such maps
+            // compose associatively, (A1, B1) then (A2, B2) = (max(A2, A1 + B2), B1 + B2), so the serial hand-over
+            // chain is a wave prefix scan and every lane writes its own range record.
             const int lane = e_lane();
-            const uint32_t kb = k;
+            const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;
             uint4 sy_l = make_uint4(0, 0, 0, 0);
-            if (kb + lane + 1 < K) sy_l = sync[es.seg_base + kb + lane];  // enc_sync_kernel: (found, i, j)
-            for (int l = 0; l < 64 && !walking && !x.status; l++) {
-                const uint32_t found = e_readlane(sy_l.x, l);
-                if (found) {
-                    const uint32_t i = e_readlane(sy_l.y, l), j = e_readlane(sy_l.z, l);
-                    // logs run in lock-step from (i, j) on; hand over no earlier than event a - 1
-                    uint32_t i_eff = (a > 0 && i + 1 < a) ? a - 1 : i;
-                    uint32_t j_eff = j + (i_eff - i);
-                    if (i_eff >= a) sx_add_range(x, 0, (uint64_t)(es.seg_base + k) * SEG_EV_CAP + a, i_eff - a + 1);
-                    k = k + 1;
-                    a = j_eff + 1;
-                    st_syncs++;
-                } else {
-                    // adopt the rest of log k and continue from its final state
-                    const SpecHeader hk = H0[k];
-                    if (hk.n_events > a) sx_add_range(x, 0, (uint64_t)(es.seg_base + k) * SEG_EV_CAP + a, hk.n_events - a);
-                    T.index = hk.f_index; T.lit = hk.f_lit; T.p_idx = hk.f_pidx; T.p_midx = hk.f_pmidx; T.p_len = hk.f_plen;
-                    walking = true;
-                    st_fallbacks++;
-                    x.gap_open = x.n_gaps;
+            if (k + lane + 1 < K) sy_l = sync[es.seg_base + k + lane];  // enc_sync_kernel: (found, i, j)
+            const uint64_t nf = __ballot(sy_l.x == 0);
+            const int nb = nf ? __builtin_ctzll(nf) : 64;  // boundaries before the first one without a sync point
+            if (nb > 0) {
+                const bool act = lane < nb;
+                const int32_t ii = (int32_t)sy_l.y, jj = (int32_t)sy_l.z;
+                int32_t A = act ? jj + 1 : INT32_MIN / 2, B = act ? jj - ii : 0;
+#pragma unroll
+                for (int dd = 1; dd < 64; dd <<= 1) {
+                    const int32_t Al = __shfl_up(A, dd), Bl = __shfl_up(B, dd);
+                    if (lane >= dd) { const int32_t t = Al + B; A = A > t ? A : t; B = Bl + B; }
                 }
+                const int32_t a0 = (int32_t)a;
+                const int32_t a_out = A > a0 + B ? A : a0 + B;
+                const int32_t a_prev = __shfl_up(a_out, 1);
+                const int32_t a_in = lane ? a_prev : a0;
+                const int32_t i_eff = (a_in > 0 && ii + 1 < a_in) ? a_in - 1 : ii;
+                const uint32_t cnt = (act && i_eff >= a_in) ? (uint32_t)(i_eff - a_in + 1) : 0u;
+                uint32_t inc = cnt;
+#pragma unroll
+                for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t t = __shfl_up(inc, dd); if (lane >= dd) inc += t; }
+                const uint64_t hm = __ballot(cnt != 0);
+                const uint32_t n_new = (uint32_t)__popcll(hm), total = e_readlane(inc, 63);
+                if (x.n_ranges + n_new > x.range_cap) x.status = LZFSE_MI_IO;
+                else {
+                    if (cnt) {
+                        RangeRec r;
+                        r.begin = (uint64_t)(es.seg_base + k + lane) * SEG_EV_CAP + (uint32_t)a_in;
+                        r.count = cnt; r.out_off = x.out_count + inc - cnt; r.kind = 0;
+                        x.ranges[x.n_ranges + (uint32_t)__popcll(hm & lt)] = r;
+                    }
+                    x.n_ranges += n_new;
+                    x.out_count += total;
+                    a = e_readlane((uint32_t)a_out, nb - 1);
+                    k += (uint32_t)nb;
+                    st_syncs += (uint32_t)nb;
+                }
+            }
+            if (nb < 64 && !x.status) {
+                // no sync point at boundary k: adopt the rest of log k and continue from its final state
+                const SpecHeader hk = H0[k];
+                if (hk.n_events > a) sx_add_range(x, 0, (uint64_t)(es.seg_base + k) * SEG_EV_CAP + a, hk.n_events - a);
+                T.index = hk.f_index; T.lit = hk.f_lit; T.p_idx = hk.f_pidx; T.p_midx = hk.f_pmidx; T.p_len = hk.f_plen;
+                walking = true;
+                st_fallbacks++;
+                x.gap_open = x.n_gaps;
             }
             continue;
         }
@@ -567,7 +595,8 @@ struct Emit {  // serial LMD emitter used for the (rare) events that straddle a 
 
 __device__ __forceinline__ void em_put(Emit &w, uint32_t l, uint32_t m, uint32_t d) {
     if (w.lmd_count >= w.lmd_cap) { w.status = LZFSE_MI_IO; return; }
-    w.lmds[w.lmd_count++] = make_uint2(l | (m << 16), d);
+    if (e_lane() == 0) w.lmds[w.lmd_count] = make_uint2(l | (m << 16), d);
+    w.lmd_count++;
     w.n_lmd++;
 }
 __device__ __forceinline__ void em_push_l(Emit &w, uint32_t l) { w.prev_d = 1; em_put(w, l, 0, 1); }
@@ -603,14 +632,17 @@ __device__ bool em_buffer_push(Emit &w, uint32_t &n_lit, uint32_t &match_len, ui
     return true;
 }
 
-// One thread per stream cuts the event list into bvx2 blocks, using the stream-wide inclusive prefix
-// sums of per-event LMD and literal counts (enc_compact / enc_rscan / enc_papply).
+// One wave per stream cuts the event list into bvx2 blocks, using the stream-wide inclusive prefix sums of
+// per-event LMD and literal counts (enc_compact / enc_rscan / enc_papply). Blocks follow each other serially (a
+// block starts where the previous one ended, remainder of the boundary event included); all values are
+// wave-uniform, the lanes only share the search for the last event that fits (64 probes per step).
 __global__ __launch_bounds__(SEGM_THREADS) void enc_segment_kernel(const EncStream *__restrict__ streams, uint32_t n_streams,
                                                                   const MatchRec *__restrict__ matches, const uint32_t *__restrict__ pc,
                                                                   const uint32_t *__restrict__ pl, uint2 *__restrict__ lmds,
                                                                   EncBlock *__restrict__ blocks, EncStreamOut *__restrict__ outs) {
-    const uint32_t si = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t si = blockIdx.x;
     if (si >= n_streams) return;
+    const int lane = e_lane();
     const EncStream &es = streams[si];
     EncStreamOut so = outs[si];
     if (so.status) return;
@@ -641,10 +673,20 @@ __global__ __launch_bounds__(SEGM_THREADS) void enc_segment_kernel(const EncStre
             // events [j, j2) fit completely: n_lmd + sum c <= 10 000 and n_lit + sum l <= 40 000
             const uint32_t base_c = j ? PC[j - 1] : 0, base_l = j ? PL[j - 1] : 0;
             const uint32_t room_c = LMDS_PER_BLOCK - w.n_lmd, room_l = LITERALS_PER_BLOCK - w.n_lit;
-            uint32_t lo = j, hi = E;  // first event that does NOT fit
+            // first event that does NOT fit: in [j, hi] with hi <= j + 10 001 (every event has at least one LMD);
+            // fits(e) is monotone, 64 probes per step narrow [lo, hi] by a factor of 65
+            uint32_t lo = j, hi = E - j > LMDS_PER_BLOCK + 1 ? j + LMDS_PER_BLOCK + 1 : E;
             while (lo < hi) {
-                uint32_t mid = (lo + hi) >> 1;
-                if (PC[mid] - base_c <= room_c && PL[mid] - base_l <= room_l) lo = mid + 1; else hi = mid;
+                const uint32_t span = hi - lo, stp = span / 65 + 1;
+                const uint32_t e = lo + stp * (uint32_t)lane + (stp - 1);  // probes lo+stp-1, lo+2stp-1, ...
+                const bool in = e < hi;
+                const bool fits = in && PC[e] - base_c <= room_c && PL[e] - base_l <= room_l;
+                const uint64_t fm = __ballot(fits), im = __ballot(in);
+                const uint32_t nfit = (uint32_t)__popcll(fm);  // monotone: the fitting probes are the first nfit
+                // all events up to probe nfit-1 fit; probe nfit (if any) does not
+                const uint32_t new_lo = lo + stp * nfit;
+                const uint32_t new_hi = nfit < (uint32_t)__popcll(im) ? lo + stp * nfit + (stp - 1) : hi;
+                lo = new_lo; hi = new_hi;
             }
             const uint32_t j2 = lo;
             ev_end = j2;
@@ -680,13 +722,14 @@ __global__ __launch_bounds__(SEGM_THREADS) void enc_segment_kernel(const EncStre
         b.n_lmd = w.n_lmd; b.n_lit = w.n_lit; b.n_match = w.n_match;
         b.hdr_len = 0; b.lit_len = 0; b.lmd_len = 0; b.pad = 0;
         b.ev_begin = ev_begin; b.ev_end = ev_end; b.head_lmds = head_lmds; b.head_prev_d = head_prev_d;
-        bk[n_blk++] = b;
+        if (lane == 0) bk[n_blk] = b;
+        n_blk++;
         stage_used += need;
         raw_pos += w.n_lit + w.n_match;
     }
     so.n_blocks = n_blk;
     so.status = w.status;
-    outs[si] = so;
+    if (lane == 0) outs[si] = so;
 }
 
 // ------------------------------------------------------------------------------------ LMD writing
@@ -755,7 +798,7 @@ void launch_enc_compact(const EncStream *streams, const uint32_t *slot_stream, u
 }
 void launch_enc_segment(const EncStream *streams, uint32_t ns, const MatchRec *matches, const uint32_t *pc, const uint32_t *pl,
                         uint2 *lmds, EncBlock *blocks, EncStreamOut *outs, hipStream_t st) {
-    hipLaunchKernelGGL(enc_segment_kernel, dim3((ns + SEGM_THREADS - 1) / SEGM_THREADS), dim3(SEGM_THREADS), 0, st, streams, ns, matches,
+    hipLaunchKernelGGL(enc_segment_kernel, dim3(ns), dim3(SEGM_THREADS), 0, st, streams, ns, matches,
                        pc, pl, lmds, blocks, outs);
 }
 void launch_enc_lmd(const EncStream *streams, const uint32_t *slot_stream, uint32_t n_slots, const EncStreamOut *outs,
