@@ -38,7 +38,8 @@ namespace lzmi {
 // or the LDS last-seen entry written by earlier steps.
 __global__ __launch_bounds__(64) void enc_chain_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
                                                        const EncTile *__restrict__ tiles, uint32_t n_tiles,
-                                                       uint2 *__restrict__ prev, uint32_t *__restrict__ summary) {
+                                                       uint2 *__restrict__ prev, uint32_t *__restrict__ summary,
+                                                       uint32_t *__restrict__ flist, uint32_t *__restrict__ fcount) {
     __shared__ uint16_t last[1u << HASH_BITS];  // offset in tile + 1, 0 = none
     const uint32_t t = blockIdx.x;
     if (t >= n_tiles) return;
@@ -51,6 +52,8 @@ __global__ __launch_bounds__(64) void enc_chain_kernel(const uint8_t *__restrict
     const uint32_t n_pos = st.n - 3;  // positions 0 .. n-4 are hashed (frontend_bytes.rs:166-170)
     const uint32_t t_end = tl.start + TILE_POS < n_pos ? tl.start + TILE_POS : n_pos;
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    uint32_t *fl = flist + (uint64_t)t * (1u << HASH_BITS);
+    uint32_t n_first = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // 16 steps (1024 positions) per batch: the source values of a batch are loaded together, so the wave
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(64) void enc_chain_kernel(const uint8_t *__restrict
 #pragma unroll
         for (int j = 0; j < CH_STEPS; j++) {
             const uint32_t p0 = pb + 64 * j;
-            if (p0 >= t_end) break;
+            if (p0 >= t_end) continue;  // (not break: the loop must stay fully unrolled, vv[] lives in registers)
             const uint32_t p = p0 + lane;
             const bool valid = p < t_end;
             const uint32_t v = vv[j];
@@ -92,11 +95,21 @@ __global__ __launch_bounds__(64) void enc_chain_kernel(const uint8_t *__restrict
                 if (lower) pr = p0 + (63 - __builtin_clzll(lower));
                 if (valid && (same >> lane) >> 1 == 0) last[key] = (uint16_t)mine;  // newest of its bucket wins
             }
+            // first occurrence of its bucket in the tile: the link into earlier tiles is made by enc_link_kernel
+            // from this list (offset | bucket << 16); the first tile of a stream has nothing before it
+            const bool first = valid && pr == NONE_TILE;
+            if (tl.start == 0) { if (first) pr = NONE; }
+            else {
+                const uint64_t fm = __ballot(first);
+                if (first) fl[n_first + (uint32_t)__popcll(fm & lt_mask)] = (p - tl.start) | (key << 16);
+                n_first += (uint32_t)__popcll(fm);
+            }
             if (valid) pv[p] = make_uint2(pr, v);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
     }
+    if (lane == 0) fcount[t] = n_first;
     uint32_t *sm = summary + (uint64_t)t * (1u << HASH_BITS);
     for (uint32_t k = lane; k < (1u << HASH_BITS); k += 64) {
         uint32_t o = last[k];
@@ -104,29 +117,26 @@ __global__ __launch_bounds__(64) void enc_chain_kernel(const uint8_t *__restrict
     }
 }
 
-// Cross-tile links: a bucket's first occurrence in a tile points at the newest occurrence in an
-// earlier tile of the same stream. Anything further back than 5 tiles is outside the
+// Cross-tile links: a bucket's first occurrence in a tile (listed by enc_chain_kernel) points at the newest
+// occurrence in an earlier tile of the same stream. Anything further back than 5 tiles is outside the
 // 262 139-byte window (fse/constants.rs:42) and would end the candidate scan anyway.
-__global__ void enc_link_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
-                                const EncTile *__restrict__ tiles, uint32_t n_tiles, uint2 *__restrict__ prev,
-                                const uint32_t *__restrict__ summary) {
+__global__ void enc_link_kernel(const EncStream *__restrict__ streams, const EncTile *__restrict__ tiles, uint32_t n_tiles,
+                                uint2 *__restrict__ prev, const uint32_t *__restrict__ summary,
+                                const uint32_t *__restrict__ flist, const uint32_t *__restrict__ fcount) {
     const uint32_t t = blockIdx.y;
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= fcount[t]) return;
     const EncTile tl = tiles[t];
     const EncStream st = streams[tl.stream];
-    const uint32_t p = tl.start + blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t n_pos = st.n - 3;
-    if (p >= n_pos || p >= tl.start + TILE_POS) return;
-    uint2 *pv = prev + st.pos_base;
-    const uint2 cur = pv[p];
-    if (cur.x != NONE_TILE) return;
-    const uint32_t key = bucket_of(cur.y);
+    const uint32_t ent = flist[(uint64_t)t * (1u << HASH_BITS) + e];
+    const uint32_t p = tl.start + (ent & 0xFFFF), key = ent >> 16;
     uint32_t r = NONE;
     const uint32_t t_idx = tl.start / TILE_POS;  // tile index inside the stream
     for (uint32_t back = 1; back <= 5 && back <= t_idx; back++) {
         uint32_t sv = summary[(uint64_t)(t - back) * (1u << HASH_BITS) + key];
         if (sv != NONE) { r = sv; break; }
     }
-    pv[p].x = r;
+    prev[st.pos_base + p].x = r;
 }
 
 // ------------------------------------------------------------------------------------ candidates
@@ -1420,7 +1430,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     if (nt > 65535) return LZFSE_MI_UNSUPPORTED;  // grid.y limit of the per-tile kernels (4 GiB per call)
 
     if (!eb_ensure(S, EB_STREAMS, ns * sizeof(EncStream)) || !eb_ensure(S, EB_TILES, nt * sizeof(EncTile)) ||
-        !eb_ensure(S, EB_PREV, pos_total * 8) || !eb_ensure(S, EB_SUMMARY, (size_t)nt * (1u << HASH_BITS) * 4) ||
+        !eb_ensure(S, EB_PREV, pos_total * 8) || !eb_ensure(S, EB_SUMMARY, (size_t)nt * ((2u << HASH_BITS) + 1) * 4) ||
         !eb_ensure(S, EB_REC, pos_total * 8) || !eb_ensure(S, EB_LMDS, lmd_total * 8) ||
         !eb_ensure(S, EB_BLOCKS, (size_t)blk_total * sizeof(EncBlock)) || !eb_ensure(S, EB_OUTS, ns * sizeof(EncStreamOut)) ||
         !eb_ensure(S, EB_STAGE, stage_total + 256) || !eb_ensure(S, EB_SLOTS, (size_t)blk_total * 4) ||
@@ -1438,6 +1448,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     EncTile *d_tiles = (EncTile *)S.bufs[EB_TILES];
     uint2 *d_prev = (uint2 *)S.bufs[EB_PREV];
     uint32_t *d_summary = (uint32_t *)S.bufs[EB_SUMMARY];
+    uint32_t *d_flist = d_summary + (size_t)nt * (1u << HASH_BITS), *d_fcount = d_flist + (size_t)nt * (1u << HASH_BITS);
     uint2 *d_rec = (uint2 *)S.bufs[EB_REC];
     uint2 *d_lmds = (uint2 *)S.bufs[EB_LMDS];
     EncBlock *d_blocks = (EncBlock *)S.bufs[EB_BLOCKS];
@@ -1452,11 +1463,11 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     E_TRY(hipMemsetAsync(d_bitmap, 0, pos_total / 8 + 64, stq));
     {
         StageTimer t(c, "enc_chain");
-        hipLaunchKernelGGL(enc_chain_kernel, dim3(nt), dim3(64), 0, stq, d_src, d_streams, d_tiles, nt, d_prev, d_summary);
+        hipLaunchKernelGGL(enc_chain_kernel, dim3(nt), dim3(64), 0, stq, d_src, d_streams, d_tiles, nt, d_prev, d_summary, d_flist, d_fcount);
     }
     {
         StageTimer t(c, "enc_link");
-        hipLaunchKernelGGL(enc_link_kernel, dim3((TILE_POS + 255) / 256, nt), dim3(256), 0, stq, d_src, d_streams, d_tiles, nt, d_prev, d_summary);
+        hipLaunchKernelGGL(enc_link_kernel, dim3((1u << HASH_BITS) / 256, nt), dim3(256), 0, stq, d_streams, d_tiles, nt, d_prev, d_summary, d_flist, d_fcount);
     }
     {
         StageTimer t(c, "enc_cand");
@@ -1550,17 +1561,19 @@ extern "C" int lzfse_mi_debug_candidates(lzfse_mi_ctx *c, const uint8_t *h_src, 
     uint32_t nt = (uint32_t)ht.size();
     size_t padn = (n + 255) & ~(size_t)255;
     if (!eb_ensure(S, EB_STREAMS, sizeof(EncStream)) || !eb_ensure(S, EB_TILES, nt * sizeof(EncTile)) ||
-        !eb_ensure(S, EB_PREV, padn * 8) || !eb_ensure(S, EB_SUMMARY, (size_t)nt * (1u << HASH_BITS) * 4) ||
+        !eb_ensure(S, EB_PREV, padn * 8) || !eb_ensure(S, EB_SUMMARY, (size_t)nt * ((2u << HASH_BITS) + 1) * 4) ||
         !eb_ensure(S, EB_REC, padn * 8) || !eb_ensure(S, EB_STAGE, padn + 256) || !eb_ensure(S, EB_BITMAP, padn / 8 + 64))
         return LZFSE_MI_IO;
     uint8_t *d_src = (uint8_t *)S.bufs[EB_STAGE];
     E_TRY(hipMemcpyAsync(d_src, h_src, n, hipMemcpyHostToDevice, stq));
     E_TRY(hipMemcpyAsync(S.bufs[EB_STREAMS], &e, sizeof e, hipMemcpyHostToDevice, stq));
     E_TRY(hipMemcpyAsync(S.bufs[EB_TILES], ht.data(), nt * sizeof(EncTile), hipMemcpyHostToDevice, stq));
+    uint32_t *dbg_summary = (uint32_t *)S.bufs[EB_SUMMARY];
+    uint32_t *dbg_flist = dbg_summary + (size_t)nt * (1u << HASH_BITS), *dbg_fcount = dbg_flist + (size_t)nt * (1u << HASH_BITS);
     hipLaunchKernelGGL(enc_chain_kernel, dim3(nt), dim3(64), 0, stq, d_src, (EncStream *)S.bufs[EB_STREAMS], (EncTile *)S.bufs[EB_TILES], nt,
-                       (uint2 *)S.bufs[EB_PREV], (uint32_t *)S.bufs[EB_SUMMARY]);
-    hipLaunchKernelGGL(enc_link_kernel, dim3((TILE_POS + 255) / 256, nt), dim3(256), 0, stq, d_src, (EncStream *)S.bufs[EB_STREAMS],
-                       (EncTile *)S.bufs[EB_TILES], nt, (uint2 *)S.bufs[EB_PREV], (uint32_t *)S.bufs[EB_SUMMARY]);
+                       (uint2 *)S.bufs[EB_PREV], dbg_summary, dbg_flist, dbg_fcount);
+    hipLaunchKernelGGL(enc_link_kernel, dim3((1u << HASH_BITS) / 256, nt), dim3(256), 0, stq, (EncStream *)S.bufs[EB_STREAMS],
+                       (EncTile *)S.bufs[EB_TILES], nt, (uint2 *)S.bufs[EB_PREV], dbg_summary, dbg_flist, dbg_fcount);
     hipLaunchKernelGGL(enc_cand_kernel, dim3(((nt + 7) / 8) * 8 * CAND_BPT), dim3(256), 0, stq, d_src, (EncStream *)S.bufs[EB_STREAMS],
                        (EncTile *)S.bufs[EB_TILES], nt, (uint2 *)S.bufs[EB_PREV], (uint2 *)S.bufs[EB_REC], (uint64_t *)S.bufs[EB_BITMAP], 0);
     E_TRY(hipMemcpyAsync(h_prev, S.bufs[EB_PREV], (n - 3) * 8, hipMemcpyDeviceToHost, stq));  // {prev, value} pairs
