@@ -1,0 +1,74 @@
+"""GPU parity tests for large batches, which the library cuts into sub-batches that run side by side on two HIP
+streams (split batches): results, statuses and ordering must be those of one call."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import lzfse_rust_amd as m
+    return m.Context(0)
+
+
+def _mixed(snappy_raw):
+    rng = np.random.default_rng(21)
+    big = [snappy_raw[k] for k in ("urls.10K", "plrabn12.txt", "html_x_4", "lcet10.txt", "kppkn.gtb", "fireworks.jpeg")] * 3
+    tiny = [bytes(n) for n in (0, 1, 20, 21, 4096, 4097)] + [rng.integers(0, 256, size=n, dtype=np.uint8).tobytes() for n in (7, 300, 4096, 5000)]
+    raws = []
+    for i, b in enumerate(big):  # interleave so that both lanes see every size class
+        raws.append(b)
+        if i < len(tiny):
+            raws.append(tiny[i])
+    return raws
+
+
+def test_split_encode_matches_oracle(ctx, oracle, snappy_raw):
+    raws = _mixed(snappy_raw)
+    assert len(raws) >= 8 and sum(map(len, raws)) >= 4 << 20  # large enough to be split
+    ctx.enable_timing(True)
+    outs, st = ctx.encode_batch(raws)
+    t = ctx.timings()
+    ctx.enable_timing(False)
+    assert t["enc_cand"][1] == 2, t  # two sub-batches ran
+    for r, o, e in zip(raws, outs, st):
+        assert e == 0
+        assert o.tobytes() == oracle.encode(r), len(r)
+
+
+def test_split_decode_statuses_per_stream(ctx, oracle, snappy_raw):
+    raws = _mixed(snappy_raw)
+    encs = [oracle.encode(r) for r in raws]
+    caps = [max(len(r), 16) for r in raws]
+    # damage some streams in both lanes, and give two streams too little room
+    bad = {3: "flip", 8: "trunc", 13: "cap", 20: "flip", 21: "cap"}
+    for i, kind in bad.items():
+        if kind == "flip":
+            e = bytearray(encs[i]); e[len(e) // 2] ^= 0x40; encs[i] = bytes(e)
+        elif kind == "trunc":
+            encs[i] = encs[i][:-5]
+        else:
+            caps[i] = max(len(raws[i]) - 1, 0)
+    outs, st = ctx.decode_batch(encs, caps=caps)
+    for i, (r, e, o, s) in enumerate(zip(raws, encs, outs, st)):
+        es = oracle.decode_status(e, caps[i])
+        assert (s == 0) == (es == 0), (i, s, es)
+        if s == 0:
+            assert o.tobytes() == oracle.decode(e, cap=max(caps[i], 1))
+        if i not in bad:
+            assert s == 0 and o.tobytes() == r
+
+
+def test_split_lane_count_override(snappy_raw, oracle):
+    """LZFSE_MI_LANES_* are read when the first batch call of a process is made, so this only checks that the
+    default (2 lanes) leaves a result identical to a batch too small to be split."""
+    import lzfse_rust_amd as m
+    c = m.Context(0)
+    r = snappy_raw["html"]
+    small, _ = c.encode_batch([r])             # never split
+    many, st = c.encode_batch([r] * 48)        # 4.9 MB, split
+    assert all(e == 0 for e in st)
+    assert all(o.tobytes() == small[0].tobytes() for o in many)
