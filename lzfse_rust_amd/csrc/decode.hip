@@ -727,22 +727,29 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
                         else t[mq + k] = dst[(int64_t)tile_base + sp];
                     }
                 }
+                // a thread owns bytes tid, tid + NT, ...: one bit per owned byte that still has to jump (its origin
+                // is not a final byte yet). Final bytes, most of the tile, drop out of the rounds.
+                static_assert(TILE / NT <= 32, "one mask bit per owned byte");
+                __syncthreads();
+                uint32_t um = 0;
+                for (uint32_t k = 0, b = tid; b < tile_len; k++, b += NT)
+                    if (s_org[b] != b) um |= 1u << k;
+                const uint32_t dm = um;
                 for (;;) {
-                    __syncthreads();
                     bool changed = false;
-                    for (uint32_t b = tid; b < tile_len; b += NT) {
+                    for (uint32_t m2 = um; m2; m2 &= m2 - 1) {
+                        const uint32_t k = (uint32_t)__builtin_ctz(m2), b = tid + k * NT;
                         const uint32_t o = s_org[b];
-                        if (o == b) continue;
                         const uint32_t o1 = s_org[o];
-                        if (o1 == o) continue;
+                        if (o1 == o) { um &= ~(1u << k); continue; }
                         s_org[b] = s_org[s_org[o1]];
                         changed = true;
                     }
                     if (!__syncthreads_or(changed)) break;
                 }
-                for (uint32_t b = tid; b < tile_len; b += NT) {
-                    const uint32_t o = s_org[b];
-                    if (o != b) t[b] = t[o];
+                for (uint32_t m2 = dm; m2; m2 &= m2 - 1) {
+                    const uint32_t b = tid + (uint32_t)__builtin_ctz(m2) * NT;
+                    t[b] = t[s_org[b]];
                 }
             }
             __syncthreads();
@@ -943,6 +950,12 @@ void launch_dec_lz(int variant, const uint8_t *src, const StreamIn *streams, con
                            blocks, bres, lmds, lits, dst, sres);
     else if (variant == 2)
         hipLaunchKernelGGL((dec_lz_kernel<512, 8192>), dim3(n_streams), dim3(512), 0, st, src, streams, plan,
+                           blocks, bres, lmds, lits, dst, sres);
+    else if (variant == 4)
+        hipLaunchKernelGGL((dec_lz_kernel<1024, 16384>), dim3(n_streams), dim3(1024), 0, st, src, streams, plan,
+                           blocks, bres, lmds, lits, dst, sres);
+    else if (variant == 5)
+        hipLaunchKernelGGL((dec_lz_kernel<1024, 24576>), dim3(n_streams), dim3(1024), 0, st, src, streams, plan,
                            blocks, bres, lmds, lits, dst, sres);
     else if (variant == 3)
         hipLaunchKernelGGL((dec_lz_kernel<512, 16384>), dim3(n_streams), dim3(512), 0, st, src, streams, plan,
