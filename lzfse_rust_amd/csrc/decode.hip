@@ -554,6 +554,7 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
     __shared__ uint32_t s_d[NT];
     __shared__ uint32_t s_lit[NT];   // literal offset inside the block's literal buffer
     __shared__ uint16_t s_org[TILE];  // per-byte origin inside the tile (pointer jumping)
+    __shared__ uint32_t s_dm[NT];     // bit k of s_dm[x]: tile byte x + k * NT is produced by an in-tile match
     __shared__ uint32_t s_long[2 * NT];
     __shared__ uint32_t s_scan[2 * NW + 2];
     __shared__ uint32_t s_cnt[4];
@@ -700,15 +701,21 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
             const uint32_t mo = ex_s + l;                              // tile offset of the match
             const int64_t so = (int64_t)mo - (int64_t)dd;              // tile offset of its source (may be < 0)
             if (tot_dep) {
-                for (uint32_t b = tid; b < tile_len; b += NT) s_org[b] = (uint16_t)b;
+                // s_dm: one bit per tile byte that is produced by an in-tile match (its origin s_org[] is meaningful);
+                // thread x owns bytes x, x + NT, ... and finds their bits in s_dm[x], so it needs no sweep over the
+                // tile to know which of its bytes still have to jump. Bytes without a bit are final.
+                static_assert(TILE / NT <= 32 && (NT & (NT - 1)) == 0, "one mask bit per owned byte");
+                constexpr uint32_t NTS = 31 - __builtin_clz((unsigned)NT);
+                s_dm[tid] = 0;
                 if (tid == 0) s_cnt[3] = 0;
                 __syncthreads();
                 if (dep) {
                     if (m <= SHORT_COPY) {
                         for (uint32_t k = 0; k < m; k++) {
                             const int64_t sp = so + k;
-                            if (sp >= 0) s_org[mo + k] = (uint16_t)sp;
-                            else t[mo + k] = dst[(int64_t)tile_base + sp];   // finished output of earlier tiles
+                            const uint32_t q = mo + k;
+                            if (sp >= 0) { s_org[q] = (uint16_t)sp; atomicOr(&s_dm[q & (NT - 1)], 1u << (q >> NTS)); }
+                            else t[q] = dst[(int64_t)tile_base + sp];   // finished output of earlier tiles
                         }
                     } else {
                         s_long[atomicAdd(&s_cnt[3], 1u)] = tid;
@@ -723,33 +730,28 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
                     const int64_t sq = (int64_t)mq - (int64_t)ddq;
                     for (uint32_t k = lane; k < mm; k += 64) {
                         const int64_t sp = sq + k;
-                        if (sp >= 0) s_org[mq + k] = (uint16_t)sp;
-                        else t[mq + k] = dst[(int64_t)tile_base + sp];
+                        const uint32_t qq = mq + k;
+                        if (sp >= 0) { s_org[qq] = (uint16_t)sp; atomicOr(&s_dm[qq & (NT - 1)], 1u << (qq >> NTS)); }
+                        else t[qq] = dst[(int64_t)tile_base + sp];
                     }
                 }
-                // a thread owns bytes tid, tid + NT, ...: one bit per owned byte that still has to jump (its origin
-                // is not a final byte yet). Final bytes, most of the tile, drop out of the rounds.
-                static_assert(TILE / NT <= 32, "one mask bit per owned byte");
                 __syncthreads();
-                uint32_t um = 0;
-                for (uint32_t k = 0, b = tid; b < tile_len; k++, b += NT)
-                    if (s_org[b] != b) um |= 1u << k;
-                const uint32_t dm = um;
+                const uint32_t dm = s_dm[tid];
+                uint32_t um = dm;  // owned bytes whose origin is not known to be final yet
                 for (;;) {
-                    bool changed = false;
                     for (uint32_t m2 = um; m2; m2 &= m2 - 1) {
-                        const uint32_t k = (uint32_t)__builtin_ctz(m2), b = tid + k * NT;
+                        const uint32_t k = (uint32_t)__builtin_ctz(m2), b = tid + (k << NTS);
                         const uint32_t o = s_org[b];
+                        if (!((s_dm[o & (NT - 1)] >> (o >> NTS)) & 1u)) { um &= ~(1u << k); continue; }
                         const uint32_t o1 = s_org[o];
-                        if (o1 == o) { um &= ~(1u << k); continue; }
-                        s_org[b] = s_org[s_org[o1]];
-                        changed = true;
+                        if (!((s_dm[o1 & (NT - 1)] >> (o1 >> NTS)) & 1u)) { s_org[b] = (uint16_t)o1; um &= ~(1u << k); continue; }
+                        s_org[b] = s_org[o1];
                     }
-                    if (!__syncthreads_or(changed)) break;
+                    if (!__syncthreads_or(um != 0)) break;
                 }
                 for (uint32_t m2 = dm; m2; m2 &= m2 - 1) {
-                    const uint32_t b = tid + (uint32_t)__builtin_ctz(m2) * NT;
-                    t[b] = t[s_org[b]];
+                    const uint32_t b2 = tid + ((uint32_t)__builtin_ctz(m2) << NTS);
+                    t[b2] = t[s_org[b2]];
                 }
             }
             __syncthreads();
