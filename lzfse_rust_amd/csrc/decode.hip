@@ -371,7 +371,6 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
         int e = bw_init(w, p + lit_off, h.lit_payload + 8, h.lit_bits, glo, ghi, ring[1]);
         const int q4 = lane & 3;
         uint32_t state = q4 == 0 ? h.lit_state[0] : q4 == 1 ? h.lit_state[1] : q4 == 2 ? h.lit_state[2] : h.lit_state[3];
-        uint32_t rec = 0;
         uint8_t *out = lit_out + d.lit_base;
         const uint32_t n_groups = e ? 0u : h.lit_num >> 2;
         uint64_t win = bw_window(w);
@@ -390,12 +389,7 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
             word |= dpp_shr<2>(word);  // lane 3 holds the four symbols
             bw_advance(w, read_lane(pre, 3));
             win = bw_window(w);
-            word = read_lane(word, 3);
-            if (lane == (int)(g & 63)) rec = word;
-            if ((g & 63) == 63) ((uint32_t *)out)[(g & ~63u) + lane] = rec;
-        }
-        if (n_groups & 63) {
-            if (lane < (int)(n_groups & 63)) ((uint32_t *)out)[(n_groups & ~63u) + lane] = rec;
+            if (lane == 3) ((uint32_t *)out)[g] = word;  // one 4-byte store per group of four literals
         }
         if (!e) e = bw_finalize(w);
         uint32_t s0 = read_lane(state, 0) | read_lane(state, 1) | read_lane(state, 2) | read_lane(state, 3);
@@ -409,7 +403,6 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
         uint32_t state = li == 0 ? h.lmd_state[0] : li == 1 ? h.lmd_state[1] : h.lmd_state[2];
         const uint32_t tbase = li == 0 ? 0u : (li == 1 ? 64u : 128u);
         const uint32_t smask = li == 2 ? 255u : 63u;
-        uint2 rec = make_uint2(0, 0);
         LmdRec *out = lmd_out + d.lmd_base;
         uint32_t acc_sum = 0;   // lane 0: sum of L, lane 1: sum of M
         uint32_t prev_d = 0;    // lane 2
@@ -422,9 +415,10 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
             uint32_t pre = k + vb;
             pre += dpp_shr<1>(pre);
             pre += dpp_shr<2>(pre);
-            const uint64_t x = win >> ((64 - pre) & 63);  // pre == 0 only when k = vb = 0 below
-            const uint32_t extra = (uint32_t)x & ((1u << vb) - 1u);
-            const uint32_t sb = (uint32_t)(x >> vb) & ((1u << k) - 1u);
+            // a lane's field (state bits above value bits) is at most 10 + 15 bits: one 64-bit shift, two 32-bit extracts
+            const uint32_t x = (uint32_t)(win >> ((64 - pre) & 63));  // pre == 0 only when k = vb = 0 below
+            const uint32_t extra = x & ((1u << vb) - 1u);
+            const uint32_t sb = (x >> vb) & ((1u << k) - 1u);
             state = (uint32_t)((int32_t)sb + delta) & smask;
             const uint32_t val = ent.y + extra;
             bw_advance(w, read_lane(pre, 2));
@@ -432,12 +426,7 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
             acc_sum += val;
             if (val != 0) prev_d = val;                               // lane 2: lmd_type.rs:153-160
             const uint32_t lm = dpp_shr<2>(val) | (dpp_shr<1>(val) << 16);  // lane 2: l | m << 16
-            const uint32_t r0 = read_lane(lm, 2), r1 = read_lane(prev_d, 2);
-            if (lane == (int)(i & 63)) rec = make_uint2(r0, r1);
-            if ((i & 63) == 63) out[(i & ~63u) + lane] = rec;
-        }
-        if (n & 63) {
-            if (lane < (int)(n & 63)) out[(n & ~63u) + lane] = rec;
+            if (lane == 2) out[i] = make_uint2(lm, prev_d);           // one 8-byte store per LMD, nothing waits for it
         }
         if (!e) e = bw_finalize(w);
         const uint32_t sum_l = read_lane(acc_sum, 0), sum_m = read_lane(acc_sum, 1);
