@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--replicas", type=int, default=64, help="copies of the 12-file corpus per GPU")
-    ap.add_argument("--workload", default="snappy", choices=["snappy", "text64m", "chunks4m"])
+    ap.add_argument("--workload", default="snappy", choices=["snappy", "text64m", "chunks4m", "chunks1g"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -107,6 +107,16 @@ def main():
     elif args.workload == "text64m":
         batch_raw = [synth_text(64 << 20, seed=1 + rank)]
         workload = "64 MiB synthetic enwik-style text, ONE stream, encode+decode"
+    elif args.workload == "chunks1g":
+        # 1 GiB per GPU cut at 4 MiB = 256 independent streams. 16 copies of 64 MiB of
+        # synthetic text, each copy perturbed in one byte out of 251 so that copies do not match each other
+        base = np.frombuffer(synth_text(64 << 20, seed=1 + rank), dtype=np.uint8)
+        batch_raw = []
+        for c in range(16):
+            a = base.copy()
+            a[c % 251::251] ^= np.uint8(1 + c)
+            batch_raw += [a[i:i + (4 << 20)].tobytes() for i in range(0, a.size, 4 << 20)]
+        workload = "1 GiB synthetic text (16 perturbed copies of 64 MiB) cut into 256 independent 4 MiB streams, encode+decode"
     else:
         t = synth_text(256 << 20, seed=1 + rank)
         batch_raw = [t[i:i + (4 << 20)] for i in range(0, len(t), 4 << 20)]

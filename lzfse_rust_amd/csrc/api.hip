@@ -325,8 +325,19 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
     HIP_TRY(hipStreamSynchronize(st));
     std::vector<StreamPlan> h_plan(ns);
     uint64_t nb = 0, nl = 0, nu = 0, nj = 0;
-    int jump_mode = -1;  // -1: by stream size, 0: never, 1: always (diagnostics)
+    int jump_mode = -1;  // -1: by cost, 0: never, 1: always (diagnostics)
     if (const char *ev = getenv("LZFSE_MI_LZ_JUMP")) jump_mode = atoi(ev);
+    // Streams >= 2 MiB may take the pointer-jumping LZ path. One workgroup per stream copies ~0.6 GB/s whatever else
+    // runs, the jumping passes move ~25 GB/s over all eligible bytes together: jumping pays when the largest stream,
+    // not the batch, sets the time (one 64 MiB stream: yes; 128 streams of 4 MiB: no).
+    if (jump_mode < 0) {
+        uint64_t el_bytes = 0, el_max = 0;
+        for (uint32_t i = 0; i < ns; i++) {
+            if (h_walk[i].status || h_walk[i].raw_total > dst_cap[i] || h_walk[i].n_vxn != 0) continue;
+            if (h_walk[i].raw_total >= (2ull << 20)) { el_bytes += h_walk[i].raw_total; el_max = std::max<uint64_t>(el_max, h_walk[i].raw_total); }
+        }
+        if (el_max * 42 <= el_bytes) jump_mode = 0;
+    }
     for (uint32_t i = 0; i < ns; i++) {
         StreamPlan &p = h_plan[i];
         p.blk_base = nb; p.lmd_base = nl; p.lit_base = nu; p.n_blocks = h_walk[i].n_blocks; p.skip = 0;
