@@ -79,6 +79,8 @@ struct lzfse_mi_ctx {
     lzfse_mi_timings last{};
     // second lane of a split batch call: own stream, scratch and timers (created on first use)
     lzfse_mi_ctx *shadow[LZFSE_MI_MAX_LANES - 1] = {};
+    lzmi::LaneGate gates[LZFSE_MI_MAX_LANES - 1];            // owned by the main context
+    lzmi::LaneGate *gate_in = nullptr, *gate_out = nullptr;  // set per lane for the duration of a split encode
     hipEvent_t split_ev = nullptr;
     int last_split = 0;  // helper lanes used by the last batch call
 
@@ -107,6 +109,8 @@ StageTimer::~StageTimer() {
 }
 hipStream_t ctx_stream(lzfse_mi_ctx *c) { return c->stream; }
 EncScratch &ctx_enc(lzfse_mi_ctx *c) { return c->enc; }
+LaneGate *ctx_gate_in(lzfse_mi_ctx *c) { return c->gate_in; }
+LaneGate *ctx_gate_out(lzfse_mi_ctx *c) { return c->gate_out; }
 }  // namespace lzmi
 
 static void timing_begin(lzfse_mi_ctx *c) {
@@ -200,6 +204,7 @@ void lzfse_mi_destroy(lzfse_mi_ctx *c) {
     for (auto &s : c->shadow) { if (s) lzfse_mi_destroy(s); s = nullptr; }
     (void)hipSetDevice(c->device);
     if (c->split_ev) (void)hipEventDestroy(c->split_ev);
+    for (auto &g : c->gates) if (g.ev) (void)hipEventDestroy(g.ev);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->d_streams, &c->d_walk, &c->d_plan, &c->d_blocks, &c->d_bres, &c->d_sres,
                       &c->d_lmds, &c->d_lits, &c->d_origin, &c->d_jerr, &c->d_in, &c->d_out})
@@ -455,7 +460,7 @@ typedef int (*batch_dev_fn)(lzfse_mi_ctx *, size_t, const void *, const uint64_t
 // drive the others on shadow contexts (own stream and scratch each). Streams are independent, so the results are
 // those of one call. Measured best: 2 lanes in both directions (LZFSE_MI_LANES_ENC / _DEC override,
 // LZFSE_MI_NO_SPLIT=1 turns it off).
-static int split_batch(lzfse_mi_ctx *c, batch_dev_fn one, int lanes, size_t count, const void *d_src, const uint64_t *src_off,
+static int split_batch(lzfse_mi_ctx *c, batch_dev_fn one, int lanes, bool stagger, size_t count, const void *d_src, const uint64_t *src_off,
                        const uint64_t *src_len, void *d_dst, const uint64_t *dst_off, const uint64_t *dst_cap,
                        uint64_t *out_lens, int *statuses) {
     if (!c) return LZFSE_MI_BAD_ARGUMENT;
@@ -499,6 +504,17 @@ static int split_batch(lzfse_mi_ctx *c, batch_dev_fn one, int lanes, size_t coun
         c->shadow[k]->timing = c->timing;
     }
     if (!ok) return one(c, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap, out_lens, statuses);
+    // staggered start (encode): lane k + 1 begins when lane k has queued its candidate kernel
+    for (int k = 0; stagger && k + 1 < lanes; k++) {
+        lzmi::LaneGate &g = c->gates[k];
+        if (!g.ev && hipEventCreateWithFlags(&g.ev, hipEventDisableTiming) != hipSuccess) { g.ev = nullptr; stagger = false; }
+    }
+    for (int k = 0; k < lanes; k++) {
+        lzfse_mi_ctx *cx = k == 0 ? c : c->shadow[k - 1];
+        cx->gate_in = (stagger && k > 0) ? &c->gates[k - 1] : nullptr;
+        cx->gate_out = (stagger && k + 1 < lanes) ? &c->gates[k] : nullptr;
+        if (cx->gate_out) cx->gate_out->state.store(0);
+    }
     auto run = [&](lzfse_mi_ctx *cx, Part &p) {
         p.rc = one(cx, p.idx.size(), d_src, p.so.data(), p.sl.data(), d_dst, p.dof.data(), p.dc.data(), p.ol.data(), p.st.data());
     };
@@ -510,6 +526,10 @@ static int split_batch(lzfse_mi_ctx *c, batch_dev_fn one, int lanes, size_t coun
     }
     run(c, part[0]);
     for (auto &h : helpers) h.join();
+    for (int k = 0; k < lanes; k++) {
+        lzfse_mi_ctx *cx = k == 0 ? c : c->shadow[k - 1];
+        cx->gate_in = cx->gate_out = nullptr;
+    }
     for (size_t k = started + 1; k < part.size(); k++) run(c, part[k]);  // lanes whose thread could not be started
     int rc = 0;
     for (Part &p : part) {
@@ -530,14 +550,14 @@ int lzfse_mi_decode_batch_device(lzfse_mi_ctx *c, size_t count, const void *d_sr
                                  const uint64_t *src_len, void *d_dst, const uint64_t *dst_off,
                                  const uint64_t *dst_cap, uint64_t *out_lens, int *statuses) {
     static const int lanes = lanes_of("LZFSE_MI_LANES_DEC", 2);
-    return split_batch(c, decode_batch_device_one, lanes, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap, out_lens, statuses);
+    return split_batch(c, decode_batch_device_one, lanes, false, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap, out_lens, statuses);
 }
 
 int lzfse_mi_encode_batch_device(lzfse_mi_ctx *c, size_t count, const void *d_src, const uint64_t *src_off,
                                  const uint64_t *src_len, void *d_dst, const uint64_t *dst_off,
                                  const uint64_t *dst_cap, uint64_t *out_lens, int *statuses) {
     static const int lanes = lanes_of("LZFSE_MI_LANES_ENC", 2);
-    return split_batch(c, encode_batch_device_one, lanes, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap, out_lens, statuses);
+    return split_batch(c, encode_batch_device_one, lanes, getenv("LZFSE_MI_NO_STAGGER") == nullptr, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap, out_lens, statuses);
 }
 
 // ---------------------------------------------------------------------------- host-pointer API

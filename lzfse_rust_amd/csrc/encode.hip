@@ -25,6 +25,8 @@
 #include <cstdlib>
 #include <vector>
 
+#include <thread>
+
 #include "enc_common.h"
 
 struct lzfse_mi_ctx;
@@ -1373,6 +1375,11 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
                      uint64_t *out_lens, int *statuses) {
     hipStream_t stq = ctx_stream(c);
     EncScratch &S = ctx_enc(c);
+    // whatever path leaves this function, the next lane of a split call must not be left waiting
+    struct GateRelease {
+        LaneGate *g;
+        ~GateRelease() { if (g) { int e = 0; g->state.compare_exchange_strong(e, 2); } }
+    } gate_release{ctx_gate_out(c)};
     const char *walk_env = getenv("LZFSE_MI_WALK");
     const bool serial_walk = walk_env && walk_env[0] == 's';  // diagnostic: the single-wave walker
     std::vector<EncStream> hs;
@@ -1461,6 +1468,11 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     E_TRY(hipMemcpyAsync(d_slots, hslots.data(), (size_t)blk_total * 4, hipMemcpyHostToDevice, stq));
     E_TRY(hipMemsetAsync(d_outs, 0, ns * sizeof(EncStreamOut), stq));
     E_TRY(hipMemsetAsync(d_bitmap, 0, pos_total / 8 + 64, stq));
+    if (LaneGate *gi = ctx_gate_in(c)) {
+        // lane of a split call: start when the previous lane has queued its candidate kernel (LaneGate, internal.h)
+        for (int spins = 0; gi->state.load() == 0 && spins < 2000000; spins++) std::this_thread::yield();
+        if (gi->state.load() == 1) (void)hipStreamWaitEvent(stq, gi->ev, 0);
+    }
     {
         StageTimer t(c, "enc_chain");
         hipLaunchKernelGGL(enc_chain_kernel, dim3(nt), dim3(64), 0, stq, d_src, d_streams, d_tiles, nt, d_prev, d_summary, d_flist, d_fcount);
@@ -1469,6 +1481,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         StageTimer t(c, "enc_link");
         hipLaunchKernelGGL(enc_link_kernel, dim3((1u << HASH_BITS) / 256, nt), dim3(256), 0, stq, d_streams, d_tiles, nt, d_prev, d_summary, d_flist, d_fcount);
     }
+    if (LaneGate *go = ctx_gate_out(c)) go->state.store(hipEventRecord(go->ev, stq) == hipSuccess ? 1 : 2);
     {
         StageTimer t(c, "enc_cand");
         hipLaunchKernelGGL(enc_cand_kernel, dim3(((nt + 7) / 8) * 8 * CAND_BPT), dim3(256), 0, stq, d_src, d_streams, d_tiles, nt, d_prev, d_rec, d_bitmap,

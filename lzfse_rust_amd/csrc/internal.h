@@ -2,6 +2,8 @@
 #pragma once
 #include "common.h"
 
+#include <atomic>
+
 struct lzfse_mi_ctx;
 
 namespace lzmi {
@@ -14,6 +16,16 @@ struct StageTimer {
     ~StageTimer();
 };
 hipStream_t ctx_stream(lzfse_mi_ctx *c);
+
+// Hand-over point between two lanes of a split encode call: the later lane starts its kernels when the earlier one
+// has queued its match-candidate kernel, so that one lane's latency-bound stages run under the other lane's
+// throughput-bound stage instead of both lanes doing the same thing at the same time.
+struct LaneGate {
+    hipEvent_t ev = nullptr;
+    std::atomic<int> state{0};  // 0: pending, 1: ev recorded, 2: released without an event
+};
+LaneGate *ctx_gate_in(lzfse_mi_ctx *c);
+LaneGate *ctx_gate_out(lzfse_mi_ctx *c);
 
 // ---- decode.hip ----
 void launch_dec_walk(bool emit, const uint8_t *src, const StreamIn *streams, uint32_t n_streams,
