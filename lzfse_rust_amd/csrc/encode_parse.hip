@@ -38,6 +38,27 @@ __device__ __forceinline__ uint32_t next_has(const uint64_t *bm, uint32_t index,
     return (w << 6) + (uint32_t)__builtin_ctzll(bits);
 }
 
+// the same scan by a whole wave (uniform arguments and result): 64 bitmap words per step, for the stitcher's true
+// walk, which crosses long stretches without any candidate on incompressible data
+__device__ __forceinline__ uint32_t next_has_wave(const uint64_t *bm, uint32_t index, uint32_t stop) {
+    const int lane = e_lane();
+    uint32_t w = index >> 6;
+    const uint64_t first = bm[w] & (~0ull << (index & 63));
+    if (first) return (w << 6) + (uint32_t)__builtin_ctzll(first);
+    for (w++; (w << 6) < stop; w += 64) {
+        const uint32_t wl = w + (uint32_t)lane;
+        const uint64_t bits = (wl << 6) < stop ? bm[wl] : 0ull;
+        const uint64_t nz = __ballot(bits != 0);
+        if (nz) {
+            const int L = __builtin_ctzll(nz);
+            const uint32_t lo = e_readlane((uint32_t)bits, L), hi = e_readlane((uint32_t)(bits >> 32), L);
+            const uint64_t b = (uint64_t)lo | ((uint64_t)hi << 32);
+            return ((w + (uint32_t)L) << 6) + (uint32_t)__builtin_ctzll(b);
+        }
+    }
+    return stop;
+}
+
 // Match::select::<40> (match_object.rs:12-33) on an incoming match; returns true on emit
 __device__ __forceinline__ bool select40(WState &st, uint32_t i_idx, uint32_t i_midx, uint32_t i_len,
                                          uint32_t &e_idx, uint32_t &e_midx, uint32_t &e_len) {
@@ -67,6 +88,19 @@ __device__ __forceinline__ bool select40(WState &st, uint32_t i_idx, uint32_t i_
 // exact forward / backward lengths by the whole wave (512 / 64 bytes per step); every lane must call
 __device__ uint32_t st_wave_lcp_fwd(const uint8_t *s, uint32_t a, uint32_t b, uint32_t len, uint32_t max) {
     const int lane = e_lane();
+    // bulk: 16 bytes per lane, two steps in flight = 2 KiB per round trip (matches of 100 KB and more exist)
+    while (len + 2048 <= max) {
+        const uint32_t o0 = len + 16 * lane, o1 = o0 + 1024;
+        uint4 a0, b0, a1, b1;
+        __builtin_memcpy(&a0, s + a + o0, 16); __builtin_memcpy(&b0, s + b + o0, 16);
+        __builtin_memcpy(&a1, s + a + o1, 16); __builtin_memcpy(&b1, s + b + o1, 16);
+        const bool bad0 = ((a0.x ^ b0.x) | (a0.y ^ b0.y) | (a0.z ^ b0.z) | (a0.w ^ b0.w)) != 0;
+        const bool bad1 = ((a1.x ^ b1.x) | (a1.y ^ b1.y) | (a1.z ^ b1.z) | (a1.w ^ b1.w)) != 0;
+        const uint64_t m0 = __ballot(bad0), m1 = __ballot(bad1);
+        if (m0) { len += 16 * (uint32_t)__builtin_ctzll(m0); break; }       // the 8-byte loop below finds the byte
+        if (m1) { len += 1024 + 16 * (uint32_t)__builtin_ctzll(m1); break; }
+        len += 2048;
+    }
     while (len < max) {
         uint32_t off = len + 8 * lane;
         uint64_t x = 0;
@@ -396,7 +430,7 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
         }
         // ---- true walk (exact, scalar): frontend_bytes.rs:183-208 ----
         if (T.index >= end) { done = true; break; }
-        uint32_t p = next_has(bm, T.index, end);
+        uint32_t p = next_has_wave(bm, T.index, end);
         if (p >= end) { T.index = end; done = true; break; }
         st_iters++;
         T.index = p;
