@@ -72,3 +72,32 @@ def test_split_lane_count_override(snappy_raw, oracle):
     many, st = c.encode_batch([r] * 48)        # 4.9 MB, split
     assert all(e == 0 for e in st)
     assert all(o.tobytes() == small[0].tobytes() for o in many)
+
+
+def test_many_mid_size_streams_take_the_per_stream_lz_path(ctx, snappy_raw):
+    """100 streams of 2.2 MiB (50 per lane): each is large enough for the pointer-jumping LZ path, but with this
+    many the cost model keeps them on one workgroup per stream (api.hip, jump_mode); one 6 MiB stream alone jumps."""
+    base = (snappy_raw["alice29.txt"] + snappy_raw["html"] + snappy_raw["kppkn.gtb"]) * 6
+    raws = []
+    for i in range(100):
+        a = np.frombuffer(base[: 2200 * 1024 + 997 * i], dtype=np.uint8).copy()
+        a[i % 251::251] ^= np.uint8(1 + i)
+        raws.append(a.tobytes())
+    outs, st = ctx.encode_batch(raws)
+    assert all(e == 0 for e in st)
+    ctx.enable_timing(True)
+    dec, st2 = ctx.decode_batch([o.tobytes() for o in outs])
+    t = ctx.timings()
+    ctx.enable_timing(False)
+    assert all(e == 0 for e in st2)
+    for r, o in zip(raws, dec):
+        assert o.tobytes() == r
+    assert "dec_jump_rounds" not in t and "dec_lz" in t, t
+    big = base[: 6 << 20]
+    o1, s1 = ctx.encode_batch([big])
+    ctx.enable_timing(True)
+    d1, s2 = ctx.decode_batch([o1[0].tobytes()])
+    t1 = ctx.timings()
+    ctx.enable_timing(False)
+    assert s1[0] == 0 and s2[0] == 0 and d1[0].tobytes() == big
+    assert "dec_jump_rounds" in t1, t1
