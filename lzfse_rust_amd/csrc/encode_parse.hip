@@ -710,6 +710,18 @@ __global__ __launch_bounds__(SEGM_THREADS) void enc_segment_kernel(const EncStre
             // first event that does NOT fit: in [j, hi] with hi <= j + 10 001 (every event has at least one LMD);
             // fits(e) is monotone, 64 probes per step narrow [lo, hi] by a factor of 65
             uint32_t lo = j, hi = E - j > LMDS_PER_BLOCK + 1 ? j + LMDS_PER_BLOCK + 1 : E;
+            // nearly every event is one LMD, so the answer is usually just below j + room_c: one dense probe of the
+            // 64 events below that point settles most blocks in a single round trip
+            if (hi - lo > 128) {
+                const uint32_t top = (j + room_c + 1 < hi) ? j + room_c + 1 : hi;  // events >= top cannot fit (top <= hi)
+                if (top - lo > 64) {
+                    const uint32_t e = top - 64 + (uint32_t)lane;
+                    const bool fits = PC[e] - base_c <= room_c && PL[e] - base_l <= room_l;
+                    const uint32_t nfit = (uint32_t)__popcll(__ballot(fits));  // monotone: the first nfit probes fit
+                    if (nfit == 0) hi = top - 64;                               // answer below the probed range
+                    else { lo = top - 64 + nfit; hi = nfit < 64 ? lo : top; }   // exact when a probe failed
+                }
+            }
             while (lo < hi) {
                 const uint32_t span = hi - lo, stp = span / 65 + 1;
                 const uint32_t e = lo + stp * (uint32_t)lane + (stp - 1);  // probes lo+stp-1, lo+2stp-1, ...
