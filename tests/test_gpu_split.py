@@ -33,7 +33,7 @@ def test_split_encode_matches_oracle(ctx, oracle, snappy_raw):
     outs, st = ctx.encode_batch(raws)
     t = ctx.timings()
     ctx.enable_timing(False)
-    assert t["enc_cand"][1] == 2, t  # two sub-batches ran
+    assert t["enc_cand"][1] >= 2, t  # sub-batches ran side by side
     for r, o, e in zip(raws, outs, st):
         assert e == 0
         assert o.tobytes() == oracle.encode(r), len(r)
