@@ -218,6 +218,8 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
     __shared__ uint16_t wts[N_WEIGHTS];
     __shared__ uint16_t cum[N_WEIGHTS];
     __shared__ uint32_t ring[2][128];
+    __shared__ uint32_t stg_lmd[64 * 3 + 1];  // 64 steps of (L, M, D) values, + one dump slot for the idle lanes
+    __shared__ __attribute__((aligned(4))) uint8_t stg_lit[64 * 4 + 4];   // 64 groups of four literals, + dump slot
     __shared__ int sh_status[2];
     __shared__ uint32_t sh_sums[2];
 
@@ -373,23 +375,31 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
         uint32_t state = q4 == 0 ? h.lit_state[0] : q4 == 1 ? h.lit_state[1] : q4 == 2 ? h.lit_state[2] : h.lit_state[3];
         uint8_t *out = lit_out + d.lit_base;
         const uint32_t n_groups = e ? 0u : h.lit_num >> 2;
+        // The symbols go to LDS, one byte per state lane (the idle lanes write a dump slot, so the store needs no
+        // exec masking), and every 64 groups the wave stores 64 dwords coalesced: two instructions per step.
+        const uint32_t s_home = lane < 4 ? (uint32_t)lane : 256u, s_inc = lane < 4 ? 4u : 0u;
+        uint32_t sidx = s_home;
         uint64_t win = bw_window(w);
         for (uint32_t g = 0; g < n_groups; g++) {
             const uint32_t ent = u_tab[state];
             const uint32_t k = ent & 0xFF;
-            const uint32_t sym = (ent >> 8) & 0xFF;
             const int32_t delta = (int32_t)(int16_t)(ent >> 16);
             uint32_t pre = k;
             pre += dpp_shr<1>(pre);
             pre += dpp_shr<2>(pre);  // inclusive prefix over lanes 0..3
             const uint32_t bits = (uint32_t)(win >> ((64 - pre) & 63)) & ((1u << k) - 1u);  // pre == 0 only with k == 0
             state = (uint32_t)((int32_t)bits + delta) & 1023u;
-            uint32_t word = sym << (8 * q4);
-            word |= dpp_shr<1>(word);
-            word |= dpp_shr<2>(word);  // lane 3 holds the four symbols
+            stg_lit[sidx] = (uint8_t)(ent >> 8);
+            sidx += s_inc;
             bw_advance(w, read_lane(pre, 3));
             win = bw_window(w);
-            if (lane == 3) ((uint32_t *)out)[g] = word;  // one 4-byte store per group of four literals
+            if ((g & 63) == 63) {
+                ((uint32_t *)out)[(g & ~63u) + lane] = ((const uint32_t *)stg_lit)[lane];
+                sidx = s_home;
+            }
+        }
+        if (n_groups & 63) {
+            if (lane < (int)(n_groups & 63)) ((uint32_t *)out)[(n_groups & ~63u) + lane] = ((const uint32_t *)stg_lit)[lane];
         }
         if (!e) e = bw_finalize(w);
         uint32_t s0 = read_lane(state, 0) | read_lane(state, 1) | read_lane(state, 2) | read_lane(state, 3);
@@ -404,9 +414,24 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
         const uint32_t tbase = li == 0 ? 0u : (li == 1 ? 64u : 128u);
         const uint32_t smask = li == 2 ? 255u : 63u;
         LmdRec *out = lmd_out + d.lmd_base;
-        uint32_t acc_sum = 0;   // lane 0: sum of L, lane 1: sum of M
-        uint32_t prev_d = 0;    // lane 2
         const uint32_t n = e ? 0u : h.lmd_num;
+        // The three values of a step go to LDS (idle lanes write a dump slot: no exec masking); every 64 steps the
+        // wave turns them into 64 LMD records: D = 0 takes the previous distance (lmd_type.rs:153-160) by a wave scan,
+        // the sums of L and M accumulate per lane, and the records are stored coalesced.
+        const uint32_t s_home = lane < 3 ? (uint32_t)lane : 192u, s_inc = lane < 3 ? 3u : 0u;
+        uint32_t sidx = s_home;
+        uint32_t acc_l = 0, acc_m = 0, carry_d = 0;
+        auto flush = [&](uint32_t base, uint32_t cnt) {
+            const bool have = (uint32_t)lane < cnt;
+            const uint32_t vl = have ? stg_lmd[3 * lane] : 0u, vm = have ? stg_lmd[3 * lane + 1] : 0u, vd = have ? stg_lmd[3 * lane + 2] : 0u;
+            const uint64_t nz = __ballot(vd != 0);
+            const uint64_t upto = nz & (lane == 63 ? ~0ull : ((2ull << lane) - 1));
+            const uint32_t from = __shfl(vd, upto ? 63 - __builtin_clzll(upto) : lane);
+            const uint32_t dv = upto ? from : carry_d;
+            if (have) out[base + lane] = make_uint2(vl | (vm << 16), dv);
+            acc_l += vl; acc_m += vm;
+            if (nz) carry_d = read_lane(vd, 63 - __builtin_clzll(nz));
+        };
         uint64_t win = bw_window(w);
         for (uint32_t i = 0; i < n; i++) {
             const uint2 ent = v_tab[tbase + state];
@@ -420,13 +445,19 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
             const uint32_t extra = x & ((1u << vb) - 1u);
             const uint32_t sb = (x >> vb) & ((1u << k) - 1u);
             state = (uint32_t)((int32_t)sb + delta) & smask;
-            const uint32_t val = ent.y + extra;
+            stg_lmd[sidx] = ent.y + extra;
+            sidx += s_inc;
             bw_advance(w, read_lane(pre, 2));
             win = bw_window(w);
-            acc_sum += val;
-            if (val != 0) prev_d = val;                               // lane 2: lmd_type.rs:153-160
-            const uint32_t lm = dpp_shr<2>(val) | (dpp_shr<1>(val) << 16);  // lane 2: l | m << 16
-            if (lane == 2) out[i] = make_uint2(lm, prev_d);           // one 8-byte store per LMD, nothing waits for it
+            if ((i & 63) == 63) { flush(i & ~63u, 64); sidx = s_home; }
+        }
+        if (n & 63) flush(n & ~63u, n & 63);
+        uint32_t acc_sum = 0;  // lane 0: sum of L, lane 1: sum of M (wave totals)
+        {
+            uint32_t tl = acc_l, tm = acc_m;
+#pragma unroll
+            for (int dd = 32; dd > 0; dd >>= 1) { tl += __shfl_xor(tl, dd); tm += __shfl_xor(tm, dd); }
+            acc_sum = lane == 0 ? tl : tm;
         }
         if (!e) e = bw_finalize(w);
         const uint32_t sum_l = read_lane(acc_sum, 0), sum_m = read_lane(acc_sum, 1);
