@@ -64,7 +64,7 @@ struct lzfse_mi_ctx {
     // batch descriptors / results
     DevBuf d_streams, d_walk, d_plan, d_blocks, d_bres, d_sres;
     // decode scratch
-    DevBuf d_lmds, d_lits, d_origin, d_jerr;
+    DevBuf d_lmds, d_lits, d_origin, d_jerr, d_wcache;
     // encode scratch (encode.hip)
     EncScratch enc;
     // host-pointer API staging
@@ -207,7 +207,7 @@ void lzfse_mi_destroy(lzfse_mi_ctx *c) {
     for (auto &g : c->gates) if (g.ev) (void)hipEventDestroy(g.ev);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->d_streams, &c->d_walk, &c->d_plan, &c->d_blocks, &c->d_bres, &c->d_sres,
-                      &c->d_lmds, &c->d_lits, &c->d_origin, &c->d_jerr, &c->d_in, &c->d_out})
+                      &c->d_lmds, &c->d_lits, &c->d_origin, &c->d_jerr, &c->d_wcache, &c->d_in, &c->d_out})
         b->release();
     enc_scratch_release(c->enc);
     c->h_in.release();
@@ -311,11 +311,17 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
     const uint32_t ns = (uint32_t)count;
     std::vector<StreamIn> h_streams(ns);
     uint64_t src_total = 0;
+    // walk cache: the count pass leaves its descriptors there (one per ~2 KiB of input plus a few per stream; a real
+    // bvx2 block is far larger), so that placing them afterwards is a parallel copy instead of a second serial walk
+    uint64_t cache_total = 0;
     for (uint32_t i = 0; i < ns; i++) {
-        h_streams[i] = {src_off[i], src_len[i], dst_off[i], dst_cap[i]};
+        const uint64_t cap = src_len[i] / 2048 + 4;
+        h_streams[i] = {src_off[i], src_len[i], dst_off[i], dst_cap[i], cache_total, cap};
+        cache_total += cap;
         src_total = std::max<uint64_t>(src_total, src_off[i] + src_len[i]);
     }
-    if (!c->d_streams.ensure(ns * sizeof(StreamIn)) || !c->d_walk.ensure(ns * sizeof(StreamWalk)) ||
+    if (!c->d_wcache.ensure(cache_total * sizeof(BlockDesc)) ||
+        !c->d_streams.ensure(ns * sizeof(StreamIn)) || !c->d_walk.ensure(ns * sizeof(StreamWalk)) ||
         !c->d_plan.ensure(ns * sizeof(StreamPlan)) || !c->d_sres.ensure(ns * sizeof(StreamResult)))
         return LZFSE_MI_IO;
     HIP_TRY(hipMemcpyAsync(c->d_streams.p, h_streams.data(), ns * sizeof(StreamIn), hipMemcpyHostToDevice, st));
@@ -323,7 +329,7 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
     {
         StageTimer t(c, "dec_walk");
         launch_dec_walk(false, (const uint8_t *)d_src, (const StreamIn *)c->d_streams.p, ns,
-                        (StreamWalk *)c->d_walk.p, nullptr, nullptr, st);
+                        (StreamWalk *)c->d_walk.p, nullptr, (BlockDesc *)c->d_wcache.p, st);
     }
     std::vector<StreamWalk> h_walk(ns);
     HIP_TRY(hipMemcpyAsync(h_walk.data(), c->d_walk.p, ns * sizeof(StreamWalk), hipMemcpyDeviceToHost, st));
@@ -372,8 +378,13 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
     HIP_TRY(hipMemsetAsync(c->d_sres.p, 0, ns * sizeof(StreamResult), st));
     {
         StageTimer t(c, "dec_walk");
-        launch_dec_walk(true, (const uint8_t *)d_src, (const StreamIn *)c->d_streams.p, ns, nullptr,
-                        (const StreamPlan *)c->d_plan.p, (BlockDesc *)c->d_blocks.p, st);
+        launch_dec_emit((const StreamIn *)c->d_streams.p, ns, (const StreamPlan *)c->d_plan.p, (const BlockDesc *)c->d_wcache.p,
+                        cache_total, (BlockDesc *)c->d_blocks.p, st);
+        bool rewalk = false;  // streams whose blocks did not fit their share of the cache
+        for (uint32_t i = 0; i < ns; i++) rewalk |= !h_plan[i].skip && h_plan[i].n_blocks > h_streams[i].cache_cap;
+        if (rewalk)
+            launch_dec_walk(true, (const uint8_t *)d_src, (const StreamIn *)c->d_streams.p, ns, nullptr,
+                            (const StreamPlan *)c->d_plan.p, (BlockDesc *)c->d_blocks.p, st);
     }
     {
         StageTimer t(c, "dec_fse");

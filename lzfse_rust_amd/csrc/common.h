@@ -28,6 +28,8 @@ enum BlockKind : uint32_t { KIND_VX2 = 0, KIND_VX1 = 1, KIND_RAW = 2, KIND_VXN =
 // One independent LZFSE stream of a batch (offsets into the batch's device buffers).
 struct StreamIn {
     uint64_t src_off, src_len, dst_off, dst_cap;
+    uint64_t cache_off;   // decode: first entry of the stream in the header-walk cache (BlockDesc with stream-relative bases)
+    uint64_t cache_cap;   // ... and its capacity in blocks; longer streams are re-walked when the descriptors are emitted
 };
 
 // Result of the header walk for one stream (decode).

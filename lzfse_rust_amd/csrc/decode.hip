@@ -48,15 +48,18 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 
 // ------------------------------------------------------------------------------------ walk
 
-// One thread per stream. EMIT = false: count blocks / LMDs / literals and validate headers.
-// EMIT = true: write BlockDesc records at the bases the host assigned from the counts.
+// One thread per stream. EMIT = false: count blocks / LMDs / literals, validate headers, and leave the descriptors
+// (with stream-relative LMD / literal bases) in the walk cache. EMIT = true: the serial re-walk for streams with
+// more blocks than their share of the cache: writes BlockDesc records at the bases the host assigned from the counts.
+// The cached descriptors are placed by dec_emit_kernel, in parallel.
 template <bool EMIT>
 __global__ void dec_walk_kernel(const uint8_t *__restrict__ src, const StreamIn *__restrict__ streams,
                                 uint32_t n_streams, StreamWalk *__restrict__ walk,
                                 const StreamPlan *__restrict__ plan, BlockDesc *__restrict__ blocks) {
+    __shared__ BlockDesc stage[EMIT ? 1 : 64][EMIT ? 1 : 8];
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_streams) return;
-    if (EMIT && plan[s].skip) return;
+    if (EMIT && (plan[s].skip || plan[s].n_blocks <= streams[s].cache_cap)) return;
     const StreamIn in = streams[s];
     const uint8_t *base = src + in.src_off;
     uint64_t n = in.src_len, pos = 0;
@@ -115,6 +118,13 @@ __global__ void dec_walk_kernel(const uint8_t *__restrict__ src, const StreamIn 
         if (EMIT) {
             if (w.n_blocks >= max_blocks) break;  // cannot happen: same walk as the count pass
             blocks[blk_i + w.n_blocks] = d;
+        } else if (w.n_blocks < in.cache_cap) {
+            // `blocks` is the walk cache in this pass. The descriptors are staged in LDS, 8 per thread, and written
+            // out together: a store per block would make the next header load wait for it (loads and stores
+            // complete in order), doubling the time of this serial walk.
+            stage[threadIdx.x][w.n_blocks & 7] = d;
+            if ((w.n_blocks & 7) == 7)
+                for (uint32_t k = 0; k < 8; k++) blocks[in.cache_off + w.n_blocks - 7 + k] = stage[threadIdx.x][k];
         }
         w.n_blocks++;
         w.n_lmds += d.n_lmd; lmd_i += d.n_lmd;
@@ -122,7 +132,29 @@ __global__ void dec_walk_kernel(const uint8_t *__restrict__ src, const StreamIn 
         w.raw_total += d.n_raw;
         pos += skip;
     }
-    if (!EMIT) walk[s] = w;
+    if (!EMIT) {
+        const uint64_t nc = w.n_blocks < in.cache_cap ? w.n_blocks : in.cache_cap;
+        for (uint64_t k = nc & ~7ull; k < nc; k++) blocks[in.cache_off + k] = stage[threadIdx.x][k & 7];
+        walk[s] = w;
+    }
+}
+
+// one thread per cached descriptor: add the stream's bases and put it at its place
+__global__ void dec_emit_kernel(const StreamIn *__restrict__ streams, uint32_t n_streams, const StreamPlan *__restrict__ plan,
+                                const BlockDesc *__restrict__ cache, uint64_t cache_total, BlockDesc *__restrict__ blocks) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= cache_total) return;
+    uint32_t lo = 0, hi = n_streams - 1;  // last stream with cache_off <= e
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (streams[mid].cache_off <= e) lo = mid; else hi = mid - 1;
+    }
+    const StreamPlan pl = plan[lo];
+    const uint64_t k = e - streams[lo].cache_off;
+    if (pl.skip || k >= pl.n_blocks || pl.n_blocks > streams[lo].cache_cap) return;
+    BlockDesc d = cache[e];
+    d.lmd_base += pl.lmd_base; d.lit_base += pl.lit_base;
+    blocks[pl.blk_base + k] = d;
 }
 
 // ------------------------------------------------------------------------------------ FSE stage
@@ -954,6 +986,13 @@ void launch_dec_walk(bool emit, const uint8_t *src, const StreamIn *streams, uin
     dim3 grid((n_streams + 63) / 64), block(64);
     if (emit) hipLaunchKernelGGL(dec_walk_kernel<true>, grid, block, 0, st, src, streams, n_streams, walk, plan, blocks);
     else hipLaunchKernelGGL(dec_walk_kernel<false>, grid, block, 0, st, src, streams, n_streams, walk, plan, blocks);
+}
+
+void launch_dec_emit(const StreamIn *streams, uint32_t n_streams, const StreamPlan *plan, const BlockDesc *cache, uint64_t cache_total,
+                     BlockDesc *blocks, hipStream_t st) {
+    if (!cache_total) return;
+    hipLaunchKernelGGL(dec_emit_kernel, dim3((uint32_t)((cache_total + 255) / 256)), dim3(256), 0, st, streams, n_streams, plan, cache,
+                       cache_total, blocks);
 }
 
 void launch_dec_fse(const uint8_t *src, uint64_t src_total, const BlockDesc *blocks, uint32_t n_blocks,

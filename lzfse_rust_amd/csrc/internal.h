@@ -30,6 +30,8 @@ LaneGate *ctx_gate_out(lzfse_mi_ctx *c);
 // ---- decode.hip ----
 void launch_dec_walk(bool emit, const uint8_t *src, const StreamIn *streams, uint32_t n_streams,
                      StreamWalk *walk, const StreamPlan *plan, BlockDesc *blocks, hipStream_t st);
+void launch_dec_emit(const StreamIn *streams, uint32_t n_streams, const StreamPlan *plan, const BlockDesc *cache, uint64_t cache_total,
+                     BlockDesc *blocks, hipStream_t st);
 void launch_dec_fse(const uint8_t *src, uint64_t src_total, const BlockDesc *blocks, uint32_t n_blocks,
                     uint8_t *lit_out, LmdRec *lmd_out, BlockResult *results, hipStream_t st);
 void launch_dec_lz(int variant, const uint8_t *src, const StreamIn *streams, const StreamPlan *plan,

@@ -135,3 +135,17 @@ def test_decode_pointer_jumping_path(ctx, oracle, golden_dir, snappy_raw):
         assert (e == 0) == (es == 0), (e, es)
         if e == 0:
             assert o.tobytes() == oracle.decode(c, cap=1 << 20)
+
+
+def test_decode_many_tiny_blocks_rewalk(ctx, oracle, snappy_raw):
+    """Streams with far more blocks than their share of the header-walk cache (one per 2 KiB of input) take the
+    serial re-walk when the block descriptors are placed; mixed with ordinary streams in one batch."""
+    tiny = b"".join(b"bvx-" + (1).to_bytes(4, "little") + bytes([i & 255]) for i in range(3000)) + b"bvx$"
+    tiny2 = b"".join(b"bvx-" + (3).to_bytes(4, "little") + bytes([i & 255, 7, 9]) for i in range(500)) + b"bvx$"
+    ordinary = oracle.encode(snappy_raw["html"])
+    srcs = [ordinary, tiny, ordinary, tiny2]
+    outs, st = ctx.decode_batch(srcs)
+    assert all(e == 0 for e in st), st
+    for s, o in zip(srcs, outs):
+        assert o.tobytes() == oracle.decode(s)
+    assert len(outs[1]) == 3000 and len(outs[3]) == 1500
