@@ -140,6 +140,32 @@ LZMI_HD inline int fse_validate(const FseHeader &h) {
 }
 
 // fse/block.rs:108-136
+// the same from the header's four 8-byte words (the walk fetches them with one round trip)
+LZMI_HD inline int fse_parse_v2(uint64_t q0, uint64_t q1, uint64_t q2, uint64_t q3, FseHeader &h) {
+    h.n_raw = (uint32_t)(q0 >> 32);
+    uint64_t q = q1;
+    h.lit_num = (uint32_t)(q & 0xFFFFF);
+    h.lit_payload = (uint32_t)((q >> 20) & 0xFFFFF);
+    h.lmd_num = (uint32_t)((q >> 40) & 0xFFFFF);
+    h.lit_bits = 7u - (uint32_t)((q >> 60) & 7);
+    q = q2;
+    h.lit_state[0] = (uint32_t)(q & 0x3FF);
+    h.lit_state[1] = (uint32_t)((q >> 10) & 0x3FF);
+    h.lit_state[2] = (uint32_t)((q >> 20) & 0x3FF);
+    h.lit_state[3] = (uint32_t)((q >> 30) & 0x3FF);
+    h.lmd_payload = (uint32_t)((q >> 40) & 0xFFFFF);
+    h.lmd_bits = 7u - (uint32_t)((q >> 60) & 7);
+    q = q3;
+    uint32_t header_size = (uint32_t)q;
+    h.lmd_state[0] = (uint32_t)((q >> 32) & 0x3FF);
+    h.lmd_state[1] = (uint32_t)((q >> 42) & 0x3FF);
+    h.lmd_state[2] = (uint32_t)((q >> 52) & 0x3FF);
+    h.n_weight = header_size - V2_HEADER_SIZE;  // wrapping_sub
+    if (h.n_weight > V2_WEIGHT_PAYLOAD_BYTES_MAX) return LZFSE_MI_FSE_BAD_WEIGHT_PAYLOAD;
+    h.hdr_size = V2_HEADER_SIZE + h.n_weight;
+    return fse_validate(h);
+}
+
 LZMI_HD inline int fse_load_v2(const uint8_t *p, FseHeader &h) {
     h.n_raw = ld_u32(p + 4);
     uint64_t q = ld_u64(p + 8);

@@ -70,8 +70,12 @@ __global__ void dec_walk_kernel(const uint8_t *__restrict__ src, const StreamIn 
     uint32_t max_blocks = EMIT ? plan[s].n_blocks : 0xFFFFFFFFu;
     for (;;) {
         if (n - pos < 4) { w.status = LZFSE_MI_PAYLOAD_UNDERFLOW; break; }
-        uint32_t magic = ld_u32(base + pos);
         uint64_t avail = n - pos;
+        // a whole v2 header in one round trip (this loop is a chain of dependent loads, one block after the other)
+        const bool wide = avail >= V2_HEADER_SIZE;
+        uint64_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+        if (wide) { q0 = ld_u64(base + pos); q1 = ld_u64(base + pos + 8); q2 = ld_u64(base + pos + 16); q3 = ld_u64(base + pos + 24); }
+        uint32_t magic = wide ? (uint32_t)q0 : ld_u32(base + pos);
         if (magic == MAGIC_EOS) {
             if (avail != 4) w.status = LZFSE_MI_PAYLOAD_OVERFLOW;  // decoder.rs:93-95
             break;
@@ -86,7 +90,7 @@ __global__ void dec_walk_kernel(const uint8_t *__restrict__ src, const StreamIn 
             FseHeader h;
             bool v1 = magic == MAGIC_VX1;
             if (avail < (v1 ? V1_HEADER_SIZE : V2_HEADER_SIZE)) st = LZFSE_MI_PAYLOAD_UNDERFLOW;
-            else st = v1 ? fse_load_v1(base + pos, h) : fse_load_v2(base + pos, h);
+            else st = v1 ? fse_load_v1(base + pos, h) : fse_parse_v2(q0, q1, q2, q3, h);
             if (!st) {
                 skip = (uint64_t)h.hdr_size + h.lit_payload + h.lmd_payload;
                 if (skip > avail) st = LZFSE_MI_PAYLOAD_UNDERFLOW;  // decode/take.rs:10-19
