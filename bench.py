@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--replicas", type=int, default=64, help="copies of the 12-file corpus per GPU")
+    ap.add_argument("--replicas", type=int, default=256, help="copies of the 12-file corpus per GPU (256: 3072 streams, 752 MB)")
     ap.add_argument("--workload", default="snappy", choices=["snappy", "text64m", "chunks4m", "chunks1g"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -221,7 +221,7 @@ def main():
         # WRITE_SIZE runs of this same default workload, profiles/r01_pmc_traffic.json; KiB -> bytes, raw figures)
         traffic = None
         try:
-            if args.workload == "snappy" and args.replicas == 64:
+            if args.workload == "snappy" and args.replicas == 256:
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
                 key = [k for k in pm if k.startswith(dom + "_kernel")]
                 if key:

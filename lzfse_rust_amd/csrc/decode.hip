@@ -1013,18 +1013,6 @@ void launch_dec_lz(int variant, const uint8_t *src, const StreamIn *streams, con
     if (variant == 0)
         hipLaunchKernelGGL((dec_lz_kernel<256, 8192>), dim3(n_streams), dim3(256), 0, st, src, streams, plan,
                            blocks, bres, lmds, lits, dst, sres);
-    else if (variant == 2)
-        hipLaunchKernelGGL((dec_lz_kernel<512, 8192>), dim3(n_streams), dim3(512), 0, st, src, streams, plan,
-                           blocks, bres, lmds, lits, dst, sres);
-    else if (variant == 4)
-        hipLaunchKernelGGL((dec_lz_kernel<1024, 16384>), dim3(n_streams), dim3(1024), 0, st, src, streams, plan,
-                           blocks, bres, lmds, lits, dst, sres);
-    else if (variant == 5)
-        hipLaunchKernelGGL((dec_lz_kernel<1024, 24576>), dim3(n_streams), dim3(1024), 0, st, src, streams, plan,
-                           blocks, bres, lmds, lits, dst, sres);
-    else if (variant == 3)
-        hipLaunchKernelGGL((dec_lz_kernel<512, 16384>), dim3(n_streams), dim3(512), 0, st, src, streams, plan,
-                           blocks, bres, lmds, lits, dst, sres);
     else
         hipLaunchKernelGGL((dec_lz_kernel<1024, 32768>), dim3(n_streams), dim3(1024), 0, st, src, streams, plan,
                            blocks, bres, lmds, lits, dst, sres);
