@@ -565,10 +565,13 @@ __global__ __launch_bounds__(64) void enc_compact_kernel(const EncStream *__rest
     if (lane == 0) rsum[slot] = make_uint2(carry_c, carry_l);
 }
 
-// one workgroup per stream: exclusive scan of the range totals
-__global__ __launch_bounds__(1024) void enc_rscan_kernel(const EncStream *__restrict__ streams, uint32_t n_streams,
-                                                         const EncStreamOut *__restrict__ outs, uint2 *__restrict__ rsum) {
-    __shared__ uint32_t sh[2 * 16 + 2];
+// one workgroup per stream: exclusive scan of the range totals (a 256-thread workgroup finds room on a busy chip
+// much sooner than a 1024-thread one; a stream has one range per 2 KiB segment or fewer)
+constexpr int RSCAN_THREADS = 256;
+__global__ __launch_bounds__(RSCAN_THREADS) void enc_rscan_kernel(const EncStream *__restrict__ streams, uint32_t n_streams,
+                                                                  const EncStreamOut *__restrict__ outs, uint2 *__restrict__ rsum) {
+    constexpr int NWV = RSCAN_THREADS / 64;
+    __shared__ uint32_t sh[2 * NWV + 2];
     const uint32_t si = blockIdx.x;
     if (si >= n_streams) return;
     const EncStream &es = streams[si];
@@ -577,7 +580,7 @@ __global__ __launch_bounds__(1024) void enc_rscan_kernel(const EncStream *__rest
     uint2 *rs = rsum + es.range_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t carry_c = 0, carry_l = 0;
-    for (uint32_t g0 = 0; g0 < so.n_ranges; g0 += 1024) {
+    for (uint32_t g0 = 0; g0 < so.n_ranges; g0 += RSCAN_THREADS) {
         const uint32_t j = g0 + tid;
         const uint2 v = j < so.n_ranges ? rs[j] : make_uint2(0, 0);
         uint32_t ic = v.x, il = v.y;
@@ -586,11 +589,11 @@ __global__ __launch_bounds__(1024) void enc_rscan_kernel(const EncStream *__rest
             uint32_t xx = __shfl_up(ic, d2), yy = __shfl_up(il, d2);
             if (lane >= d2) { ic += xx; il += yy; }
         }
-        if (lane == 63) { sh[wave] = ic; sh[16 + wave] = il; }
+        if (lane == 63) { sh[wave] = ic; sh[NWV + wave] = il; }
         __syncthreads();
         uint32_t oc = 0, ol = 0, tc = 0, tl = 0;
-        for (int w = 0; w < 16; w++) {
-            uint32_t xx = sh[w], yy = sh[16 + w];
+        for (int w = 0; w < NWV; w++) {
+            uint32_t xx = sh[w], yy = sh[NWV + w];
             if (w < wave) { oc += xx; ol += yy; }
             tc += xx; tl += yy;
         }
@@ -839,7 +842,7 @@ void launch_enc_compact(const EncStream *streams, const uint32_t *slot_stream, u
     if (!n_slots) return;
     hipLaunchKernelGGL(enc_compact_kernel, dim3(n_slots), dim3(64), 0, st, streams, slot_stream, outs, ranges, logs, gaps, matches, pc, pl,
                        rsum);
-    hipLaunchKernelGGL(enc_rscan_kernel, dim3(ns), dim3(1024), 0, st, streams, ns, outs, rsum);
+    hipLaunchKernelGGL(enc_rscan_kernel, dim3(ns), dim3(RSCAN_THREADS), 0, st, streams, ns, outs, rsum);
     hipLaunchKernelGGL(enc_papply_kernel, dim3(n_slots), dim3(64), 0, st, streams, slot_stream, outs, ranges, rsum, pc, pl);
 }
 void launch_enc_segment(const EncStream *streams, uint32_t ns, const MatchRec *matches, const uint32_t *pc, const uint32_t *pl,
