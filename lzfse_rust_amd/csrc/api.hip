@@ -393,7 +393,9 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
     }
     {
         StageTimer t(c, "dec_lz");
-        int variant = 1;  // 1024 threads / 32 KiB tile (0: 256 threads / 8 KiB tile, kept for the parity tests)
+        // one workgroup per stream: with few streams per CU the 1024-thread / 32 KiB-tile kernel finishes a stream
+        // soonest; with >= 4 streams per CU the 256-thread / 8 KiB-tile kernel (5 workgroups per CU) moves more bytes
+        int variant = ns >= 1024 ? 0 : 1;
         if (const char *ev = getenv("LZFSE_MI_LZ_VARIANT")) variant = atoi(ev);
         launch_dec_lz(variant, (const uint8_t *)d_src, (const StreamIn *)c->d_streams.p,
                       (const StreamPlan *)c->d_plan.p, ns, (const BlockDesc *)c->d_blocks.p,
