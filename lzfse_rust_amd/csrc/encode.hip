@@ -214,6 +214,7 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
     __shared__ uint32_t q_i[4][256], q_c[4][256];  // per-wave work list of phase 3: position, candidate
     __shared__ uint16_t q_id[4][256], q_res[4][256];
     __shared__ uint32_t q_dist[4][256], q_tab[4][64];  // distance of a listed head; first head per distance hash
+    __shared__ uint32_t s_win[4][52];                  // per wave: 192 source bytes around its 64 positions (+ read slack)
     const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const uint32_t t = (slot / CAND_BPT) * 8 + xcd, bx = slot % CAND_BPT;
     if (t >= n_tiles) return;
@@ -231,6 +232,24 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
     const uint32_t max_total = valid ? n - i : 0;
     const uint32_t cap_total = max_total < FCAP ? max_total : FCAP;
     const uint32_t c1 = cap_total < CAND_C1 ? cap_total : CAND_C1;
+    // ---- source window of the wave: bytes [i0 - 32, i0 + 160) of the stream (i0 = position of lane 0) go to LDS
+    // with one coalesced load; every lane's own side of the byte compares (forward up to 64 + 16 bytes, backward
+    // up to 32) is read from there instead of 64 separate unaligned loads per step ----
+    {
+        const uint32_t i0 = i - (uint32_t)lane;
+        if (lane < 48) {
+            const int64_t pos = (int64_t)i0 - 32 + 4 * lane;
+            uint32_t wv4 = 0;
+            if (pos >= 0 && pos + 4 <= (int64_t)n) wv4 = ld_u32(s + pos);
+            else
+                for (int k = 0; k < 4; k++)
+                    if (pos + k >= 0 && pos + k < (int64_t)n) wv4 |= (uint32_t)s[pos + k] << (8 * k);
+            s_win[threadIdx.x >> 6][lane] = wv4;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    const uint32_t *win = s_win[threadIdx.x >> 6];
     // ---- phase 1: follow the chain (<= 4 dependent 8-byte gathers: next link + value) ----
     uint32_t cc[4] = {NONE, NONE, NONE, NONE};
     uint32_t ln[4] = {0, 0, 0, 0};
@@ -280,7 +299,12 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
             for (int k = 0; k < 4; k++) go[k] = act[k] && room;
             const uint4 zero4 = make_uint4(0, 0, 0, 0);
             uint4 a = zero4, bq[4] = {zero4, zero4, zero4, zero4};
-            if (go[0] || go[1] || go[2] || go[3]) a = ld_u128(s + i + off);
+            if (go[0] || go[1] || go[2] || go[3]) {
+                const uint32_t wo = 32u + (uint32_t)lane + off, q = wo >> 2, sh = (wo & 3) * 8;  // wo + 16 <= 32 + 63 + 52 + 16 < 192
+                const uint32_t d0 = win[q], d1 = win[q + 1], d2 = win[q + 2], d3 = win[q + 3], d4 = win[q + 4];
+                a = make_uint4(__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh),
+                               __builtin_amdgcn_alignbit(d3, d2, sh), __builtin_amdgcn_alignbit(d4, d3, sh));
+            }
 #pragma unroll
             for (int k = 0; k < 4; k++)
                 if (go[k]) bq[k] = ld_u128(s + cc[k] + off);
@@ -441,7 +465,21 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
         const bool bfol = best_len != 0 && lane > 0 && bd_lo == bd;
         const uint32_t bmax = best_idx < BCAP ? best_idx : BCAP;
         uint32_t bw = 0;
-        if (best_len && !bfol && !(dbg & 2)) bw = lcs_bwd(s, i, best_idx, bmax);
+        if (best_len && !bfol && !(dbg & 2)) {
+            // lcs_bwd with this position's side read from the window (8 bytes per step, at most BCAP = 32 back)
+            uint32_t len = 0;
+            bool open = true;
+            while (open && len + 8 <= bmax) {
+                const uint32_t wo = 32u + (uint32_t)lane - len - 8, q = wo >> 2, sh = (wo & 3) * 8;
+                const uint32_t d0 = win[q], d1 = win[q + 1], d2 = win[q + 2];
+                const uint64_t av = (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
+                const uint64_t x = av ^ ld_u64(s + best_idx - len - 8);
+                if (x) { len += (uint32_t)(__builtin_clzll(x) >> 3); open = false; }
+                else len += 8;
+            }
+            while (open && len < bmax && s[i - len - 1] == s[best_idx - len - 1]) len++;
+            bw = len;
+        }
         const uint64_t hm = __ballot(best_len != 0 && !bfol);
         if (__any(bfol)) {
             const uint64_t below = hm & lt_mask;
