@@ -810,7 +810,55 @@ __device__ __forceinline__ uint32_t d_sym_of(uint32_t v) {
     return 4 * q + r;
 }
 
-// weights.rs:218-278 (normalize_m1), run by one lane over a table in LDS
+// weights.rs:218-278 (normalize_m1) by one wave over a table in LDS (n <= 256, every lane must call): the scaling,
+// the total and the first strict maximum are lane-parallel; the common correction (the surplus fits a quarter of the
+// largest weight) is one update, the rare trimming loops (weights.rs:246-278) stay serial on lane 0.
+__device__ void normalize_m1_wave(uint16_t *w, uint32_t n, uint32_t in_total, uint32_t out_total) {
+    if (in_total == 0) return;
+    const int lane = e_lane();
+    const uint32_t shift = __builtin_clz(out_total);
+    const uint32_t multiply = (1u << 31) / in_total;
+    const uint32_t round = 1u << (shift - 1);
+    uint32_t sum = 0, best = 0;  // best = weight << 16 | (0xFFFF - index): max picks the largest weight, lowest index
+    for (uint32_t i = lane; i < n; i += 64) {
+        const uint32_t wi = w[i];
+        if (wi == 0) continue;
+        uint32_t f = (wi * multiply + round) >> shift;
+        if (f == 0) f = 1;
+        w[i] = (uint16_t)f;
+        sum += f;
+        const uint32_t key = (f << 16) | (0xFFFFu - i);
+        best = key > best ? key : best;
+    }
+#pragma unroll
+    for (int dd = 32; dd > 0; dd >>= 1) {
+        sum += __shfl_xor(sum, dd);
+        const uint32_t o = __shfl_xor(best, dd);
+        best = o > best ? o : best;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane != 0) return;
+    const uint32_t max_index = 0xFFFFu - (best & 0xFFFFu);
+    int32_t remaining = (int32_t)out_total - (int32_t)sum;
+    if (-remaining < (int32_t)w[max_index] / 4) {
+        w[max_index] = (uint16_t)((int32_t)w[max_index] + remaining);
+    } else {
+        uint32_t overflow = (uint32_t)(-remaining);
+        for (int s = 3; s >= 0; s--)
+            for (uint32_t i = 0; i < n; i++) {
+                if (overflow == 0) break;
+                uint32_t wi = w[i];
+                if (wi == 0) continue;
+                uint32_t k = (wi - 1) >> s;
+                if (k > overflow) k = overflow;
+                w[i] = (uint16_t)(wi - k);
+                overflow -= k;
+            }
+    }
+}
+
+// the same by one lane (kept for reference: the restatement closest to weights.rs:218-278)
 __device__ void normalize_m1(uint16_t *w, uint32_t n, uint32_t in_total, uint32_t out_total) {
     if (in_total == 0) return;
     uint32_t shift = __builtin_clz(out_total);
@@ -1061,10 +1109,10 @@ __global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *_
     __syncthreads();
     lap(1);
     // ---- normalize (one lane per table) ----
-    if (tid == 0 && blk.n_lmd) normalize_m1(wts, 20, blk.n_lmd, L_STATES);
-    if (tid == 64 && blk.n_lmd) normalize_m1(wts + 20, 20, blk.n_lmd, M_STATES);
-    if (tid == 128 && blk.n_lmd) normalize_m1(wts + 40, 64, blk.n_lmd, D_STATES);
-    if (tid == 192 && n_lit) normalize_m1(wts + 104, 256, n_lit, U_STATES);
+    if (wave == 0 && blk.n_lmd) normalize_m1_wave(wts, 20, blk.n_lmd, L_STATES);
+    if (wave == 1 && blk.n_lmd) normalize_m1_wave(wts + 20, 20, blk.n_lmd, M_STATES);
+    if (wave == 2 && blk.n_lmd) normalize_m1_wave(wts + 40, 64, blk.n_lmd, D_STATES);
+    if (wave == 3 && n_lit) normalize_m1_wave(wts + 104, 256, n_lit, U_STATES);
     __syncthreads();
     lap(2);
     // ---- weight payload (weight_encoder.rs:23-37, weights.rs:139-163) + E tables (encoder.rs:219-240) ----
