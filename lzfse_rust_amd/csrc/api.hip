@@ -569,7 +569,14 @@ int lzfse_mi_decode_batch_device(lzfse_mi_ctx *c, size_t count, const void *d_sr
 int lzfse_mi_encode_batch_device(lzfse_mi_ctx *c, size_t count, const void *d_src, const uint64_t *src_off,
                                  const uint64_t *src_len, void *d_dst, const uint64_t *dst_off,
                                  const uint64_t *dst_cap, uint64_t *out_lens, int *statuses) {
-    static const int lanes = lanes_of("LZFSE_MI_LANES_ENC", 2);
+    // two lanes, three from 512 MiB on (measured: +5 % at 752 MB, -4 % at 188 MB, where the lanes' tails dominate)
+    static const int lanes_env = getenv("LZFSE_MI_LANES_ENC") ? lanes_of("LZFSE_MI_LANES_ENC", 2) : 0;
+    int lanes = lanes_env;
+    if (!lanes) {
+        uint64_t total = 0;
+        for (size_t i = 0; src_len && i < count; i++) total += src_len[i];
+        lanes = total >= (512ull << 20) ? 3 : 2;
+    }
     return split_batch(c, encode_batch_device_one, lanes, getenv("LZFSE_MI_NO_STAGGER") == nullptr, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap, out_lens, statuses);
 }
 
