@@ -144,3 +144,62 @@ def test_encode_all_size_classes_through_api(ctx, oracle):
     assert all(e == 0 for e in st2)
     for r, o in zip(raws, dec):
         assert o.tobytes() == r
+
+
+def test_encode_random_structures_bit_exact(ctx, oracle):
+    """Property-style sweep: 160 streams of random length and random structure (noise, low-entropy noise, repeats
+    with mutations, periodic data, word soup, long runs) in one batch, every output equal to the oracle's."""
+    rng = np.random.default_rng(1234)
+    words = [bytes(rng.integers(97, 123, size=int(rng.integers(1, 12)), dtype=np.uint8)) for _ in range(500)]
+
+    def gen(kind, n):
+        if kind == 0:
+            return rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+        if kind == 1:
+            return (rng.integers(0, 4, size=n, dtype=np.uint8) * 37).astype(np.uint8).tobytes()
+        if kind == 2:
+            chunk = rng.integers(0, 256, size=int(rng.integers(5, 5000)), dtype=np.uint8)
+            a = np.tile(chunk, n // chunk.size + 1)[:n].copy()
+            idx = rng.integers(0, n, size=max(1, n // int(rng.integers(50, 5000))))
+            a[idx] ^= rng.integers(1, 256, size=idx.size, dtype=np.uint8)
+            return a.tobytes()
+        if kind == 3:
+            per = int(rng.integers(1, 70000))
+            return (bytes(rng.integers(0, 256, size=per, dtype=np.uint8)) * (n // per + 1))[:n]
+        if kind == 4:
+            out = bytearray()
+            while len(out) < n:
+                out += words[int(rng.integers(0, 500))] + b" "
+            return bytes(out[:n])
+        runs = bytearray()
+        while len(runs) < n:
+            runs += bytes([int(rng.integers(0, 256))]) * int(rng.integers(1, 3000))
+        return bytes(runs[:n])
+
+    raws = [gen(int(rng.integers(0, 6)), int(rng.integers(4097, 300000))) for _ in range(160)]
+    outs, st = ctx.encode_batch(raws)
+    assert all(e == 0 for e in st)
+    for r, o in zip(raws, outs):
+        assert o.tobytes() == oracle.encode(r), len(r)
+    dec, st2 = ctx.decode_batch([o.tobytes() for o in outs])
+    assert all(e == 0 for e in st2)
+    for r, o in zip(raws, dec):
+        assert o.tobytes() == r
+
+
+def test_encode_block_boundaries_bit_exact(ctx, oracle):
+    """Multi-block streams whose blocks close on the literal limit (noise), on the LMD limit (dense short matches),
+    inside over-long literal runs (L > 315) and inside over-long matches (M > 2 359): fse/buffer.rs:45-97."""
+    rng = np.random.default_rng(77)
+    noise = rng.integers(0, 256, size=1_300_000, dtype=np.uint8).tobytes()
+    dense = np.tile(rng.integers(0, 256, size=8, dtype=np.uint8), 200_000)
+    dense[::9] ^= rng.integers(1, 256, size=dense[::9].size, dtype=np.uint8)  # a mismatch every 9 bytes: ~10^5 tiny matches
+    long_runs = b"".join(bytes([int(rng.integers(0, 256))]) * int(rng.integers(2000, 9000)) for _ in range(300))
+    mixed = noise[:50_000] + long_runs[:400_000] + dense.tobytes()[:300_000] + noise[50_000:120_000] + bytes(250_000)
+    lit_runs = b"".join(rng.integers(0, 256, size=int(rng.integers(300, 700)), dtype=np.uint8).tobytes() + b"0123456789abcdef" * 3
+                        for _ in range(2500))
+    raws = [noise, dense.tobytes(), long_runs, mixed, lit_runs]
+    outs, st = ctx.encode_batch(raws)
+    assert all(e == 0 for e in st)
+    for r, o in zip(raws, outs):
+        assert o.tobytes() == oracle.encode(r), len(r)
