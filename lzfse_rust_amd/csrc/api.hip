@@ -358,9 +358,9 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
         if (h_walk[i].status) { statuses[i] = h_walk[i].status; p.skip = 1; p.n_blocks = 0; continue; }
         if (h_walk[i].raw_total > dst_cap[i]) { statuses[i] = LZFSE_MI_BUFFER_OVERFLOW; p.skip = 1; p.n_blocks = 0; continue; }
         nb += h_walk[i].n_blocks; nl += h_walk[i].n_lmds; nu += h_walk[i].n_lits;
-        // large streams: LZ stage by pointer jumping (origin indices are 32-bit over the whole batch)
+        // large streams: LZ stage by pointer jumping (origin indices are 31-bit over the whole batch, the top bit marks final bytes)
         const bool big = jump_mode < 0 ? h_walk[i].raw_total >= (2ull << 20) : jump_mode > 0;
-        if (big && h_walk[i].n_vxn == 0 && nj + h_walk[i].raw_total + 8 < 0xFFFFFFF0ull && h_walk[i].raw_total > 0) {
+        if (big && h_walk[i].n_vxn == 0 && nj + h_walk[i].raw_total + 8 < 0x7FFFFFF0ull && h_walk[i].raw_total > 0) {
             p.jump = 1; p.jbase = nj;
             nj += (h_walk[i].raw_total + 3) & ~3ull;
         }

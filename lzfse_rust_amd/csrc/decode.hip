@@ -856,6 +856,9 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
 // literal; chains of length n collapse in O(log n) rounds. The last pass gathers the bytes.
 
 constexpr int JUMP_THREADS = 256;
+// top bit of an origin: the index names a final byte (a literal, or the resolved end of a chain); such entries are
+// never visited again, so a round costs gathers only for the bytes that are still on a chain
+constexpr uint32_t JUMP_FINAL = 0x80000000u;
 
 // one workgroup per block: literals (and raw blocks) are written, origins initialised
 __global__ __launch_bounds__(JUMP_THREADS) void dec_jump_init_kernel(
@@ -878,7 +881,7 @@ __global__ __launch_bounds__(JUMP_THREADS) void dec_jump_init_kernel(
     const uint32_t o0 = (uint32_t)d.dst_rel;
     if (d.kind == KIND_RAW) {
         const uint8_t *p = src + d.src_pos + 8;
-        for (uint32_t i = tid; i < d.n_raw; i += JUMP_THREADS) { dst[o0 + i] = p[i]; org[o0 + i] = jb + o0 + i; }
+        for (uint32_t i = tid; i < d.n_raw; i += JUMP_THREADS) { dst[o0 + i] = p[i]; org[o0 + i] = (jb + o0 + i) | JUMP_FINAL; }
         return;
     }
     const BlockResult br = bres[b];
@@ -900,7 +903,7 @@ __global__ __launch_bounds__(JUMP_THREADS) void dec_jump_init_kernel(
         bad |= bad_d;
         const uint8_t *ls = blit + run_lit + ex_l;
         const bool l_long = l > 32, m_long = m > 32 && !bad_d;
-        if (!l_long) for (uint32_t k = 0; k < l; k++) { dst[o + k] = ls[k]; org[o + k] = jb + o + k; }
+        if (!l_long) for (uint32_t k = 0; k < l; k++) { dst[o + k] = ls[k]; org[o + k] = (jb + o + k) | JUMP_FINAL; }
         if (!m_long && !bad_d) for (uint32_t k = 0; k < m; k++) org[p + k] = jb + p + k - dd;
         // long runs: the whole wave works on one lane's run at a time
         uint64_t ql = __ballot(l_long);
@@ -909,7 +912,7 @@ __global__ __launch_bounds__(JUMP_THREADS) void dec_jump_init_kernel(
             const uint32_t qo = read_lane(o, L), qn = read_lane(l, L);
             const uint64_t qs = ((uint64_t)read_lane((uint32_t)((uintptr_t)ls >> 32), L) << 32) | read_lane((uint32_t)(uintptr_t)ls, L);
             const uint8_t *q_ls = (const uint8_t *)(uintptr_t)qs;
-            for (uint32_t k = lane; k < qn; k += 64) { dst[qo + k] = q_ls[k]; org[qo + k] = jb + qo + k; }
+            for (uint32_t k = lane; k < qn; k += 64) { dst[qo + k] = q_ls[k]; org[qo + k] = (jb + qo + k) | JUMP_FINAL; }
         }
         uint64_t qm = __ballot(m_long);
         while (qm) {
@@ -930,14 +933,16 @@ __global__ __launch_bounds__(256) void dec_jump_round_kernel(uint32_t *__restric
     bool changed = false;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
-        const uint32_t o = origin[q];
-        if (o == (uint32_t)q) continue;
-        uint32_t o1 = origin[o];
-        if (o1 == o) continue;
-        uint32_t o2 = origin[o1];
-        uint32_t o3 = origin[o2];
-        origin[q] = o3;
-        changed = true;
+        uint32_t cur = origin[q];
+        if (cur & JUMP_FINAL) continue;
+        // up to three hops; an entry carrying JUMP_FINAL holds the final byte of its chain (itself for a literal)
+#pragma unroll
+        for (int h = 0; h < 3; h++) {
+            cur = origin[cur];
+            if (cur & JUMP_FINAL) break;
+        }
+        origin[q] = cur;
+        if (!(cur & JUMP_FINAL)) changed = true;
     }
     if (__any(changed) && (threadIdx.x & 63) == 0) flags[round] = 1;
 }
@@ -962,7 +967,7 @@ __global__ __launch_bounds__(JUMP_THREADS) void dec_jump_apply_kernel(const Stre
         const uint32_t q = o0 + i;
         uint32_t w = 0;
         const uint32_t cnt = n - i < 4 ? n - i : 4;
-        for (uint32_t k = 0; k < cnt; k++) w |= (uint32_t)dst[org[q + k] - jb] << (8 * k);
+        for (uint32_t k = 0; k < cnt; k++) w |= (uint32_t)dst[(org[q + k] & ~JUMP_FINAL) - jb] << (8 * k);
         if (cnt == 4) __builtin_memcpy(dst + q, &w, 4);
         else for (uint32_t k = 0; k < cnt; k++) dst[q + k] = (uint8_t)(w >> (8 * k));
     }
