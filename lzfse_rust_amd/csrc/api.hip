@@ -412,6 +412,14 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
     HIP_TRY(hipMemcpyAsync(h_sres.data(), c->d_sres.p, ns * sizeof(StreamResult), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (hipGetLastError() != hipSuccess) return LZFSE_MI_IO;
+    if (getenv("LZFSE_MI_LZ_STATS") && nj) {
+        uint32_t hf[20] = {};
+        if (hipMemcpy(hf, d_jflags, sizeof hf, hipMemcpyDeviceToHost) == hipSuccess) {
+            fprintf(stderr, "jump rounds that still moved bytes:");
+            for (int r2 = 0; r2 < 17; r2++) fprintf(stderr, " %u", hf[r2]);
+            fprintf(stderr, "\n");
+        }
+    }
     if (getenv("LZFSE_MI_LZ_STATS")) {
         for (uint32_t i = 0; i < ns && i < 16; i++) {
             const StreamResult &q = h_sres[i];
