@@ -108,6 +108,13 @@ int lzfse_mi_decode_batch(lzfse_mi_ctx *ctx, size_t count, const uint8_t *const 
                           const size_t *lens, uint8_t *const *dsts, const size_t *caps,
                           size_t *out_lens, int *statuses);
 
+/* The u32 some error kinds carry (src/error/mod.rs:47 Error::BadBlock(magic); src/fse/error_kind.rs:12-21
+ * FseErrorKind::BadLmdCount(n_lmds), BadLiteralCount(n_literals)): value for stream `stream_index` of the LAST batch
+ * call on this context (index 0 for the single-stream calls); 0 when the stream's status carries none.
+ * VnErrorKind::BadPayloadCount(u32) (src/vn/error_kind.rs:11) is raised by the reference's encoder-side constructor
+ * only (vn/block.rs:16-22) and cannot occur on this path. */
+int lzfse_mi_last_error_detail(lzfse_mi_ctx *ctx, size_t stream_index, uint32_t *detail);
+
 /* ---- device-resident entry points (inputs and outputs already in HBM) ----------------- */
 /* Stream i reads d_src[src_off[i] .. src_off[i] + src_len[i]) and writes at
  * d_dst[dst_off[i] ..], at most dst_cap[i] bytes. Offset/length arrays are HOST arrays.

@@ -19,6 +19,7 @@ _SYMBOLS = [
     "lzfse_mi_encode_bound", "lzfse_mi_encode", "lzfse_mi_decode", "lzfse_mi_decode_size",
     "lzfse_mi_encode_batch", "lzfse_mi_decode_batch", "lzfse_mi_decode_batch_device",
     "lzfse_mi_encode_batch_device", "lzfse_mi_enable_timing", "lzfse_mi_get_timings", "lzfse_mi_encode_small",
+    "lzfse_mi_last_error_detail",
 ]
 
 
@@ -61,6 +62,8 @@ def lib():
         f = getattr(L, name)
         f.restype = C.c_int
         f.argtypes = [vp, sz, vp, u64p, u64p, vp, u64p, u64p, u64p, ip]
+    L.lzfse_mi_last_error_detail.restype = C.c_int
+    L.lzfse_mi_last_error_detail.argtypes = [vp, sz, C.POINTER(C.c_uint32)]
     L.lzfse_mi_enable_timing.restype = C.c_int
     L.lzfse_mi_enable_timing.argtypes = [vp, C.c_int]
     L.lzfse_mi_get_timings.restype = C.c_int

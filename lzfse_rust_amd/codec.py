@@ -20,10 +20,11 @@ OK = 0
 class LzfseError(Exception):
     """crate::Error (src/error/mod.rs:40-61) / io::Error for the encoder."""
 
-    def __init__(self, status):
+    def __init__(self, status, detail=0):
         self.status = int(status)
+        self.detail = int(detail)  # BadBlock(magic) / BadLmdCount(n) / BadLiteralCount(n), else 0
         msg = _native.lib().lzfse_mi_status_string(self.status).decode()
-        super().__init__(f"lzfse status {self.status}: {msg}")
+        super().__init__(f"lzfse status {self.status}: {msg}" + (f" (0x{self.detail:08X})" if self.detail else ""))
 
 
 def _check(st):
@@ -64,6 +65,12 @@ class Context:
         _check(self._lib.lzfse_mi_get_timings(self._h, C.byref(t)))
         return {t.names[i].decode(): (float(t.ms[i]), int(t.launches[i])) for i in range(t.n_stages)}
 
+    def error_detail(self, stream_index=0):
+        """u32 payload of Error::BadBlock / FseErrorKind::BadLmdCount / BadLiteralCount for a stream of the last call."""
+        v = C.c_uint32(0)
+        _check(self._lib.lzfse_mi_last_error_detail(self._h, int(stream_index), C.byref(v)))
+        return v.value
+
     # -- host-pointer batch --
     def _host_batch(self, fn, srcs, caps):
         n = len(srcs)
@@ -84,7 +91,7 @@ class Context:
 
     def decode_batch(self, srcs, caps=None):
         if caps is None:
-            caps = [decode_size(s) for s in srcs]
+            caps = [decode_size(s, partial=True) for s in srcs]
         return self._host_batch(self._lib.lzfse_mi_decode_batch, srcs, caps)
 
     # -- device-resident batch: raw device pointers (e.g. torch tensor.data_ptr()) --
@@ -124,11 +131,14 @@ def encode_bound(n):
     return _native.lib().lzfse_mi_encode_bound(int(n))
 
 
-def decode_size(src):
-    """decode::probe: sum of n_raw_bytes over the block headers (src/decode/probe.rs:11-35)."""
+def decode_size(src, partial=False):
+    """decode::probe: sum of n_raw_bytes over the block headers (src/decode/probe.rs:11-35). partial=True: no raise on
+    a header-level error; the size of the blocks before it (what the decoder needs to reach the reference's error)."""
     a = np.frombuffer(bytes(src) if not isinstance(src, np.ndarray) else src, dtype=np.uint8)
     v = C.c_uint64(0)
-    _check(_native.lib().lzfse_mi_decode_size(a.ctypes.data if a.size else None, a.size, C.byref(v)))
+    st = _native.lib().lzfse_mi_decode_size(a.ctypes.data if a.size else None, a.size, C.byref(v))
+    if not partial:
+        _check(st)
     return v.value
 
 
@@ -155,7 +165,8 @@ class LzfseDecoder:
     def decode_bytes(self, src, dst):
         """Appends the decoded bytes of stream `src` to bytearray `dst`; returns bytes appended."""
         outs, st = self._ctx.decode_batch([src])
-        _check(st[0])
+        if st[0] != OK:
+            raise LzfseError(st[0], self._ctx.error_detail(0))
         dst += outs[0].tobytes()
         return len(outs[0])
 

@@ -83,6 +83,9 @@ struct lzfse_mi_ctx {
     lzmi::LaneGate *gate_in = nullptr, *gate_out = nullptr;  // set per lane for the duration of a split encode
     hipEvent_t split_ev = nullptr;
     int last_split = 0;  // helper lanes used by the last batch call
+    // u32 payload of the error kinds that carry one (Error::BadBlock(magic), FseErrorKind::BadLmdCount(n) /
+    // BadLiteralCount(n)): per stream of the last sub-batch run on this context / of the last API call
+    std::vector<uint32_t> detail, detail_out;
 
     hipEvent_t get_event() {
         if (ev_used == ev_pool.size()) {
@@ -127,7 +130,7 @@ static void timing_end(lzfse_mi_ctx *c) {
         if (hipEventElapsedTime(&ms, sp.a, sp.b) != hipSuccess) continue;
         int k = -1;
         for (int i = 0; i < t.n_stages; i++)
-            if (t.names[i] == sp.name) k = i;
+            if (t.names[i] == sp.name || !strcmp(t.names[i], sp.name)) k = i;
         if (k < 0) {
             if (t.n_stages == LZFSE_MI_MAX_STAGES) continue;
             k = t.n_stages++;
@@ -242,7 +245,7 @@ int lzfse_mi_get_timings(lzfse_mi_ctx *c, lzfse_mi_timings *out) {
         for (int j = 0; j < s.n_stages; j++) {
             int k = -1;
             for (int i = 0; i < out->n_stages; i++)
-                if (out->names[i] == s.names[j]) k = i;
+                if (out->names[i] == s.names[j] || !strcmp(out->names[i], s.names[j])) k = i;
             if (k < 0) {
                 if (out->n_stages == LZFSE_MI_MAX_STAGES) continue;
                 k = out->n_stages++;
@@ -256,44 +259,57 @@ int lzfse_mi_get_timings(lzfse_mi_ctx *c, lzfse_mi_timings *out) {
     return LZFSE_MI_OK;
 }
 
-// decode/probe.rs:11-35 on the host (pure header arithmetic, no payload is touched)
+// decode/probe.rs:11-35 on the host (pure header arithmetic, no payload is touched). On a header-level error *raw_len
+// still receives the raw size of the blocks before it: enough capacity for lzfse_mi_decode to reach the error the
+// reference would report (an error inside an earlier block comes first, decoder.rs:76-99).
 int lzfse_mi_decode_size(const uint8_t *src, size_t n, uint64_t *raw_len) {
     if ((!src && n) || !raw_len) return LZFSE_MI_BAD_ARGUMENT;
     size_t pos = 0;
     uint64_t total = 0;
+    int rc = LZFSE_MI_OK;
     for (;;) {
-        if (n - pos < 4) return LZFSE_MI_PAYLOAD_UNDERFLOW;
+        if (n - pos < 4) { rc = LZFSE_MI_PAYLOAD_UNDERFLOW; break; }
         uint32_t magic = ld_u32(src + pos);
         size_t avail = n - pos;
         uint64_t skip;
         uint32_t n_raw;
-        if (magic == MAGIC_EOS) break;
+        if (magic == MAGIC_EOS) {
+            if (avail != 4) rc = LZFSE_MI_PAYLOAD_OVERFLOW;
+            break;
+        }
         if (magic == MAGIC_VX2 || magic == MAGIC_VX1) {
             bool v1 = magic == MAGIC_VX1;
-            if (avail < (v1 ? V1_HEADER_SIZE : V2_HEADER_SIZE)) return LZFSE_MI_PAYLOAD_UNDERFLOW;
+            if (avail < (v1 ? V1_HEADER_SIZE : V2_HEADER_SIZE)) { rc = LZFSE_MI_PAYLOAD_UNDERFLOW; break; }
             FseHeader h;
             int e = v1 ? fse_load_v1(src + pos, h) : fse_load_v2(src + pos, h);
-            if (e) return e;
+            if (e) { rc = e; break; }
             skip = (uint64_t)h.hdr_size + h.lit_payload + h.lmd_payload;
             n_raw = h.n_raw;
         } else if (magic == MAGIC_VXN) {
-            if (avail < 12) return LZFSE_MI_PAYLOAD_UNDERFLOW;
+            if (avail < 12) { rc = LZFSE_MI_PAYLOAD_UNDERFLOW; break; }
             n_raw = ld_u32(src + pos + 4);
             skip = 12ull + ld_u32(src + pos + 8);
         } else if (magic == MAGIC_RAW) {
-            if (avail < 8) return LZFSE_MI_PAYLOAD_UNDERFLOW;
+            if (avail < 8) { rc = LZFSE_MI_PAYLOAD_UNDERFLOW; break; }
             n_raw = ld_u32(src + pos + 4);
             skip = 8ull + n_raw;
         } else {
-            return LZFSE_MI_BAD_BLOCK;
+            rc = LZFSE_MI_BAD_BLOCK;
+            break;
         }
-        if (skip >= avail) return LZFSE_MI_PAYLOAD_UNDERFLOW;
+        if (skip >= avail) {
+            // cut short: a bvx1 / bvx2 / bvxn block is still decoded as far as it goes (its own errors come first)
+            // (an LZVN op byte yields at most 271 / 2 output bytes, so a cut block cannot produce more than 136 x avail)
+            if (magic == MAGIC_VXN) total += std::min<uint64_t>(n_raw, 136ull * avail);
+            else if (magic != MAGIC_RAW) total += n_raw;
+            rc = LZFSE_MI_PAYLOAD_UNDERFLOW;
+            break;
+        }
         pos += (size_t)skip;
         total += n_raw;
     }
-    if (n - pos != 4) return LZFSE_MI_PAYLOAD_OVERFLOW;
     *raw_len = total;
-    return LZFSE_MI_OK;
+    return rc;
 }
 
 // ---------------------------------------------------------------------------- decode (device)
@@ -344,7 +360,7 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
     if (jump_mode < 0) {
         uint64_t el_bytes = 0, el_max = 0;
         for (uint32_t i = 0; i < ns; i++) {
-            if (h_walk[i].status || h_walk[i].raw_total > dst_cap[i] || h_walk[i].n_vxn != 0) continue;
+            if (h_walk[i].raw_total > dst_cap[i] || h_walk[i].n_vxn != 0) continue;
             if (h_walk[i].raw_total >= (2ull << 20)) { el_bytes += h_walk[i].raw_total; el_max = std::max<uint64_t>(el_max, h_walk[i].raw_total); }
         }
         if (el_max * 42 <= el_bytes) jump_mode = 0;
@@ -355,12 +371,16 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
         p.jbase = 0; p.jump = 0; p.pad = 0;
         statuses[i] = LZFSE_MI_OK;
         out_lens[i] = 0;
-        if (h_walk[i].status) { statuses[i] = h_walk[i].status; p.skip = 1; p.n_blocks = 0; continue; }
-        if (h_walk[i].raw_total > dst_cap[i]) { statuses[i] = LZFSE_MI_BUFFER_OVERFLOW; p.skip = 1; p.n_blocks = 0; continue; }
+        // A stream whose walk failed at block k still has its first k blocks decoded: the reference decodes in order, so
+        // an error inside one of them is the one it reports (decoder.rs:76-99); otherwise the walk's status stands.
+        if (h_walk[i].status && h_walk[i].n_blocks == 0) { statuses[i] = h_walk[i].status; p.skip = 1; p.n_blocks = 0; continue; }
+        // (a stream whose headers promise more than dst_cap is decoded block by block up to the one that does not fit:
+        // the header counts of a damaged stream are not to be trusted, and the first error in stream order wins)
         nb += h_walk[i].n_blocks; nl += h_walk[i].n_lmds; nu += h_walk[i].n_lits;
         // large streams: LZ stage by pointer jumping (origin indices are 31-bit over the whole batch, the top bit marks final bytes)
         const bool big = jump_mode < 0 ? h_walk[i].raw_total >= (2ull << 20) : jump_mode > 0;
-        if (big && h_walk[i].n_vxn == 0 && nj + h_walk[i].raw_total + 8 < 0x7FFFFFF0ull && h_walk[i].raw_total > 0) {
+        if (big && h_walk[i].n_vxn == 0 && nj + h_walk[i].raw_total + 8 < 0x7FFFFFF0ull && h_walk[i].raw_total > 0 &&
+            h_walk[i].raw_total <= dst_cap[i]) {
             p.jump = 1; p.jbase = nj;
             nj += (h_walk[i].raw_total + 3) & ~3ull;
         }
@@ -431,9 +451,14 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
     }
     for (uint32_t i = 0; i < ns; i++) {
         if (h_plan[i].skip) continue;
-        statuses[i] = h_sres[i].status;
-        out_lens[i] = h_sres[i].status ? 0 : h_sres[i].out_len;
+        statuses[i] = h_sres[i].status ? h_sres[i].status : h_walk[i].status;
+        out_lens[i] = statuses[i] ? 0 : h_sres[i].out_len;
     }
+    c->detail.assign(ns, 0u);
+    for (uint32_t i = 0; i < ns; i++)
+        if (statuses[i] && statuses[i] == h_walk[i].status &&
+            (statuses[i] == LZFSE_MI_BAD_BLOCK || statuses[i] == LZFSE_MI_FSE_BAD_LMD_COUNT || statuses[i] == LZFSE_MI_FSE_BAD_LITERAL_COUNT))
+            c->detail[i] = h_walk[i].detail;
     timing_end(c);
     return LZFSE_MI_OK;
 }
@@ -446,6 +471,7 @@ static int encode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
     if (count == 0) return LZFSE_MI_OK;
     if (count > 0x7FFFFFFFu) return LZFSE_MI_BAD_ARGUMENT;
     HIP_TRY(hipSetDevice(c->device));
+    c->detail.assign(count, 0u);
     timing_begin(c);
     int r = enc_batch_device(c, (uint32_t)count, (const uint8_t *)d_src, src_off, src_len, (uint8_t *)d_dst,
                              dst_off, dst_cap, out_lens, statuses);
@@ -492,14 +518,18 @@ static int split_batch(lzfse_mi_ctx *c, batch_dev_fn one, int lanes, bool stagge
     static const bool no_split = getenv("LZFSE_MI_NO_SPLIT") != nullptr;
     if (lanes > LZFSE_MI_MAX_LANES) lanes = LZFSE_MI_MAX_LANES;
     while (lanes > 1 && (count < (size_t)4 * lanes || total < ((uint64_t)lanes << 21))) lanes--;
-    if (no_split || lanes < 2 || !src_off || !dst_off || !dst_cap || !out_lens || !statuses)
-        return one(c, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap, out_lens, statuses);
+    auto unsplit = [&]() {
+        c->detail.clear();
+        const int r = one(c, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap, out_lens, statuses);
+        c->detail_out = c->detail;
+        return r;
+    };
+    if (no_split || lanes < 2 || !src_off || !dst_off || !dst_cap || !out_lens || !statuses) return unsplit();
     if (hipSetDevice(c->device) != hipSuccess) return LZFSE_MI_IO;
     if (!c->split_ev && hipEventCreateWithFlags(&c->split_ev, hipEventDisableTiming) != hipSuccess) c->split_ev = nullptr;
     for (int k = 0; k + 1 < lanes; k++)
         if (!c->shadow[k] && lzfse_mi_create(c->device, &c->shadow[k]) != LZFSE_MI_OK) { c->shadow[k] = nullptr; lanes = k + 1; break; }
-    if (lanes < 2 || !c->split_ev)
-        return one(c, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap, out_lens, statuses);
+    if (lanes < 2 || !c->split_ev) return unsplit();
     struct Part {
         std::vector<size_t> idx;
         std::vector<uint64_t> so, sl, dof, dc, ol;
@@ -524,7 +554,7 @@ static int split_batch(lzfse_mi_ctx *c, batch_dev_fn one, int lanes, bool stagge
         ok = hipStreamWaitEvent(c->shadow[k]->stream, c->split_ev, 0) == hipSuccess;
         c->shadow[k]->timing = c->timing;
     }
-    if (!ok) return one(c, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap, out_lens, statuses);
+    if (!ok) return unsplit();
     // staggered start (encode): lane k + 1 begins when lane k has queued its candidate kernel
     for (int k = 0; stagger && k + 1 < lanes; k++) {
         lzmi::LaneGate &g = c->gates[k];
@@ -536,8 +566,11 @@ static int split_batch(lzfse_mi_ctx *c, batch_dev_fn one, int lanes, bool stagge
         cx->gate_out = (stagger && k + 1 < lanes) ? &c->gates[k] : nullptr;
         if (cx->gate_out) cx->gate_out->state.store(0);
     }
+    c->detail_out.assign(count, 0u);
     auto run = [&](lzfse_mi_ctx *cx, Part &p) {
+        cx->detail.clear();
         p.rc = one(cx, p.idx.size(), d_src, p.so.data(), p.sl.data(), d_dst, p.dof.data(), p.dc.data(), p.ol.data(), p.st.data());
+        for (size_t k = 0; k < p.idx.size() && k < cx->detail.size(); k++) c->detail_out[p.idx[k]] = cx->detail[k];
     };
     std::vector<std::thread> helpers;
     size_t started = 0;
@@ -635,6 +668,12 @@ int lzfse_mi_decode_batch(lzfse_mi_ctx *c, size_t count, const uint8_t *const *s
 int lzfse_mi_encode_batch(lzfse_mi_ctx *c, size_t count, const uint8_t *const *srcs, const size_t *lens,
                           uint8_t *const *dsts, const size_t *caps, size_t *out_lens, int *statuses) {
     return host_batch(c, lzfse_mi_encode_batch_device, count, srcs, lens, dsts, caps, out_lens, statuses);
+}
+
+int lzfse_mi_last_error_detail(lzfse_mi_ctx *c, size_t stream_index, uint32_t *detail) {
+    if (!c || !detail) return LZFSE_MI_BAD_ARGUMENT;
+    *detail = stream_index < c->detail_out.size() ? c->detail_out[stream_index] : 0u;
+    return LZFSE_MI_OK;
 }
 
 int lzfse_mi_decode(lzfse_mi_ctx *c, const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *out_len) {

@@ -41,6 +41,8 @@ struct StreamWalk {
     int32_t status;      // first header-level error (0 = walk reached bvx$ cleanly)
     uint32_t err_block;  // block index at which `status` was raised
     uint32_t n_vxn;      // number of bvxn blocks (decoded serially by the tile LZ kernel)
+    uint32_t detail;     // payload of the error kind: BadBlock(magic), BadLmdCount(num), BadLiteralCount(num)
+    uint32_t pad;
 };
 
 // Per-stream bases assigned by the host after the counting walk.
@@ -65,7 +67,10 @@ struct BlockDesc {
 
 struct BlockResult {
     int32_t status;
-    uint32_t sum_l, sum_m, pad;
+    uint32_t sum_l, sum_m;
+    // status != 0 only: number of LMDs the reference's decode loop (fse_core.rs:103-131) gets through before this
+    // status is raised (0 for everything raised before the loop). A bad D among them is raised first (BadDValue).
+    uint32_t ok_until;
 };
 
 struct StreamResult {

@@ -64,7 +64,7 @@ __global__ void dec_walk_kernel(const uint8_t *__restrict__ src, const StreamIn 
     const uint8_t *base = src + in.src_off;
     uint64_t n = in.src_len, pos = 0;
     StreamWalk w;
-    w.n_lmds = 0; w.n_lits = 0; w.raw_total = 0; w.n_blocks = 0; w.status = 0; w.err_block = 0; w.n_vxn = 0;
+    w.n_lmds = 0; w.n_lits = 0; w.raw_total = 0; w.n_blocks = 0; w.status = 0; w.err_block = 0; w.n_vxn = 0; w.detail = 0; w.pad = 0;
     uint64_t blk_i = 0, lmd_i = 0, lit_i = 0;
     if (EMIT) { blk_i = plan[s].blk_base; lmd_i = plan[s].lmd_base; lit_i = plan[s].lit_base; }
     uint32_t max_blocks = EMIT ? plan[s].n_blocks : 0xFFFFFFFFu;
@@ -84,16 +84,22 @@ __global__ void dec_walk_kernel(const uint8_t *__restrict__ src, const StreamIn 
         d.src_pos = in.src_off + pos; d.src_end = in.src_off + n; d.dst_rel = w.raw_total;
         d.lmd_base = lmd_i; d.lit_base = lit_i; d.stream = s;
         d.n_lmd = 0; d.n_lit = 0; d.n_raw = 0; d.payload = 0;
-        uint64_t skip;
+        uint64_t skip = 0;
         int st = 0;
+        // A block whose header is sound but whose payload runs past the end of the stream is still emitted (and the walk
+        // ends there): the reference takes the payload piece by piece (decoder.rs:102-157), so an error inside the part
+        // that is present (weights, literals, an LZVN opcode) comes before the PayloadUnderflow of the missing part.
+        bool truncated = false;
         if (magic == MAGIC_VX2 || magic == MAGIC_VX1) {
             FseHeader h;
             bool v1 = magic == MAGIC_VX1;
             if (avail < (v1 ? V1_HEADER_SIZE : V2_HEADER_SIZE)) st = LZFSE_MI_PAYLOAD_UNDERFLOW;
             else st = v1 ? fse_load_v1(base + pos, h) : fse_parse_v2(q0, q1, q2, q3, h);
+            if (st == LZFSE_MI_FSE_BAD_LMD_COUNT) w.detail = h.lmd_num;          // FseErrorKind::BadLmdCount(num)
+            if (st == LZFSE_MI_FSE_BAD_LITERAL_COUNT) w.detail = h.lit_num;      // FseErrorKind::BadLiteralCount(num)
             if (!st) {
                 skip = (uint64_t)h.hdr_size + h.lit_payload + h.lmd_payload;
-                if (skip > avail) st = LZFSE_MI_PAYLOAD_UNDERFLOW;  // decode/take.rs:10-19
+                truncated = skip > avail;  // decode/take.rs:10-19
                 d.kind = v1 ? KIND_VX1 : KIND_VX2;
                 d.n_lmd = h.lmd_num; d.n_lit = h.lit_num; d.n_raw = h.n_raw;
             }
@@ -105,7 +111,7 @@ __global__ void dec_walk_kernel(const uint8_t *__restrict__ src, const StreamIn 
                 d.n_raw = ld_u32(base + pos + 4);
                 d.payload = ld_u32(base + pos + 8);
                 skip = 12ull + d.payload;
-                if (skip > avail) st = LZFSE_MI_PAYLOAD_UNDERFLOW;
+                truncated = skip > avail;
             }
         } else if (magic == MAGIC_RAW) {
             if (avail < 8) st = LZFSE_MI_PAYLOAD_UNDERFLOW;
@@ -117,6 +123,7 @@ __global__ void dec_walk_kernel(const uint8_t *__restrict__ src, const StreamIn 
             }
         } else {
             st = LZFSE_MI_BAD_BLOCK;
+            w.detail = magic;  // Error::BadBlock(magic)
         }
         if (st) { w.status = st; w.err_block = w.n_blocks; break; }
         if (EMIT) {
@@ -133,7 +140,9 @@ __global__ void dec_walk_kernel(const uint8_t *__restrict__ src, const StreamIn 
         w.n_blocks++;
         w.n_lmds += d.n_lmd; lmd_i += d.n_lmd;
         w.n_lits += d.n_lit; lit_i += d.n_lit;
-        w.raw_total += d.n_raw;
+        // (a cut bvxn block produces at most 136 bytes per payload byte present; its header's count is not to be trusted)
+        w.raw_total += (truncated && d.kind == KIND_VXN && 136ull * avail < d.n_raw) ? 136ull * avail : d.n_raw;
+        if (truncated) { w.status = LZFSE_MI_PAYLOAD_UNDERFLOW; w.err_block = w.n_blocks; break; }
         pos += skip;
     }
     if (!EMIT) {
@@ -257,7 +266,7 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
     __shared__ uint32_t stg_lmd[64 * 3 + 1];  // 64 steps of (L, M, D) values, + one dump slot for the idle lanes
     __shared__ __attribute__((aligned(4))) uint8_t stg_lit[64 * 4 + 4];   // 64 groups of four literals, + dump slot
     __shared__ int sh_status[2];
-    __shared__ uint32_t sh_sums[2];
+    __shared__ uint32_t sh_sums[3];
 
     const uint32_t b = blockIdx.x;
     if (b >= n_blocks) return;
@@ -269,7 +278,13 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
 
     FseHeader h;
     int st = d.kind == KIND_VX1 ? fse_load_v1(p, h) : fse_load_v2(p, h);  // validated by the walk
-    if (st) { if (tid == 0) { results[b].status = st; } return; }
+    // the last block of a stream may be cut short (the walk emits it all the same): the reference takes header + weights,
+    // literal payload and LMD payload one after the other, each with its own PayloadUnderflow (decoder.rs:102-141)
+    const uint64_t avail = d.src_end - d.src_pos;
+    if (!st && avail < h.hdr_size) st = LZFSE_MI_PAYLOAD_UNDERFLOW;
+    if (st) { if (tid == 0) { BlockResult r; r.status = st; r.sum_l = 0; r.sum_m = 0; r.ok_until = 0; results[b] = r; } return; }
+    const bool lit_short = avail < (uint64_t)h.hdr_size + h.lit_payload;
+    const bool lmd_short = avail < (uint64_t)h.hdr_size + h.lit_payload + h.lmd_payload;
     if (tid < 2) sh_status[tid] = 0;
 
     // ---- weights (weights.rs:66-105) ----
@@ -344,7 +359,7 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
             sh_status[0] = LZFSE_MI_FSE_BAD_WEIGHT_PAYLOAD;
     }
     __syncthreads();
-    if (sh_status[0]) { if (tid == 0) results[b].status = sh_status[0]; return; }
+    if (sh_status[0]) { if (tid == 0) { BlockResult r; r.status = sh_status[0]; r.sum_l = 0; r.sum_m = 0; r.ok_until = 0; results[b] = r; } return; }
 
     // ---- decode tables (decoder.rs:244-335): per state, binary search the owning symbol ----
     for (uint32_t t = tid; t < U_STATES; t += FSE_THREADS) {
@@ -406,7 +421,8 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
     if (wave == 1) {
         // literals.rs:49-91: four interleaved states in lanes 0..3, shared cursor
         BitWindow w;
-        int e = bw_init(w, p + lit_off, h.lit_payload + 8, h.lit_bits, glo, ghi, ring[1]);
+        int e = lit_short ? LZFSE_MI_PAYLOAD_UNDERFLOW : bw_init(w, p + lit_off, h.lit_payload + 8, h.lit_bits, glo, ghi, ring[1]);
+        if (lit_short) { w.rem = 0; w.base_bit = 0; w.cb = 0; w.buf = ring[1]; w.ga = glo; w.glo = glo; w.ghi = glo; w.pend = 0; }
         const int q4 = lane & 3;
         uint32_t state = q4 == 0 ? h.lit_state[0] : q4 == 1 ? h.lit_state[1] : q4 == 2 ? h.lit_state[2] : h.lit_state[3];
         uint8_t *out = lit_out + d.lit_base;
@@ -415,7 +431,7 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
         // exec masking), and every 64 groups the wave stores 64 dwords coalesced: two instructions per step.
         const uint32_t s_home = lane < 4 ? (uint32_t)lane : 256u, s_inc = lane < 4 ? 4u : 0u;
         uint32_t sidx = s_home;
-        uint64_t win = bw_window(w);
+        uint64_t win = n_groups ? bw_window(w) : 0;
         for (uint32_t g = 0; g < n_groups; g++) {
             const uint32_t ent = u_tab[state];
             const uint32_t k = ent & 0xFF;
@@ -444,7 +460,8 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
     } else {
         // fse_core.rs:91-141 (entropy part): L, M, D in lanes 0, 1, 2
         BitWindow w;
-        int e = bw_init(w, p + lmd_off, h.lmd_payload, h.lmd_bits, glo, ghi, ring[0]);
+        int e = lmd_short ? LZFSE_MI_PAYLOAD_UNDERFLOW : bw_init(w, p + lmd_off, h.lmd_payload, h.lmd_bits, glo, ghi, ring[0]);
+        if (lmd_short) { w.rem = 0; w.base_bit = 0; w.cb = 0; w.buf = ring[0]; w.ga = glo; w.glo = glo; w.ghi = glo; w.pend = 0; }
         const int li = lane < 2 ? lane : 2;
         uint32_t state = li == 0 ? h.lmd_state[0] : li == 1 ? h.lmd_state[1] : h.lmd_state[2];
         const uint32_t tbase = li == 0 ? 0u : (li == 1 ? 64u : 128u);
@@ -456,7 +473,8 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
         // the sums of L and M accumulate per lane, and the records are stored coalesced.
         const uint32_t s_home = lane < 3 ? (uint32_t)lane : 192u, s_inc = lane < 3 ? 3u : 0u;
         uint32_t sidx = s_home;
-        uint32_t acc_l = 0, acc_m = 0, carry_d = 0;
+        uint32_t cum_l = 0, acc_m = 0, carry_d = 0;   // cum_l: literals consumed so far (uniform)
+        uint32_t lit_over = 0xFFFFFFFFu;              // first LMD whose literals run past LITERALS_PER_BLOCK (fse_core.rs:119-128)
         auto flush = [&](uint32_t base, uint32_t cnt) {
             const bool have = (uint32_t)lane < cnt;
             const uint32_t vl = have ? stg_lmd[3 * lane] : 0u, vm = have ? stg_lmd[3 * lane + 1] : 0u, vd = have ? stg_lmd[3 * lane + 2] : 0u;
@@ -465,10 +483,14 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
             const uint32_t from = __shfl(vd, upto ? 63 - __builtin_clzll(upto) : lane);
             const uint32_t dv = upto ? from : carry_d;
             if (have) out[base + lane] = make_uint2(vl | (vm << 16), dv);
-            acc_l += vl; acc_m += vm;
+            const uint32_t il = wave_incl_scan(vl);
+            const uint64_t ov = __ballot(have && cum_l + il > LITERALS_PER_BLOCK);
+            if (ov && lit_over == 0xFFFFFFFFu) lit_over = base + (uint32_t)__builtin_ctzll(ov);
+            cum_l += read_lane(il, 63);
+            acc_m += vm;
             if (nz) carry_d = read_lane(vd, 63 - __builtin_clzll(nz));
         };
-        uint64_t win = bw_window(w);
+        uint64_t win = n ? bw_window(w) : 0;
         for (uint32_t i = 0; i < n; i++) {
             const uint2 ent = v_tab[tbase + state];
             const uint32_t k = ent.x & 0xFF, vb = (ent.x >> 8) & 0xFF;
@@ -488,27 +510,31 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
             if ((i & 63) == 63) { flush(i & ~63u, 64); sidx = s_home; }
         }
         if (n & 63) flush(n & ~63u, n & 63);
-        uint32_t acc_sum = 0;  // lane 0: sum of L, lane 1: sum of M (wave totals)
-        {
-            uint32_t tl = acc_l, tm = acc_m;
+        uint32_t sum_m = acc_m;
 #pragma unroll
-            for (int dd = 32; dd > 0; dd >>= 1) { tl += __shfl_xor(tl, dd); tm += __shfl_xor(tm, dd); }
-            acc_sum = lane == 0 ? tl : tm;
+        for (int dd = 32; dd > 0; dd >>= 1) sum_m += __shfl_xor(sum_m, dd);
+        const uint32_t sum_l = cum_l;
+        // order of the reference (fse_core.rs:91-141): reader init, then per LMD the literal_index test (and the match
+        // copy, whose BadDValue the LZ stage raises for the first ok_until LMDs), then reader.finalize, then the totals
+        uint32_t ok_until = 0;
+        if (!e) {
+            if (lit_over != 0xFFFFFFFFu) { e = LZFSE_MI_FSE_BAD_LMD_PAYLOAD; ok_until = lit_over; }
+            else {
+                ok_until = n;
+                e = bw_finalize(w);
+                const uint32_t s0 = read_lane(state, 0) | read_lane(state, 1) | read_lane(state, 2);
+                if (!e && !(sum_l <= h.lit_num && sum_l + sum_m == h.n_raw && s0 == 0)) e = LZFSE_MI_FSE_BAD_LMD_PAYLOAD;
+            }
         }
-        if (!e) e = bw_finalize(w);
-        const uint32_t sum_l = read_lane(acc_sum, 0), sum_m = read_lane(acc_sum, 1);
-        uint32_t s0 = read_lane(state, 0) | read_lane(state, 1) | read_lane(state, 2);
-        // fse_core.rs:119-140: the running literal_index > 40 000 test is monotone, so it is applied to the sum
-        if (!e && !(sum_l <= h.lit_num && sum_l <= LITERALS_PER_BLOCK && sum_l + sum_m == h.n_raw && s0 == 0))
-            e = LZFSE_MI_FSE_BAD_LMD_PAYLOAD;
-        if (lane == 0) { sh_status[0] = e; sh_sums[0] = sum_l; sh_sums[1] = sum_m; }
+        if (lane == 0) { sh_status[0] = e; sh_sums[0] = sum_l; sh_sums[1] = sum_m; sh_sums[2] = ok_until; }
     }
     __syncthreads();
     if (tid == 0) {
         BlockResult r;
         // literals are loaded before the LMD stream is touched (decoder.rs:127-141)
         r.status = sh_status[1] ? sh_status[1] : sh_status[0];
-        r.sum_l = sh_sums[0]; r.sum_m = sh_sums[1]; r.pad = 0;
+        r.sum_l = sh_sums[0]; r.sum_m = sh_sums[1];
+        r.ok_until = sh_status[1] ? 0u : sh_sums[2];
         results[b] = r;
     }
 }
@@ -531,6 +557,37 @@ __device__ __forceinline__ void block_excl_scan2(uint32_t a, uint32_t b, uint32_
     }
     ea = oa + ia - a; eb = ob + ib - b; ta = sa; tb = sb;
     __syncthreads();
+}
+
+// What the reference's decode loop (fse_core.rs:103-131) meets first within the first `count` LMDs of a block, in LMD
+// order: a bad D (Error::BadDValue: the match is copied inside the loop, so this comes before the block's end-of-stream
+// status) or the end of the destination (BUFFER_OVERFLOW: literals first, then D, then the match bytes, lz/writer.rs:
+// 144-180). Returns 0 when neither happens. Called by the whole workgroup with uniform arguments; pos0 = stream
+// position of the block's first byte, cap = capacity of the stream's destination. sh: 2 * NT / 64 + 4 words.
+template <int NT>
+__device__ int lmds_first_fault(const LmdRec *bl, uint32_t count, uint64_t pos0, uint64_t cap, uint32_t *sh) {
+    constexpr int NW = NT / 64;
+    uint32_t *first = sh + 2 * NW + 2;  // [0]: first bad D, [1]: first overflow
+    uint64_t run = 0;
+    for (uint32_t g0 = 0; g0 < count; g0 += NT) {
+        const uint32_t idx = g0 + threadIdx.x;
+        const bool valid = idx < count;
+        const LmdRec r = valid ? bl[idx] : make_uint2(0, 0);
+        const uint32_t l = r.x & 0xFFFF, m = r.x >> 16, dd = r.y;
+        uint32_t ex_l, ex_s, tot_l, tot_s;
+        if (threadIdx.x < 2) first[threadIdx.x] = 0xFFFFFFFFu;
+        block_excl_scan2<NT>(l, l + m, ex_l, ex_s, tot_l, tot_s, sh);
+        const uint64_t pm = pos0 + run + ex_s + l;  // position of the match = end of the LMD's literals
+        if (valid && m != 0 && (dd == 0 || (uint64_t)dd > pm) && pm <= cap) atomicMin(&first[0], idx);
+        if (valid && pm + m > cap) atomicMin(&first[1], idx);
+        __syncthreads();
+        const uint32_t fb = first[0], fo = first[1];
+        __syncthreads();
+        if (fb != 0xFFFFFFFFu && fb <= fo) return LZFSE_MI_BAD_D_VALUE;
+        if (fo != 0xFFFFFFFFu) return LZFSE_MI_BUFFER_OVERFLOW;
+        run += tot_s;
+    }
+    return 0;
 }
 
 // LZVN block decode by one lane (vn/vn_core.rs:134-283); bvxn only occurs in tiny or foreign
@@ -612,7 +669,7 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
     __shared__ uint16_t s_org[TILE];  // per-byte origin inside the tile (pointer jumping)
     __shared__ uint32_t s_dm[NT];     // bit k of s_dm[x]: tile byte x + k * NT is produced by an in-tile match
     __shared__ uint32_t s_long[2 * NT];
-    __shared__ uint32_t s_scan[2 * NW + 2];
+    __shared__ uint32_t s_scan[2 * NW + 4];
     __shared__ uint32_t s_cnt[4];
     __shared__ int s_status;
 
@@ -656,9 +713,13 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
             continue;
         }
         const BlockResult br = bres[pl.blk_base + bi];
-        if (br.status) { status = br.status; break; }
-        if (out_pos + d.n_raw > in.dst_cap) { status = LZFSE_MI_BUFFER_OVERFLOW; break; }
         const LmdRec *bl = lmds + d.lmd_base;
+        if (br.status || out_pos + d.n_raw > in.dst_cap) {
+            // nothing of this block is written: what would the reference's loop have met first?
+            const int e = lmds_first_fault<NT>(bl, br.status ? br.ok_until : d.n_lmd, out_pos, in.dst_cap, s_scan);
+            status = e ? e : (br.status ? br.status : LZFSE_MI_BUFFER_OVERFLOW);
+            break;
+        }
         const uint8_t *blit = lits + d.lit_base;
         uint32_t lit_run = 0;
         for (uint32_t g0 = 0; g0 < d.n_lmd && !status;) {
@@ -866,7 +927,7 @@ __global__ __launch_bounds__(JUMP_THREADS) void dec_jump_init_kernel(
     const BlockDesc *__restrict__ blocks, uint32_t n_blocks, const BlockResult *__restrict__ bres,
     const LmdRec *__restrict__ lmds, const uint8_t *__restrict__ lits, uint8_t *dst_all, uint32_t *__restrict__ origin,
     uint32_t *__restrict__ jerr) {
-    __shared__ uint32_t sh[2 * (JUMP_THREADS / 64) + 2];
+    __shared__ uint32_t sh[2 * (JUMP_THREADS / 64) + 4];
     const uint32_t b = blockIdx.x;
     if (b >= n_blocks) return;
     const BlockDesc d = blocks[b];
@@ -885,8 +946,13 @@ __global__ __launch_bounds__(JUMP_THREADS) void dec_jump_init_kernel(
         return;
     }
     const BlockResult br = bres[b];
-    if (br.status) { if (tid == 0) atomicMin(&jerr[d.stream], (bi << 8) | (uint32_t)br.status); return; }
     const LmdRec *bl = lmds + d.lmd_base;
+    if (br.status) {
+        int e = lmds_first_fault<JUMP_THREADS>(bl, br.ok_until, o0, ~0ull, sh);  // (jumping streams fit their destination)
+        if (!e) e = br.status;
+        if (tid == 0) atomicMin(&jerr[d.stream], (bi << 8) | (uint32_t)e);
+        return;
+    }
     const uint8_t *blit = lits + d.lit_base;
     uint32_t run_lit = 0, run_out = 0;
     bool bad = false;
@@ -938,6 +1004,7 @@ __global__ __launch_bounds__(256) void dec_jump_round_kernel(uint32_t *__restric
         // up to three hops; an entry carrying JUMP_FINAL holds the final byte of its chain (itself for a literal)
 #pragma unroll
         for (int h = 0; h < 3; h++) {
+            if (cur >= total) { cur = (uint32_t)q | JUMP_FINAL; break; }  // never taken: every entry is defined (see launch_dec_jump)
             cur = origin[cur];
             if (cur & JUMP_FINAL) break;
         }
@@ -1030,6 +1097,9 @@ void launch_dec_jump(const uint8_t *src, const StreamIn *streams, const StreamPl
     if (!n_blocks || !total) return;
     {
         StageTimer t(c, "dec_jump_init");
+        // Every origin entry is defined before the rounds read it: padding slots between streams, the bytes of blocks that
+        // failed and of bad-D matches are never written by the init kernel; all bits set = final, names nothing.
+        (void)hipMemsetAsync(origin, 0xFF, (size_t)total * 4, st);
         hipLaunchKernelGGL(dec_jump_init_kernel, dim3(n_blocks), dim3(JUMP_THREADS), 0, st, src, streams, plan, blocks, n_blocks, bres, lmds,
                            lits, dst, origin, jerr);
     }
