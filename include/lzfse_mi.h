@@ -73,6 +73,20 @@ const char *lzfse_mi_version(void);
  * NULL restores the context's own stream. */
 int lzfse_mi_set_stream(lzfse_mi_ctx *ctx, void *hip_stream);
 
+/* Tuning knobs. A large batch call is cut into sub-batches ("lanes") that run side by side on their own HIP streams
+ * (several stages are latency-bound); results never depend on these. The LZFSE_MI_OPT_DIAG_* options exist in the
+ * diagnostic build of the library only (liblzfse_mi_diag.so, used by the test-suite to force code paths); the product
+ * library answers LZFSE_MI_UNSUPPORTED and reads no environment variable at all. */
+enum {
+    LZFSE_MI_OPT_ENCODE_LANES = 1,  /* 0: chosen by batch size (default), 1: one pass ("exclusive" kernel timing), 2..4 */
+    LZFSE_MI_OPT_DECODE_LANES = 2,
+    LZFSE_MI_OPT_STAGGER = 3,       /* encode lanes start one after the other (default 1) */
+    LZFSE_MI_OPT_DIAG_LZ_PATH = 100, /* -1: by cost, 0: tile kernel only, 1: pointer jumping for every stream */
+    LZFSE_MI_OPT_DIAG_LZ_TILE = 101, /* -1: by stream count, 0: 256-thread / 8 KiB tile, 1: 1024-thread / 32 KiB tile */
+    LZFSE_MI_OPT_DIAG_STATS = 102    /* bit mask: per-stage statistics on stderr */
+};
+int lzfse_mi_set_option(lzfse_mi_ctx *ctx, int option, int64_t value);
+
 /* Upper bound of the encoded size of an n-byte input (fse/constants.rs:54-69: every full
  * bvx2 block carries >= 39 996 raw bytes and costs <= 54 bits per LMD + 10 bits per literal). */
 size_t lzfse_mi_encode_bound(size_t n);

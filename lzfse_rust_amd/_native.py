@@ -13,21 +13,30 @@ class Timings(C.Structure):
 
 
 _lib = None
+_diag_lib = None
 
 _SYMBOLS = [
     "lzfse_mi_create", "lzfse_mi_destroy", "lzfse_mi_status_string", "lzfse_mi_version", "lzfse_mi_set_stream",
     "lzfse_mi_encode_bound", "lzfse_mi_encode", "lzfse_mi_decode", "lzfse_mi_decode_size",
     "lzfse_mi_encode_batch", "lzfse_mi_decode_batch", "lzfse_mi_decode_batch_device",
     "lzfse_mi_encode_batch_device", "lzfse_mi_enable_timing", "lzfse_mi_get_timings", "lzfse_mi_encode_small",
-    "lzfse_mi_last_error_detail",
+    "lzfse_mi_last_error_detail", "lzfse_mi_set_option",
 ]
 
 
-def lib():
-    global _lib
-    if _lib is not None:
-        return _lib
-    path = _build.LIB_PATH
+def lib(diag=False):
+    """The product library; diag=True: the diagnostic build (LZFSE_MI_OPT_DIAG_* options, debug hook) for tests."""
+    global _lib, _diag_lib
+    if diag:
+        if _diag_lib is None:
+            _diag_lib = _load(_build.DIAG_LIB_PATH)
+        return _diag_lib
+    if _lib is None:
+        _lib = _load(_build.LIB_PATH)
+    return _lib
+
+
+def _load(path):
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`. "
                            "There is no CPU fallback for the MI355X codec.")
@@ -68,5 +77,6 @@ def lib():
     L.lzfse_mi_enable_timing.argtypes = [vp, C.c_int]
     L.lzfse_mi_get_timings.restype = C.c_int
     L.lzfse_mi_get_timings.argtypes = [vp, C.POINTER(Timings)]
-    _lib = L
+    L.lzfse_mi_set_option.restype = C.c_int
+    L.lzfse_mi_set_option.argtypes = [vp, C.c_int, C.c_int64]
     return L

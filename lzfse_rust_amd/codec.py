@@ -35,8 +35,10 @@ def _check(st):
 class Context:
     """One HIP device + stream + scratch (lzfse_mi_ctx)."""
 
-    def __init__(self, device=0):
-        self._lib = _native.lib()
+    OPTIONS = {"encode_lanes": 1, "decode_lanes": 2, "stagger": 3, "diag_lz_path": 100, "diag_lz_tile": 101, "diag_stats": 102}
+
+    def __init__(self, device=0, diag=False):
+        self._lib = _native.lib(diag=diag)
         h = C.c_void_p()
         _check(self._lib.lzfse_mi_create(int(device), C.byref(h)))
         self._h = h
@@ -52,6 +54,10 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def set_option(self, name, value):
+        """lzfse_mi_set_option; the diag_* options need Context(diag=True)."""
+        _check(self._lib.lzfse_mi_set_option(self._h, self.OPTIONS[name], int(value)))
 
     # -- stream / timing plumbing --
     def set_stream(self, hip_stream_ptr):

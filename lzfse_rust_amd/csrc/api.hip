@@ -86,6 +86,10 @@ struct lzfse_mi_ctx {
     // u32 payload of the error kinds that carry one (Error::BadBlock(magic), FseErrorKind::BadLmdCount(n) /
     // BadLiteralCount(n)): per stream of the last sub-batch run on this context / of the last API call
     std::vector<uint32_t> detail, detail_out;
+    // lzfse_mi_set_option
+    int opt_lanes_enc = 0, opt_lanes_dec = 0;  // sub-batches run side by side (0: chosen by size, 1: one)
+    int opt_stagger = 1;
+    int diag_lz_jump = -1, diag_lz_variant = -1, diag_stats = 0;  // diagnostic build only
 
     hipEvent_t get_event() {
         if (ev_used == ev_pool.size()) {
@@ -114,6 +118,7 @@ hipStream_t ctx_stream(lzfse_mi_ctx *c) { return c->stream; }
 EncScratch &ctx_enc(lzfse_mi_ctx *c) { return c->enc; }
 LaneGate *ctx_gate_in(lzfse_mi_ctx *c) { return c->gate_in; }
 LaneGate *ctx_gate_out(lzfse_mi_ctx *c) { return c->gate_out; }
+int ctx_diag_stats(lzfse_mi_ctx *c) { return c->diag_stats; }
 }  // namespace lzmi
 
 static void timing_begin(lzfse_mi_ctx *c) {
@@ -145,7 +150,11 @@ static void timing_end(lzfse_mi_ctx *c) {
 
 extern "C" {
 
-const char *lzfse_mi_version(void) { return "lzfse-mi355x 0.1.0 (gfx950)"; }
+#ifdef LZFSE_MI_DIAG
+const char *lzfse_mi_version(void) { return "lzfse-mi355x 0.2.0 (gfx950, diagnostic build)"; }
+#else
+const char *lzfse_mi_version(void) { return "lzfse-mi355x 0.2.0 (gfx950)"; }
+#endif
 
 const char *lzfse_mi_status_string(int s) {
     switch (s) {
@@ -352,8 +361,7 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
     HIP_TRY(hipStreamSynchronize(st));
     std::vector<StreamPlan> h_plan(ns);
     uint64_t nb = 0, nl = 0, nu = 0, nj = 0;
-    int jump_mode = -1;  // -1: by cost, 0: never, 1: always (diagnostics)
-    if (const char *ev = getenv("LZFSE_MI_LZ_JUMP")) jump_mode = atoi(ev);
+    int jump_mode = c->diag_lz_jump;  // -1: by cost; the diagnostic build can force 0 (never) or 1 (always)
     // Streams >= 2 MiB may take the pointer-jumping LZ path. One workgroup per stream copies ~0.6 GB/s whatever else
     // runs, the jumping passes move ~25 GB/s over all eligible bytes together: jumping pays when the largest stream,
     // not the batch, sets the time (one 64 MiB stream: yes; 128 streams of 4 MiB: no).
@@ -416,7 +424,7 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
         // one workgroup per stream: with few streams per CU the 1024-thread / 32 KiB-tile kernel finishes a stream
         // soonest; with >= 4 streams per CU the 256-thread / 8 KiB-tile kernel (5 workgroups per CU) moves more bytes
         int variant = ns >= 1024 ? 0 : 1;
-        if (const char *ev = getenv("LZFSE_MI_LZ_VARIANT")) variant = atoi(ev);
+        if (c->diag_lz_variant >= 0) variant = c->diag_lz_variant;
         launch_dec_lz(variant, (const uint8_t *)d_src, (const StreamIn *)c->d_streams.p,
                       (const StreamPlan *)c->d_plan.p, ns, (const BlockDesc *)c->d_blocks.p,
                       (const BlockResult *)c->d_bres.p, (const LmdRec *)c->d_lmds.p, (const uint8_t *)c->d_lits.p,
@@ -432,7 +440,7 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
     HIP_TRY(hipMemcpyAsync(h_sres.data(), c->d_sres.p, ns * sizeof(StreamResult), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (hipGetLastError() != hipSuccess) return LZFSE_MI_IO;
-    if (getenv("LZFSE_MI_LZ_STATS") && nj) {
+    if ((c->diag_stats & 4) && nj) {
         uint32_t hf[20] = {};
         if (hipMemcpy(hf, d_jflags, sizeof hf, hipMemcpyDeviceToHost) == hipSuccess) {
             fprintf(stderr, "jump rounds that still moved bytes:");
@@ -440,7 +448,7 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
             fprintf(stderr, "\n");
         }
     }
-    if (getenv("LZFSE_MI_LZ_STATS")) {
+    if (c->diag_stats & 4) {
         for (uint32_t i = 0; i < ns && i < 16; i++) {
             const StreamResult &q = h_sres[i];
             fprintf(stderr, "lz[%u] out=%llu groups=%u dep=%u long=%u cyc scan=%llu short=%llu long=%llu dep=%llu wb=%llu total=%llu\n", i,
@@ -515,7 +523,7 @@ static int split_batch(lzfse_mi_ctx *c, batch_dev_fn one, int lanes, bool stagge
     uint64_t total = 0;
     if (count && src_len)
         for (size_t i = 0; i < count; i++) total += src_len[i];
-    static const bool no_split = getenv("LZFSE_MI_NO_SPLIT") != nullptr;
+    const bool no_split = false;
     if (lanes > LZFSE_MI_MAX_LANES) lanes = LZFSE_MI_MAX_LANES;
     while (lanes > 1 && (count < (size_t)4 * lanes || total < ((uint64_t)lanes << 21))) lanes--;
     auto unsplit = [&]() {
@@ -553,6 +561,8 @@ static int split_batch(lzfse_mi_ctx *c, batch_dev_fn one, int lanes, bool stagge
     for (int k = 0; ok && k + 1 < lanes; k++) {
         ok = hipStreamWaitEvent(c->shadow[k]->stream, c->split_ev, 0) == hipSuccess;
         c->shadow[k]->timing = c->timing;
+        c->shadow[k]->diag_lz_jump = c->diag_lz_jump; c->shadow[k]->diag_lz_variant = c->diag_lz_variant;
+        c->shadow[k]->diag_stats = c->diag_stats;
     }
     if (!ok) return unsplit();
     // staggered start (encode): lane k + 1 begins when lane k has queued its candidate kernel
@@ -594,31 +604,49 @@ static int split_batch(lzfse_mi_ctx *c, batch_dev_fn one, int lanes, bool stagge
     return rc;
 }
 
-static int lanes_of(const char *env, int dflt) {
-    const char *v = getenv(env);
-    int n = v ? atoi(v) : dflt;
-    return n < 1 ? 1 : n;
-}
-
 int lzfse_mi_decode_batch_device(lzfse_mi_ctx *c, size_t count, const void *d_src, const uint64_t *src_off,
                                  const uint64_t *src_len, void *d_dst, const uint64_t *dst_off,
                                  const uint64_t *dst_cap, uint64_t *out_lens, int *statuses) {
-    static const int lanes = lanes_of("LZFSE_MI_LANES_DEC", 2);
-    return split_batch(c, decode_batch_device_one, lanes, false, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap, out_lens, statuses);
+    if (!c) return LZFSE_MI_BAD_ARGUMENT;
+    return split_batch(c, decode_batch_device_one, c->opt_lanes_dec ? c->opt_lanes_dec : 2, false, count, d_src, src_off, src_len, d_dst,
+                       dst_off, dst_cap, out_lens, statuses);
 }
 
 int lzfse_mi_encode_batch_device(lzfse_mi_ctx *c, size_t count, const void *d_src, const uint64_t *src_off,
                                  const uint64_t *src_len, void *d_dst, const uint64_t *dst_off,
                                  const uint64_t *dst_cap, uint64_t *out_lens, int *statuses) {
+    if (!c) return LZFSE_MI_BAD_ARGUMENT;
     // two lanes, three from 512 MiB on (measured: +5 % at 752 MB, -4 % at 188 MB, where the lanes' tails dominate)
-    static const int lanes_env = getenv("LZFSE_MI_LANES_ENC") ? lanes_of("LZFSE_MI_LANES_ENC", 2) : 0;
-    int lanes = lanes_env;
+    int lanes = c->opt_lanes_enc;
     if (!lanes) {
         uint64_t total = 0;
         for (size_t i = 0; src_len && i < count; i++) total += src_len[i];
         lanes = total >= (512ull << 20) ? 3 : 2;
     }
-    return split_batch(c, encode_batch_device_one, lanes, getenv("LZFSE_MI_NO_STAGGER") == nullptr, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap, out_lens, statuses);
+    return split_batch(c, encode_batch_device_one, lanes, c->opt_stagger != 0, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap,
+                       out_lens, statuses);
+}
+
+int lzfse_mi_set_option(lzfse_mi_ctx *c, int option, int64_t value) {
+    if (!c) return LZFSE_MI_BAD_ARGUMENT;
+    switch (option) {
+    case LZFSE_MI_OPT_ENCODE_LANES:
+    case LZFSE_MI_OPT_DECODE_LANES:
+        if (value < 0 || value > LZFSE_MI_MAX_LANES) return LZFSE_MI_BAD_ARGUMENT;
+        (option == LZFSE_MI_OPT_ENCODE_LANES ? c->opt_lanes_enc : c->opt_lanes_dec) = (int)value;
+        return LZFSE_MI_OK;
+    case LZFSE_MI_OPT_STAGGER: c->opt_stagger = value != 0; return LZFSE_MI_OK;
+#ifdef LZFSE_MI_DIAG
+    case LZFSE_MI_OPT_DIAG_LZ_PATH: c->diag_lz_jump = (int)value; return LZFSE_MI_OK;
+    case LZFSE_MI_OPT_DIAG_LZ_TILE: c->diag_lz_variant = (int)value; return LZFSE_MI_OK;
+    case LZFSE_MI_OPT_DIAG_STATS: c->diag_stats = (int)value; return LZFSE_MI_OK;
+#else
+    case LZFSE_MI_OPT_DIAG_LZ_PATH:
+    case LZFSE_MI_OPT_DIAG_LZ_TILE:
+    case LZFSE_MI_OPT_DIAG_STATS: return LZFSE_MI_UNSUPPORTED;
+#endif
+    default: return LZFSE_MI_BAD_ARGUMENT;
+    }
 }
 
 // ---------------------------------------------------------------------------- host-pointer API

@@ -206,6 +206,15 @@ __device__ __forceinline__ uint64_t bw_window(const BitWindow &w) {
     return (uint64_t)x0 | ((uint64_t)x1 << 32);
 }
 
+// The window of one decode step. The reference refills its accumulator once per step (bit_reader.rs:39-50) from byte
+// index idx = ceil((rem - 64) / 8) of the slice, and a read at a negative index returns ZERO for all 64 bits, not just
+// for the bytes in front of the slice (bit_src.rs:35-46): from the moment fewer than 57 bits remain, a (damaged) stream
+// decodes as zeros. Valid streams never get there (finalize demands rem >= 64), error codes of damaged ones depend on it.
+__device__ __forceinline__ uint64_t bw_step_window(const BitWindow &w) {
+    const uint64_t v = bw_window(w);
+    return (w.rem - w.base_bit) < 57 ? 0ull : v;
+}
+
 // bit_reader.rs:20-30; len counts the 8 pad bytes in front of the payload
 __device__ inline int bw_init(BitWindow &w, const uint8_t *base, uint32_t len, uint32_t off, const uint8_t *glo,
                               const uint8_t *ghi, uint32_t *buf) {
@@ -444,7 +453,7 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
             stg_lit[sidx] = (uint8_t)(ent >> 8);
             sidx += s_inc;
             bw_advance(w, read_lane(pre, 3));
-            win = bw_window(w);
+            win = bw_step_window(w);
             if ((g & 63) == 63) {
                 ((uint32_t *)out)[(g & ~63u) + lane] = ((const uint32_t *)stg_lit)[lane];
                 sidx = s_home;
@@ -506,7 +515,7 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
             stg_lmd[sidx] = ent.y + extra;
             sidx += s_inc;
             bw_advance(w, read_lane(pre, 2));
-            win = bw_window(w);
+            win = bw_step_window(w);
             if ((i & 63) == 63) { flush(i & ~63u, 64); sidx = s_home; }
         }
         if (n & 63) flush(n & ~63u, n & 63);

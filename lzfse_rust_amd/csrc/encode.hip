@@ -1,25 +1,14 @@
 // Encode side of the MI355X LZFSE codec: hand-written HIP kernels for gfx950 (wave64).
 //
-// The reference's encoder is a serial greedy/lazy parse over a 4-way, 2^14-bucket history
-// table (encode/frontend_bytes.rs:160-268, encode/history.rs:15-118). Its table state before
-// position i is a pure function of src[0..i+3] because every position is inserted exactly once,
-// in order (frontend_bytes.rs:187,336-344). That makes the expensive part position-parallel:
+// Match finding lives in encode_match.hip (history-table replay + per-position candidates), the parse in
+// encode_parse.hip (speculative segment walks, stitching, block segmentation). Here:
 //
-//   enc_chain_kernel   per 64 Ki-position tile: prev[i] = previous position in the same bucket
-//                      (history.rs:221-224 hash, fse/object.rs:38-43), exact, in-order, with a
-//                      16 384-entry last-seen table in LDS and ballot matching inside a wave
-//   enc_link_kernel    first occurrences of a tile: link to earlier tiles (window 262 139)
-//   enc_cand_kernel    per position: walk <= 4 chain entries newest->oldest with the reference's
-//                      gates (frontend_bytes.rs:214-231), forward LCP (match_kit/match_fast.rs:
-//                      22-49) and un-gated backward LCS (:61-89), both capped
-//   enc_walk_kernel    the true serial recurrence, one wave per stream: Match::select lazy arbiter
-//                      (match_object.rs:12-33), literal_index, sync skip, LMD emission and bvx2
-//                      block segmentation (fse/buffer.rs:45-131, fse/backend.rs:76-96)
 //   enc_block_kernel   per bvx2 block: literal gather, histograms, normalize_m1 (weights.rs:
 //                      218-278), weight bytes (weight_encoder.rs:23-37), E tables (encoder.rs:
 //                      219-240), reverse FSE of literals / LMDs (literals.rs:93-133, lmds.rs:
 //                      62-93), header (block.rs:168-196)
 //   enc_pack_kernel    stream assembly: blocks back to back + bvx$ (frontend_bytes.rs:50-61)
+//   enc_batch_device   host orchestration of one encode (sub-)batch
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -32,766 +21,6 @@
 struct lzfse_mi_ctx;
 
 namespace lzmi {
-
-// ------------------------------------------------------------------------------------ chains
-
-// One wave per tile. Positions are processed in order, 64 per step; the nearest previous
-// position with the same bucket is either a lower lane of the same step (found with 14 ballots)
-// or the LDS last-seen entry written by earlier steps.
-__global__ __launch_bounds__(64) void enc_chain_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
-                                                       const EncTile *__restrict__ tiles, uint32_t n_tiles,
-                                                       uint2 *__restrict__ prev, uint32_t *__restrict__ summary,
-                                                       uint32_t *__restrict__ flist, uint32_t *__restrict__ fcount) {
-    __shared__ uint16_t last[1u << HASH_BITS];  // offset in tile + 1, 0 = none
-    const uint32_t t = blockIdx.x;
-    if (t >= n_tiles) return;
-    const EncTile tl = tiles[t];
-    const EncStream st = streams[tl.stream];
-    const int lane = e_lane();
-    for (uint32_t k = lane; k < (1u << HASH_BITS); k += 64) last[k] = 0;
-    const uint8_t *s = src + st.src_off;
-    uint2 *pv = prev + st.pos_base;  // {previous position in the bucket, 4-byte value at this position}
-    const uint32_t n_pos = st.n - 3;  // positions 0 .. n-4 are hashed (frontend_bytes.rs:166-170)
-    const uint32_t t_end = tl.start + TILE_POS < n_pos ? tl.start + TILE_POS : n_pos;
-    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
-    uint32_t *fl = flist + (uint64_t)t * (1u << HASH_BITS);
-    uint32_t n_first = 0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // 16 steps (1024 positions) per batch: the source values of a batch are loaded together, so the wave
-    // waits for memory once per batch instead of once per step (a wait also drains the link stores)
-    constexpr int CH_STEPS = 16;
-    for (uint32_t pb = tl.start; pb < t_end; pb += 64 * CH_STEPS) {
-        uint32_t vv[CH_STEPS];
-#pragma unroll
-        for (int j = 0; j < CH_STEPS; j++) {
-            const uint32_t q = pb + 64 * j + lane;
-            vv[j] = q < t_end ? ld_u32(s + q) : 0u;
-        }
-#pragma unroll
-        for (int j = 0; j < CH_STEPS; j++) {
-            const uint32_t p0 = pb + 64 * j;
-            if (p0 >= t_end) continue;  // (not break: the loop must stay fully unrolled, vv[] lives in registers)
-            const uint32_t p = p0 + lane;
-            const bool valid = p < t_end;
-            const uint32_t v = vv[j];
-            const uint32_t key = bucket_of(v);
-            const uint32_t old = last[key];
-            const uint32_t mine = p - tl.start + 1;
-            // fast path: every lane writes its own entry and reads it back; if all read their own value no
-            // two lanes of this step share a bucket and the entry read before the write is the link
-            if (valid) last[key] = (uint16_t)mine;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t chk = last[key];
-            uint32_t pr = old ? (tl.start + old - 1) : NONE_TILE;
-            if (__ballot(valid && chk != mine)) {
-                // some lanes collide: find the nearest lower lane with the same bucket by 14 ballots
-                uint64_t same = __ballot(valid);
-#pragma unroll
-                for (int b = 0; b < (int)HASH_BITS; b++) {
-                    uint64_t bb = __ballot((key >> b) & 1);
-                    same &= ((key >> b) & 1) ? bb : ~bb;
-                }
-                const uint64_t lower = same & lt_mask;
-                if (lower) pr = p0 + (63 - __builtin_clzll(lower));
-                if (valid && (same >> lane) >> 1 == 0) last[key] = (uint16_t)mine;  // newest of its bucket wins
-            }
-            // first occurrence of its bucket in the tile: the link into earlier tiles is made by enc_link_kernel
-            // from this list (offset | bucket << 16); the first tile of a stream has nothing before it
-            const bool first = valid && pr == NONE_TILE;
-            if (tl.start == 0) { if (first) pr = NONE; }
-            else {
-                const uint64_t fm = __ballot(first);
-                if (first) fl[n_first + (uint32_t)__popcll(fm & lt_mask)] = (p - tl.start) | (key << 16);
-                n_first += (uint32_t)__popcll(fm);
-            }
-            if (valid) pv[p] = make_uint2(pr, v);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    if (lane == 0) fcount[t] = n_first;
-    uint32_t *sm = summary + (uint64_t)t * (1u << HASH_BITS);
-    for (uint32_t k = lane; k < (1u << HASH_BITS); k += 64) {
-        uint32_t o = last[k];
-        sm[k] = o ? tl.start + o - 1 : NONE;
-    }
-}
-
-// Cross-tile links: a bucket's first occurrence in a tile (listed by enc_chain_kernel) points at the newest
-// occurrence in an earlier tile of the same stream. Anything further back than 5 tiles is outside the
-// 262 139-byte window (fse/constants.rs:42) and would end the candidate scan anyway.
-__global__ void enc_link_kernel(const EncStream *__restrict__ streams, const EncTile *__restrict__ tiles, uint32_t n_tiles,
-                                uint2 *__restrict__ prev, const uint32_t *__restrict__ summary,
-                                const uint32_t *__restrict__ flist, const uint32_t *__restrict__ fcount) {
-    const uint32_t t = blockIdx.y;
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= fcount[t]) return;
-    const EncTile tl = tiles[t];
-    const EncStream st = streams[tl.stream];
-    const uint32_t ent = flist[(uint64_t)t * (1u << HASH_BITS) + e];
-    const uint32_t p = tl.start + (ent & 0xFFFF), key = ent >> 16;
-    uint32_t r = NONE;
-    const uint32_t t_idx = tl.start / TILE_POS;  // tile index inside the stream
-    for (uint32_t back = 1; back <= 5 && back <= t_idx; back++) {
-        uint32_t sv = summary[(uint64_t)(t - back) * (1u << HASH_BITS) + key];
-        if (sv != NONE) { r = sv; break; }
-    }
-    prev[st.pos_base + p].x = r;
-}
-
-// ------------------------------------------------------------------------------------ candidates
-
-__device__ __forceinline__ uint4 ld_u128(const uint8_t *p) {
-    uint4 v;
-    __builtin_memcpy(&v, p, 16);
-    return v;
-}
-
-// forward common length of src[a..] and src[b..] (b < a), starting at `len`, bounded by max
-__device__ __forceinline__ uint32_t lcp_fwd(const uint8_t *s, uint32_t a, uint32_t b, uint32_t len, uint32_t max) {
-    while (len + 8 <= max) {
-        uint64_t x = ld_u64(s + a + len) ^ ld_u64(s + b + len);
-        if (x) return len + (uint32_t)(__builtin_ctzll(x) >> 3);
-        len += 8;
-    }
-    while (len < max && s[a + len] == s[b + len]) len++;
-    return len;
-}
-
-// common suffix length of src[..a) and src[..b) (b < a), bounded by max (<= b)
-__device__ __forceinline__ uint32_t lcs_bwd(const uint8_t *s, uint32_t a, uint32_t b, uint32_t max) {
-    uint32_t len = 0;
-    while (len + 8 <= max) {
-        uint64_t x = ld_u64(s + a - len - 8) ^ ld_u64(s + b - len - 8);
-        if (x) return len + (uint32_t)(__builtin_clzll(x) >> 3);
-        len += 8;
-    }
-    while (len < max && s[a - len - 1] == s[b - len - 1]) len++;
-    return len;
-}
-
-// exact forward length by the whole wave, 512 bytes per step (every lane must call)
-__device__ uint32_t cand_wave_lcp(const uint8_t *s, uint32_t a, uint32_t b, uint32_t len, uint32_t max) {
-    const int lane = e_lane();
-    while (len < max) {
-        uint32_t off = len + 8 * lane;
-        uint64_t x = 0;
-        if (off + 8 <= max) x = ld_u64(s + a + off) ^ ld_u64(s + b + off);
-        else
-            for (uint32_t k = 0; off + k < max && k < 8; k++)
-                x |= (uint64_t)(s[a + off + k] ^ s[b + off + k]) << (8 * k);
-        uint64_t bad = __ballot(x != 0);
-        if (bad) {
-            int bl = __builtin_ctzll(bad);
-            uint32_t xl = e_readlane((uint32_t)x, bl), xh = e_readlane((uint32_t)(x >> 32), bl);
-            uint64_t xx = (uint64_t)xl | ((uint64_t)xh << 32);
-            uint32_t r = len + 8 * bl + (uint32_t)(__builtin_ctzll(xx) >> 3);
-            return r < max ? r : max;
-        }
-        len += 512;
-    }
-    return max;
-}
-
-// rec[i] = { dist | bwd << 18 | capped << 31 , fwd_len }  ; fwd_len == 0: no match at i
-//
-// One lane per position, hops in lock-step. A lane compares at most CAND_C1 bytes on its own. Lanes
-// that are still equal there are grouped into runs of consecutive positions with the same distance
-// (the inside of one long match): only the head of a run is extended, by the whole wave, and the
-// followers derive LCP(i + t, c + t) = LCP(i, c) - t. Repetitive data costs O(1) per position.
-constexpr uint32_t CAND_C1 = 64;
-constexpr int CAND_GL = 8;  // lanes per group of the long-match work list
-constexpr uint32_t CAND_BPT = (TILE_POS + 255) / 256;  // workgroups per tile
-
-__global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
-                                                       const EncTile *__restrict__ tiles, uint32_t n_tiles, const uint2 *__restrict__ prev,
-                                                       uint2 *__restrict__ rec, uint64_t *__restrict__ bitmap, int dbg) {
-    // Workgroups are handed to the 8 XCDs round-robin. All workgroups of one tile go to the same XCD, so the
-    // link records and source bytes a tile gathers from (its own 0.5 MB + the 2 MB window before it) stay in
-    // that XCD's 4 MB L2 instead of being spread over all eight.
-    __shared__ uint32_t q_i[4][256], q_c[4][256];  // per-wave work list of phase 3: position, candidate
-    __shared__ uint16_t q_id[4][256], q_res[4][256];
-    __shared__ uint32_t q_dist[4][256], q_tab[4][64];  // distance of a listed head; first head per distance hash
-    __shared__ uint32_t s_win[4][52];                  // per wave: 192 source bytes around its 64 positions (+ read slack)
-    const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const uint32_t t = (slot / CAND_BPT) * 8 + xcd, bx = slot % CAND_BPT;
-    if (t >= n_tiles) return;
-    const EncTile tl = tiles[t];
-    const EncStream st = streams[tl.stream];
-    const uint32_t i = tl.start + bx * blockDim.x + threadIdx.x;
-    const uint32_t n = st.n, n_pos = n - 3;
-    if (tl.start + bx * blockDim.x >= n_pos) return;  // block-uniform
-    const bool valid = i < n_pos && i < tl.start + TILE_POS;
-    const uint8_t *s = src + st.src_off;
-    const uint2 *pv = prev + st.pos_base;
-    const int lane = e_lane();
-    const uint2 self = valid ? pv[i] : make_uint2(NONE, 0);
-    const uint32_t v = self.y;
-    const uint32_t max_total = valid ? n - i : 0;
-    const uint32_t cap_total = max_total < FCAP ? max_total : FCAP;
-    const uint32_t c1 = cap_total < CAND_C1 ? cap_total : CAND_C1;
-    // ---- source window of the wave: bytes [i0 - 32, i0 + 160) of the stream (i0 = position of lane 0) go to LDS
-    // with one coalesced load; every lane's own side of the byte compares (forward up to 64 + 16 bytes, backward
-    // up to 32) is read from there instead of 64 separate unaligned loads per step ----
-    {
-        const uint32_t i0 = i - (uint32_t)lane;
-        if (lane < 48) {
-            const int64_t pos = (int64_t)i0 - 32 + 4 * lane;
-            uint32_t wv4 = 0;
-            if (pos >= 0 && pos + 4 <= (int64_t)n) wv4 = ld_u32(s + pos);
-            else
-                for (int k = 0; k < 4; k++)
-                    if (pos + k >= 0 && pos + k < (int64_t)n) wv4 |= (uint32_t)s[pos + k] << (8 * k);
-            s_win[threadIdx.x >> 6][lane] = wv4;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    const uint32_t *win = s_win[threadIdx.x >> 6];
-    // ---- phase 1: follow the chain (<= 4 dependent 8-byte gathers: next link + value) ----
-    uint32_t cc[4] = {NONE, NONE, NONE, NONE};
-    uint32_t ln[4] = {0, 0, 0, 0};
-    {
-        bool alive = valid;
-        uint32_t c = self.x;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            if ((dbg & 4) && q >= 1) alive = false;
-            if (alive) {
-                if (c == NONE || i - c > MAX_D_VALUE) alive = false;  // frontend_bytes.rs:222-224: stop, not skip
-                else {
-                    const uint2 rc = pv[c];
-                    if (rc.y == v) { cc[q] = c; ln[q] = 4; }
-                    c = rc.x;
-                }
-            }
-        }
-    }
-    // ---- runs: consecutive positions inside one match see the same distance in the same chain slot, and
-    // LCP(i + t, c + t) = LCP(i, c) - t. Only the first lane of such a run (its head) compares bytes; the
-    // followers derive their length from the head's. The kernel is bound by the number of cache lines its
-    // divergent loads touch, and on compressible data most equal candidates are followers. ----
-    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
-    bool fol[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t dk = ln[k] ? i - cc[k] : NONE;
-        const uint32_t dlo = __shfl_up(dk, 1);
-        fol[k] = ln[k] != 0 && lane > 0 && dlo == dk;
-    }
-    // ---- phase 2: forward lengths of all heads together, 16 bytes per candidate and step, so the loads of a
-    // step are in flight at the same time ----
-    {
-        bool act[4], tail[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) { act[k] = ln[k] != 0 && !fol[k] && c1 > 4 && !(dbg & 1); tail[k] = false; }
-#pragma unroll 1
-        for (uint32_t off = 4; off < CAND_C1; off += 16) {
-            if (!__any(act[0] || act[1] || act[2] || act[3]) || ((dbg & 16) && off > 4)) break;
-            // All five loads of a step are issued before the first use: each sits alone in its branch (idle
-            // lanes issue nothing) and the lengths are updated without branches afterwards. A load next to its
-            // use inside a branch would be waited for there, one candidate after the other.
-            const bool room = off + 16 <= max_total;
-            bool go[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) go[k] = act[k] && room;
-            const uint4 zero4 = make_uint4(0, 0, 0, 0);
-            uint4 a = zero4, bq[4] = {zero4, zero4, zero4, zero4};
-            if (go[0] || go[1] || go[2] || go[3]) {
-                const uint32_t wo = 32u + (uint32_t)lane + off, q = wo >> 2, sh = (wo & 3) * 8;  // wo + 16 <= 32 + 63 + 52 + 16 < 192
-                const uint32_t d0 = win[q], d1 = win[q + 1], d2 = win[q + 2], d3 = win[q + 3], d4 = win[q + 4];
-                a = make_uint4(__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh),
-                               __builtin_amdgcn_alignbit(d3, d2, sh), __builtin_amdgcn_alignbit(d4, d3, sh));
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (go[k]) bq[k] = ld_u128(s + cc[k] + off);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint64_t lo = ((uint64_t)(a.y ^ bq[k].y) << 32) | (a.x ^ bq[k].x);
-                const uint64_t hi = ((uint64_t)(a.w ^ bq[k].w) << 32) | (a.z ^ bq[k].z);
-                // both halves are always consumed, so that neither load can be deferred into a branch
-                const uint32_t mlo = lo ? (uint32_t)(__builtin_ctzll(lo | (1ull << 63)) >> 3) : 16u;
-                const uint32_t mhi = hi ? 8 + (uint32_t)(__builtin_ctzll(hi | (1ull << 63)) >> 3) : 16u;
-                const uint32_t m = mlo < mhi ? mlo : mhi;
-                uint32_t nl = off + m;
-                const bool stop = m < 16 || nl >= c1;
-                nl = nl < c1 ? nl : c1;
-                tail[k] = tail[k] || (act[k] && !room);
-                ln[k] = go[k] ? nl : ln[k];
-                act[k] = go[k] && !stop;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (tail[k]) ln[k] = lcp_fwd(s, i, cc[k], ln[k], c1);  // within 80 bytes of the stream's end
-    }
-    // ---- phase 3: heads still equal after CAND_C1 bytes go to a per-wave work list and are extended by groups
-    // of CAND_GL lanes, 16 bytes per lane and step, several heads at a time (up to FCAP + 64, so that 63
-    // followers stay exact up to FCAP); then the followers take head - t ----
-    {
-        const int wv = threadIdx.x >> 6;
-        bool more[4], dep[4];
-        uint32_t lead[4];
-        uint64_t any_more = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            more[k] = ln[k] == CAND_C1 && !fol[k] && CAND_C1 < cap_total && !(dbg & 8);
-            dep[k] = false; lead[k] = 0;
-            any_more |= __ballot(more[k]);
-        }
-        uint32_t total = 0;
-        if (any_more) {
-            // Heads of the wave with the same distance lie inside one match (they are < 64 positions apart and
-            // each is >= 64 long): LCP(i2, i2 - d) = LCP(i0, i0 - d) + i0 - i2. One of them is measured.
-            q_tab[wv][lane] = 0xFFFFFFFFu;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (more[k]) {
-                    const uint32_t dk = i - cc[k];
-                    q_dist[wv][k * 64 + lane] = dk;
-                    atomicMin(&q_tab[wv][(dk * 0x9E3779B1u) >> 26], (uint32_t)(k * 64 + lane));
-                }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (more[k]) {
-                    const uint32_t dk = i - cc[k];
-                    lead[k] = q_tab[wv][(dk * 0x9E3779B1u) >> 26];
-                    dep[k] = lead[k] != (uint32_t)(k * 64 + lane) && q_dist[wv][lead[k]] == dk;
-                }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const bool ind = more[k] && !dep[k];
-                const uint64_t mk = __ballot(ind);
-                if (ind) {
-                    const uint32_t q = total + (uint32_t)__popcll(mk & lt_mask);
-                    q_i[wv][q] = i; q_c[wv][q] = cc[k]; q_id[wv][q] = (uint16_t)(k * 64 + lane);
-                }
-                total += (uint32_t)__popcll(mk);
-            }
-        }
-        if (total) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const int g = lane / CAND_GL, sub = lane % CAND_GL;
-            const uint64_t gmask = ((1ull << CAND_GL) - 1) << (g * CAND_GL);
-            const uint64_t before = (1ull << (g * CAND_GL)) - 1;
-            uint32_t next = 0, it_i = 0, it_c = 0, it_lim = 0, it_off = 0, it_id = 0;
-            bool busy = false;
-            for (;;) {
-                const uint64_t idle = __ballot(!busy && sub == 0);
-                if (next < total && idle) {
-                    const uint32_t q = next + (uint32_t)__popcll(idle & before);
-                    if (!busy && q < total) {
-                        busy = true;
-                        it_i = q_i[wv][q]; it_c = q_c[wv][q]; it_id = q_id[wv][q];
-                        it_off = CAND_C1;
-                        const uint32_t maxh = n - it_i;
-                        it_lim = maxh < FCAP + 64 ? maxh : FCAP + 64;
-                    }
-                    next += (uint32_t)__popcll(idle);
-                }
-                if (!__any(busy)) break;
-                const uint32_t o = it_off + 16 * sub;
-                uint64_t xl = 0, xh = 0;
-                if (busy && o < it_lim) {
-                    if (it_i + o + 16 <= n) {
-                        const uint4 a = ld_u128(s + it_i + o), bq = ld_u128(s + it_c + o);
-                        xl = ((uint64_t)(a.y ^ bq.y) << 32) | (a.x ^ bq.x);
-                        xh = ((uint64_t)(a.w ^ bq.w) << 32) | (a.z ^ bq.z);
-                    } else {
-                        for (uint32_t t = 0; it_i + o + t < n; t++) {
-                            const uint64_t x = (uint64_t)(s[it_i + o + t] ^ s[it_c + o + t]);
-                            if (t < 8) xl |= x << (8 * t); else xh |= x << (8 * (t - 8));
-                        }
-                    }
-                }
-                const bool bad = (xl | xh) != 0;
-                const uint32_t r = o + (xl ? (uint32_t)(__builtin_ctzll(xl) >> 3) : 8 + (uint32_t)(__builtin_ctzll(xh | (1ull << 63)) >> 3));
-                const uint64_t badm = __ballot(bad) & gmask;
-                const uint32_t rr = __shfl(r, badm ? __builtin_ctzll(badm) : lane);
-                if (busy) {
-                    uint32_t res = 0;
-                    bool done = false;
-                    if (badm) { res = rr < it_lim ? rr : it_lim; done = true; }
-                    else {
-                        it_off += 16 * CAND_GL;
-                        if (it_off >= it_lim) { res = it_lim; done = true; }
-                    }
-                    if (done) {
-                        if (sub == 0) q_res[wv][it_id] = (uint16_t)res;
-                        busy = false;
-                    }
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (more[k]) ln[k] = dep[k] ? q_res[wv][lead[k]] + (lead[k] & 63) - (uint32_t)lane : q_res[wv][k * 64 + lane];
-        }
-    }
-    uint32_t best_len = 0, best_idx = 0;
-    bool capped = false;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        uint32_t len = ln[k];
-        const uint32_t c = cc[k];
-        const bool head = len != 0 && !fol[k];
-        const uint64_t hm = __ballot(head);
-        if (__any(fol[k])) {
-            const uint64_t below = hm & lt_mask;
-            const int h = below ? 63 - __builtin_clzll(below) : 0;
-            const uint32_t hl = __shfl(len, h);
-            if (fol[k]) len = hl - (uint32_t)(lane - h);
-        }
-        if (len) {
-            if (len > cap_total) len = cap_total;
-            if (len == cap_total && cap_total < max_total) capped = true;
-            if (len > best_len) { best_len = len; best_idx = c; }  // ties keep the newest (:226)
-        }
-    }
-    // backward extension: the same run structure, LCS(i + t, c + t) = LCS(i, c) + t (up to the cap)
-    uint2 r = make_uint2(0, 0);
-    {
-        const uint32_t bd = best_len ? i - best_idx : NONE;
-        const uint32_t bd_lo = __shfl_up(bd, 1);
-        const bool bfol = best_len != 0 && lane > 0 && bd_lo == bd;
-        const uint32_t bmax = best_idx < BCAP ? best_idx : BCAP;
-        uint32_t bw = 0;
-        if (best_len && !bfol && !(dbg & 2)) {
-            // lcs_bwd with this position's side read from the window (8 bytes per step, at most BCAP = 32 back)
-            uint32_t len = 0;
-            bool open = true;
-            while (open && len + 8 <= bmax) {
-                const uint32_t wo = 32u + (uint32_t)lane - len - 8, q = wo >> 2, sh = (wo & 3) * 8;
-                const uint32_t d0 = win[q], d1 = win[q + 1], d2 = win[q + 2];
-                const uint64_t av = (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
-                const uint64_t x = av ^ ld_u64(s + best_idx - len - 8);
-                if (x) { len += (uint32_t)(__builtin_clzll(x) >> 3); open = false; }
-                else len += 8;
-            }
-            while (open && len < bmax && s[i - len - 1] == s[best_idx - len - 1]) len++;
-            bw = len;
-        }
-        const uint64_t hm = __ballot(best_len != 0 && !bfol);
-        if (__any(bfol)) {
-            const uint64_t below = hm & lt_mask;
-            const int h = below ? 63 - __builtin_clzll(below) : 0;
-            const uint32_t hb = __shfl(bw, h);
-            if (bfol) { bw = hb + (uint32_t)(lane - h); if (bw > bmax) bw = bmax; }
-        }
-        if (valid) {
-            if (best_len) {
-                r.x = (i - best_idx) | (bw << 18) | (capped ? REC_CAPPED : 0u);
-                r.y = best_len;
-            }
-            rec[st.pos_base + i] = r;
-        }
-    }
-    // has-match bitmap: tile starts are multiples of 64, so a wave covers exactly one word
-    const uint64_t bits = __ballot(valid && r.y != 0);
-    // (words past the stream's last position belong to the next stream: never touch them)
-    if (lane == 0 && i < tl.start + TILE_POS && i < n_pos) bitmap[(st.pos_base + i) >> 6] = bits;
-}
-
-// ------------------------------------------------------------------------------------ walk
-
-struct Walker {
-    // stream
-    const uint8_t *s;
-    const uint2 *pv;
-    const uint2 *rec;
-    uint32_t n, end;
-    // parse state (frontend_bytes.rs:25-32)
-    uint32_t literal_index;
-    uint32_t p_idx, p_midx, p_len;  // pending
-    // backend state (fse/buffer.rs:16-23)
-    uint32_t n_lmd, n_lit, n_match, prev_d;
-    uint32_t blk_src_start;
-    // outputs
-    uint2 *lmds;        // stream's LMD array
-    uint32_t lmd_cap;
-    uint32_t lmd_count; // LMDs written so far (stream)
-    uint32_t blk_lmd_start;
-    EncBlock *blocks;
-    uint32_t blk_cap, blk_count;
-    uint64_t lmd_base, stage_base, stage_cap, stage_used;
-    uint2 stash;        // lane k holds LMD (lmd_count & ~63) + k until flushed
-    int status;
-};
-
-__device__ __forceinline__ void wk_put_lmd(Walker &w, uint32_t l, uint32_t m, uint32_t d) {
-    // fse/buffer.rs:106-117 (push_lmd) / :99-104 (push_l, which passes d = 1 already "seen")
-    const int lane = e_lane();
-    if (w.lmd_count >= w.lmd_cap) { w.status = LZFSE_MI_IO; return; }
-    if (lane == (int)(w.lmd_count & 63)) w.stash = make_uint2(l | (m << 16), d);
-    w.lmd_count++;
-    if ((w.lmd_count & 63) == 0) w.lmds[w.lmd_count - 64 + lane] = w.stash;
-    w.n_lmd++;
-}
-
-__device__ __forceinline__ void wk_flush_stash(Walker &w) {
-    const int lane = e_lane();
-    uint32_t rem = w.lmd_count & 63;
-    if (rem && lane < (int)rem) w.lmds[(w.lmd_count & ~63u) + lane] = w.stash;
-}
-
-__device__ __forceinline__ void wk_push_l(Walker &w, uint32_t l) {
-    w.prev_d = 1;
-    wk_put_lmd(w, l, 0, 1);
-}
-
-__device__ __forceinline__ void wk_push_lmd(Walker &w, uint32_t l, uint32_t m, uint32_t d) {
-    uint32_t ds = (w.prev_d == d) ? 0u : d;
-    w.prev_d = d;
-    wk_put_lmd(w, l, m, ds);
-    w.n_match += m;
-}
-
-// fse/backend.rs:39-54 bookkeeping part of emit_block_v2 + buffer.rs:119-125 reset
-__device__ __forceinline__ void wk_close_block(Walker &w) {
-    if (w.blk_count >= w.blk_cap) { w.status = LZFSE_MI_IO; return; }
-    uint32_t need = stage_need(w.n_lit, w.n_lmd);
-    if (w.stage_used + need > w.stage_cap) { w.status = LZFSE_MI_IO; return; }
-    if (e_lane() == 0) {
-        EncBlock b;
-        b.lmd_start = w.lmd_base + w.blk_lmd_start;
-        b.stage_off = w.stage_base + w.stage_used;
-        b.src_start = w.blk_src_start;
-        b.n_lmd = w.n_lmd; b.n_lit = w.n_lit; b.n_match = w.n_match;
-        b.hdr_len = 0; b.lit_len = 0; b.lmd_len = 0; b.pad = 0;
-        w.blocks[w.blk_count] = b;
-    }
-    w.stage_used += need;
-    w.blk_count++;
-    w.blk_src_start += w.n_lit + w.n_match;
-    w.blk_lmd_start = w.lmd_count;
-    w.n_lmd = 0; w.n_lit = 0; w.n_match = 0; w.prev_d = 0;
-}
-
-// fse/buffer.rs:45-97; returns false when the block is full (caller closes it and retries)
-__device__ __forceinline__ bool wk_buffer_push(Walker &w, uint32_t &n_lit, uint32_t &match_len, uint32_t d) {
-    while (n_lit > MAX_L_VALUE) {
-        if (w.n_lmd == LMDS_PER_BLOCK) return false;
-        uint32_t limit = LITERALS_PER_BLOCK - w.n_lit;
-        if (MAX_L_VALUE <= limit) {
-            w.n_lit += MAX_L_VALUE; n_lit -= MAX_L_VALUE;
-            wk_push_l(w, MAX_L_VALUE);
-        } else if (limit != 0) {
-            w.n_lit += limit; n_lit -= limit;
-            wk_push_l(w, limit);
-            return false;
-        } else return false;
-    }
-    if (w.n_lmd == LMDS_PER_BLOCK) return false;
-    uint32_t literal_len = n_lit;
-    uint32_t limit = LITERALS_PER_BLOCK - w.n_lit;
-    if (literal_len <= limit) {
-        w.n_lit += literal_len; n_lit = 0;
-    } else if (limit != 0) {
-        w.n_lit += limit; n_lit -= limit;
-        wk_push_l(w, limit);
-        return false;
-    } else return false;
-    while (match_len > MAX_M_VALUE) {
-        wk_push_lmd(w, literal_len, MAX_M_VALUE, d);
-        match_len -= MAX_M_VALUE;
-        literal_len = 0;
-        if (w.n_lmd == LMDS_PER_BLOCK) return false;
-    }
-    wk_push_lmd(w, literal_len, match_len, d);
-    match_len = 0;
-    return true;
-}
-
-// fse/backend.rs:76-90 with frontend_bytes.rs:287-302
-__device__ __forceinline__ void wk_push_match(Walker &w, uint32_t idx, uint32_t len, uint32_t dist) {
-    uint32_t n_lit = idx - w.literal_index;
-    w.literal_index = idx + len;
-    uint32_t m = len;
-    for (;;) {
-        if (wk_buffer_push(w, n_lit, m, dist)) break;
-        wk_close_block(w);
-        if (w.status) return;
-    }
-}
-
-// exact forward length by the whole wave (used when a per-position length hit FCAP)
-__device__ uint32_t wave_lcp_fwd(const uint8_t *s, uint32_t a, uint32_t b, uint32_t len, uint32_t max) {
-    const int lane = e_lane();
-    while (len < max) {
-        uint32_t off = len + 8 * lane;
-        uint64_t x = 0;
-        if (off + 8 <= max) x = ld_u64(s + a + off) ^ ld_u64(s + b + off);
-        else
-            for (uint32_t k = 0; off + k < max && k < 8; k++)
-                x |= (uint64_t)(s[a + off + k] ^ s[b + off + k]) << (8 * k);
-        uint64_t bad = __ballot(x != 0);
-        if (bad) {
-            int bl = __builtin_ctzll(bad);
-            uint32_t xl = e_readlane((uint32_t)x, bl), xh = e_readlane((uint32_t)(x >> 32), bl);
-            uint64_t xx = (uint64_t)xl | ((uint64_t)xh << 32);
-            uint32_t r = len + 8 * bl + (uint32_t)(__builtin_ctzll(xx) >> 3);
-            return r < max ? r : max;
-        }
-        len += 512;
-    }
-    return max;
-}
-
-__device__ uint32_t wave_lcs_bwd(const uint8_t *s, uint32_t a, uint32_t b, uint32_t max) {
-    const int lane = e_lane();
-    uint32_t len = 0;
-    while (len < max) {
-        uint32_t off = len + lane;
-        bool bad = off < max && s[a - off - 1] != s[b - off - 1];
-        uint64_t bm = __ballot(bad);
-        if (bm) {
-            uint32_t r = len + __builtin_ctzll(bm);
-            return r < max ? r : max;
-        }
-        len += 64;
-    }
-    return max;
-}
-
-// One wave per stream. All lanes execute the same (uniform) control flow; lanes only differ when
-// they prefetch records, stash LMDs or help with an exact length.
-__global__ __launch_bounds__(64) void enc_walk_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
-                                                      uint32_t n_streams, const uint2 *__restrict__ prev,
-                                                      const uint2 *__restrict__ rec, uint2 *__restrict__ lmds,
-                                                      EncBlock *__restrict__ blocks, EncStreamOut *__restrict__ outs) {
-    const uint32_t si = blockIdx.x;
-    if (si >= n_streams) return;
-    const EncStream st = streams[si];
-    const int lane = e_lane();
-    Walker w;
-    w.s = src + st.src_off;
-    w.pv = prev + st.pos_base;
-    w.rec = rec + st.pos_base;
-    w.n = st.n; w.end = st.n - 3;
-    w.literal_index = 0; w.p_idx = 0; w.p_midx = 0; w.p_len = 0;
-    w.n_lmd = 0; w.n_lit = 0; w.n_match = 0; w.prev_d = 0; w.blk_src_start = 0;
-    w.lmds = lmds + st.lmd_base; w.lmd_cap = st.lmd_cap; w.lmd_count = 0; w.blk_lmd_start = 0;
-    w.blocks = blocks + st.blk_base; w.blk_cap = st.blk_cap; w.blk_count = 0;
-    w.lmd_base = st.lmd_base; w.stage_base = st.stage_base; w.stage_cap = st.stage_cap; w.stage_used = 0;
-    w.stash = make_uint2(0, 0);
-    w.status = 0;
-
-    // record window: 256 positions in registers; lane k of r_j holds rec[cbase + 64 j + k]. One
-    // (stalling) refill per 256 positions; has_j = lanes of r_j with an incoming match.
-    uint32_t cbase = 0;
-    uint2 r0, r1, r2, r3;
-    uint64_t has0, has1, has2, has3;
-#define WK_LOAD_WINDOW()                                                                           \
-    do {                                                                                           \
-        r0 = (cbase + lane < w.end) ? w.rec[cbase + lane] : make_uint2(0, 0);                      \
-        r1 = (cbase + 64 + lane < w.end) ? w.rec[cbase + 64 + lane] : make_uint2(0, 0);            \
-        r2 = (cbase + 128 + lane < w.end) ? w.rec[cbase + 128 + lane] : make_uint2(0, 0);          \
-        r3 = (cbase + 192 + lane < w.end) ? w.rec[cbase + 192 + lane] : make_uint2(0, 0);          \
-        has0 = __ballot(r0.y != 0); has1 = __ballot(r1.y != 0);                                    \
-        has2 = __ballot(r2.y != 0); has3 = __ballot(r3.y != 0);                                    \
-    } while (0)
-    WK_LOAD_WINDOW();
-    uint32_t index = 0;
-    uint32_t st_iters = 0, st_emits = 0, st_capped = 0, st_refills = 0;
-    const uint64_t t_begin = __builtin_amdgcn_s_memtime();
-    while (index < w.end && !w.status) {
-        if (index >= cbase + 256) {
-            cbase = index & ~63u;
-            WK_LOAD_WINDOW();
-            st_refills++;
-        }
-        // skip positions without an incoming match: select() returns None for them (match_object.rs:14)
-        uint32_t off = index - cbase, j = off >> 6;
-        uint64_t have = (j == 0 ? has0 : j == 1 ? has1 : j == 2 ? has2 : has3) & (~0ull << (off & 63));
-        while (!have && j < 3) { j++; have = j == 1 ? has1 : j == 2 ? has2 : has3; }
-        if (!have) { index = cbase + 256; continue; }
-        const int k = __builtin_ctzll(have);
-        index = cbase + 64 * j + k;
-        if (index >= w.end) break;
-        const uint2 cur = j == 0 ? r0 : j == 1 ? r1 : j == 2 ? r2 : r3;
-        st_iters++;
-        uint32_t rx = e_readlane(cur.x, k), fwd = e_readlane(cur.y, k);
-        uint32_t dist = rx & 0x3FFFF, bw = (rx >> 18) & 0xFF;
-        uint32_t midx = index - dist;
-        if (rx & REC_CAPPED) {
-            st_capped++;
-            // exact re-evaluation of find_match's forward part (frontend_bytes.rs:214-231)
-            uint32_t v = ld_u32(w.s + index);
-            uint32_t best_len = 0, best_idx = 0;
-            uint32_t c = w.pv[index].x;
-            for (int q = 0; q < 4 && c != NONE; q++) {
-                if (index - c > MAX_D_VALUE) break;
-                if (ld_u32(w.s + c) == v) {
-                    uint32_t len = wave_lcp_fwd(w.s, index, c, 4, w.n - index);
-                    if (len > best_len) { best_len = len; best_idx = c; }
-                }
-                c = w.pv[c].x;
-            }
-            fwd = best_len; midx = best_idx; dist = index - midx;
-            uint32_t bmax = midx < BCAP ? midx : BCAP;
-            bw = wave_lcs_bwd(w.s, index, midx, bmax);
-        }
-        // backward extension gate (frontend_bytes.rs:259-268): min(literal_len, match_index)
-        uint32_t room = index - w.literal_index;
-        uint32_t b = bw < room ? bw : room;
-        if (bw == BCAP && room > BCAP && midx > BCAP) {
-            uint32_t bmax = room < midx ? room : midx;
-            b = wave_lcs_bwd(w.s, index, midx, bmax);
-        }
-        const uint32_t i_idx = index - b, i_midx = midx - b, i_len = fwd + b;
-        // Match::select::<40> (match_object.rs:12-33)
-        bool emit = false;
-        uint32_t e_idx = 0, e_midx = 0, e_len = 0;
-        if (i_len >= GOOD_MATCH_LEN) {
-            emit = true; e_idx = i_idx; e_midx = i_midx; e_len = i_len; w.p_len = 0;
-        } else if (w.p_len == 0) {
-            w.p_idx = i_idx; w.p_midx = i_midx; w.p_len = i_len;
-        } else if (w.p_idx + w.p_len <= i_idx) {
-            emit = true; e_idx = w.p_idx; e_midx = w.p_midx; e_len = w.p_len;
-            w.p_idx = i_idx; w.p_midx = i_midx; w.p_len = i_len;
-        } else if (i_len > w.p_len) {
-            emit = true; e_idx = i_idx; e_midx = i_midx; e_len = i_len; w.p_len = 0;
-        } else {
-            emit = true; e_idx = w.p_idx; e_midx = w.p_midx; e_len = w.p_len; w.p_len = 0;
-        }
-        if (emit) {
-            st_emits++;
-            wk_push_match(w, e_idx, e_len, e_idx - e_midx);
-            if (w.literal_index >= w.end) break;
-            index += 1;
-            if (index < w.literal_index) index = w.literal_index;  // sync_history: skipped positions
-        } else {
-            index += 1;
-        }
-    }
-    if (!w.status) {
-        // flush_pending (frontend_bytes.rs:271-285)
-        if (w.p_len != 0) { wk_push_match(w, w.p_idx, w.p_len, w.p_idx - w.p_midx); w.p_len = 0; }
-    }
-    if (!w.status) {
-        // flush_literals -> push_literals == push_match(literals, 0, D = 1) (fse/backend.rs:67-73)
-        uint32_t len = w.n - w.literal_index;
-        if (len) wk_push_match(w, w.n, 0, 1);
-    }
-    if (!w.status) wk_close_block(w);  // finalize (fse/backend.rs:92-95)
-    wk_flush_stash(w);
-    if (lane == 0) {
-        EncStreamOut o;
-        o.n_blocks = w.blk_count; o.status = w.status; o.out_len = 0;
-        o.iters = st_iters; o.emits = st_emits; o.capped = st_capped; o.refills = st_refills;
-        o.cycles = __builtin_amdgcn_s_memtime() - t_begin;
-        outs[si] = o;
-    }
-}
 
 // ------------------------------------------------------------------------------------ block encode
 
@@ -1431,7 +660,7 @@ __global__ __launch_bounds__(256) void enc_pack_kernel(const EncStream *__restri
 
 // ------------------------------------------------------------------------------------ host side
 
-enum { EB_STREAMS, EB_TILES, EB_PREV, EB_SUMMARY, EB_REC, EB_LMDS, EB_BLOCKS, EB_OUTS, EB_STAGE, EB_SLOTS,
+enum { EB_STREAMS, EB_TILES, EB_CAND4, EB_SPANS, EB_REC, EB_LMDS, EB_BLOCKS, EB_OUTS, EB_STAGE, EB_SLOTS,
        EB_BITMAP, EB_SEGS, EB_LOGS, EB_HDRS, EB_RANGES, EB_GAPS, EB_MATCHES, EB_PC, EB_PL, EB_RSLOTS, EB_SYNC, EB_RSUM, EB_DBG, EB_N };
 static_assert(EB_N <= 32, "EncScratch slots");
 
@@ -1456,6 +685,29 @@ void enc_scratch_release(EncScratch &s) {
 
 #define E_TRY(x) do { if ((x) != hipSuccess) return LZFSE_MI_IO; } while (0)
 
+// Spans of the history-table replay (encode_match.hip): a stream is one span unless that would leave the chip short of
+// waves (16 per span) or one wave with a much longer scan than the rest; further spans replay TB_WARM positions first.
+static void plan_spans(const std::vector<EncStream> &hs, std::vector<EncSpan> &spans) {
+    uint64_t total = 0;
+    for (const EncStream &e : hs) total += e.n - 3;
+    // aim at >= 160 spans (2 560 waves, a little over what the chip holds at 9 waves per CU); never below 512 Ki positions,
+    // where the 256 Ki warm-up would cost more than the parallelism is worth
+    uint64_t span_len = (total / 160 + 65535) & ~65535ull;
+    if (span_len < (512u << 10)) span_len = 512u << 10;
+    for (uint32_t si = 0; si < hs.size(); si++) {
+        const uint32_t n_pos = hs[si].n - 3;
+        uint32_t parts = (uint32_t)((n_pos + span_len - 1) / span_len);
+        if (parts > 1 && n_pos - (uint64_t)(parts - 1) * span_len < span_len / 2) parts--;  // no short tail span
+        if (parts < 1) parts = 1;
+        const uint32_t len = ((n_pos + parts - 1) / parts + 63) & ~63u;
+        for (uint32_t k = 0; k < parts; k++) {
+            const uint32_t begin = k * len, end = (k + 1 == parts || begin + len > n_pos) ? n_pos : begin + len;
+            if (begin >= n_pos) break;
+            spans.push_back({si, begin > 262144u ? begin - 262144u : 0u, begin, end});
+        }
+    }
+}
+
 int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, const uint64_t *src_off,
                      const uint64_t *src_len, uint8_t *d_dst, const uint64_t *dst_off, const uint64_t *dst_cap,
                      uint64_t *out_lens, int *statuses) {
@@ -1466,8 +718,6 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         LaneGate *g;
         ~GateRelease() { if (g) { int e = 0; g->state.compare_exchange_strong(e, 2); } }
     } gate_release{ctx_gate_out(c)};
-    const char *walk_env = getenv("LZFSE_MI_WALK");
-    const bool serial_walk = walk_env && walk_env[0] == 's';  // diagnostic: the single-wave walker
     std::vector<EncStream> hs;
     for (uint32_t i = 0; i < count; i++) {
         out_lens[i] = 0;
@@ -1485,6 +735,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     // longest streams first: per-stream serial stages of the longest stream bound the batch
     std::stable_sort(hs.begin(), hs.end(), [](const EncStream &a, const EncStream &b) { return a.n > b.n; });
     std::vector<EncTile> ht;
+    std::vector<EncSpan> hspans;
     std::vector<uint32_t> hslots, hrslots;
     std::vector<uint2> hsegs;
     uint64_t pos_total = 0, lmd_total = 0, stage_total = 0, match_total = 0;
@@ -1519,29 +770,27 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         stage_total += e.stage_cap;
         match_total += e.match_cap;
     }
-    const uint32_t nt = (uint32_t)ht.size(), nseg = (uint32_t)hsegs.size();
-    if (nt > 65535) return LZFSE_MI_UNSUPPORTED;  // grid.y limit of the per-tile kernels (4 GiB per call)
+    plan_spans(hs, hspans);
+    const uint32_t nt = (uint32_t)ht.size(), nseg = (uint32_t)hsegs.size(), nsp = (uint32_t)hspans.size();
 
     if (!eb_ensure(S, EB_STREAMS, ns * sizeof(EncStream)) || !eb_ensure(S, EB_TILES, nt * sizeof(EncTile)) ||
-        !eb_ensure(S, EB_PREV, pos_total * 8) || !eb_ensure(S, EB_SUMMARY, (size_t)nt * ((2u << HASH_BITS) + 1) * 4) ||
+        !eb_ensure(S, EB_CAND4, pos_total * 16) || !eb_ensure(S, EB_SPANS, (size_t)nsp * sizeof(EncSpan)) ||
         !eb_ensure(S, EB_REC, pos_total * 8) || !eb_ensure(S, EB_LMDS, lmd_total * 8) ||
         !eb_ensure(S, EB_BLOCKS, (size_t)blk_total * sizeof(EncBlock)) || !eb_ensure(S, EB_OUTS, ns * sizeof(EncStreamOut)) ||
         !eb_ensure(S, EB_STAGE, stage_total + 256) || !eb_ensure(S, EB_SLOTS, (size_t)blk_total * 4) ||
         !eb_ensure(S, EB_BITMAP, pos_total / 8 + 64))
         return LZFSE_MI_IO;
-    if (!serial_walk &&
-        (!eb_ensure(S, EB_SEGS, (size_t)nseg * sizeof(uint2)) || !eb_ensure(S, EB_LOGS, (size_t)nseg * SEG_EV_CAP * sizeof(SpecEvent)) ||
-         !eb_ensure(S, EB_HDRS, (size_t)nseg * sizeof(SpecHeader)) || !eb_ensure(S, EB_RANGES, (size_t)range_total * sizeof(RangeRec)) ||
-         !eb_ensure(S, EB_GAPS, match_total * sizeof(MatchRec)) || !eb_ensure(S, EB_MATCHES, match_total * sizeof(MatchRec)) ||
-         !eb_ensure(S, EB_PC, match_total * 4) || !eb_ensure(S, EB_PL, match_total * 4) ||
-         !eb_ensure(S, EB_RSLOTS, (size_t)range_total * 4) || !eb_ensure(S, EB_SYNC, (size_t)nseg * sizeof(uint4)) ||
-         !eb_ensure(S, EB_RSUM, (size_t)range_total * sizeof(uint2))))
+    if (!eb_ensure(S, EB_SEGS, (size_t)nseg * sizeof(uint2)) || !eb_ensure(S, EB_LOGS, (size_t)nseg * SEG_EV_CAP * sizeof(SpecEvent)) ||
+        !eb_ensure(S, EB_HDRS, (size_t)nseg * sizeof(SpecHeader)) || !eb_ensure(S, EB_RANGES, (size_t)range_total * sizeof(RangeRec)) ||
+        !eb_ensure(S, EB_GAPS, match_total * sizeof(MatchRec)) || !eb_ensure(S, EB_MATCHES, match_total * sizeof(MatchRec)) ||
+        !eb_ensure(S, EB_PC, match_total * 4) || !eb_ensure(S, EB_PL, match_total * 4) ||
+        !eb_ensure(S, EB_RSLOTS, (size_t)range_total * 4) || !eb_ensure(S, EB_SYNC, (size_t)nseg * sizeof(uint4)) ||
+        !eb_ensure(S, EB_RSUM, (size_t)range_total * sizeof(uint2)))
         return LZFSE_MI_IO;
     EncStream *d_streams = (EncStream *)S.bufs[EB_STREAMS];
     EncTile *d_tiles = (EncTile *)S.bufs[EB_TILES];
-    uint2 *d_prev = (uint2 *)S.bufs[EB_PREV];
-    uint32_t *d_summary = (uint32_t *)S.bufs[EB_SUMMARY];
-    uint32_t *d_flist = d_summary + (size_t)nt * (1u << HASH_BITS), *d_fcount = d_flist + (size_t)nt * (1u << HASH_BITS);
+    EncSpan *d_spans = (EncSpan *)S.bufs[EB_SPANS];
+    uint4 *d_cand4 = (uint4 *)S.bufs[EB_CAND4];
     uint2 *d_rec = (uint2 *)S.bufs[EB_REC];
     uint2 *d_lmds = (uint2 *)S.bufs[EB_LMDS];
     EncBlock *d_blocks = (EncBlock *)S.bufs[EB_BLOCKS];
@@ -1551,6 +800,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     uint64_t *d_bitmap = (uint64_t *)S.bufs[EB_BITMAP];
     E_TRY(hipMemcpyAsync(d_streams, hs.data(), ns * sizeof(EncStream), hipMemcpyHostToDevice, stq));
     E_TRY(hipMemcpyAsync(d_tiles, ht.data(), nt * sizeof(EncTile), hipMemcpyHostToDevice, stq));
+    E_TRY(hipMemcpyAsync(d_spans, hspans.data(), (size_t)nsp * sizeof(EncSpan), hipMemcpyHostToDevice, stq));
     E_TRY(hipMemcpyAsync(d_slots, hslots.data(), (size_t)blk_total * 4, hipMemcpyHostToDevice, stq));
     E_TRY(hipMemsetAsync(d_outs, 0, ns * sizeof(EncStreamOut), stq));
     E_TRY(hipMemsetAsync(d_bitmap, 0, pos_total / 8 + 64, stq));
@@ -1560,23 +810,15 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         if (gi->state.load() == 1) (void)hipStreamWaitEvent(stq, gi->ev, 0);
     }
     {
-        StageTimer t(c, "enc_chain");
-        hipLaunchKernelGGL(enc_chain_kernel, dim3(nt), dim3(64), 0, stq, d_src, d_streams, d_tiles, nt, d_prev, d_summary, d_flist, d_fcount);
-    }
-    {
-        StageTimer t(c, "enc_link");
-        hipLaunchKernelGGL(enc_link_kernel, dim3((1u << HASH_BITS) / 256, nt), dim3(256), 0, stq, d_streams, d_tiles, nt, d_prev, d_summary, d_flist, d_fcount);
+        StageTimer t(c, "enc_table");
+        launch_enc_table(d_src, d_streams, d_spans, nsp, d_cand4, stq);
     }
     if (LaneGate *go = ctx_gate_out(c)) go->state.store(hipEventRecord(go->ev, stq) == hipSuccess ? 1 : 2);
     {
         StageTimer t(c, "enc_cand");
-        hipLaunchKernelGGL(enc_cand_kernel, dim3(((nt + 7) / 8) * 8 * CAND_BPT), dim3(256), 0, stq, d_src, d_streams, d_tiles, nt, d_prev, d_rec, d_bitmap,
-                           getenv("LZFSE_MI_CAND_DEBUG") ? atoi(getenv("LZFSE_MI_CAND_DEBUG")) : 0);
+        launch_enc_cand(d_src, d_streams, d_tiles, nt, d_cand4, d_rec, d_bitmap, stq);
     }
-    if (serial_walk) {
-        StageTimer t(c, "enc_walk");
-        hipLaunchKernelGGL(enc_walk_kernel, dim3(ns), dim3(64), 0, stq, d_src, d_streams, ns, d_prev, d_rec, d_lmds, d_blocks, d_outs);
-    } else {
+    {
         uint2 *d_segs = (uint2 *)S.bufs[EB_SEGS];
         SpecEvent *d_logs = (SpecEvent *)S.bufs[EB_LOGS];
         SpecHeader *d_hdrs = (SpecHeader *)S.bufs[EB_HDRS];
@@ -1587,11 +829,11 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         E_TRY(hipMemcpyAsync(d_rslots, hrslots.data(), (size_t)range_total * 4, hipMemcpyHostToDevice, stq));
         {
             StageTimer t(c, "enc_spec");
-            launch_enc_spec(d_src, d_streams, d_segs, nseg, d_prev, d_rec, d_bitmap, d_logs, d_hdrs, stq);
+            launch_enc_spec(d_src, d_streams, d_segs, nseg, d_cand4, d_rec, d_bitmap, d_logs, d_hdrs, stq);
         }
         {
             StageTimer t(c, "enc_stitch");
-            launch_enc_stitch(d_src, d_streams, ns, d_segs, nseg, d_prev, d_rec, d_bitmap, d_logs, d_hdrs, (uint4 *)S.bufs[EB_SYNC], d_ranges, d_gaps,
+            launch_enc_stitch(d_src, d_streams, ns, d_segs, nseg, d_cand4, d_rec, d_bitmap, d_logs, d_hdrs, (uint4 *)S.bufs[EB_SYNC], d_ranges, d_gaps,
                               d_outs, stq);
         }
         {
@@ -1608,10 +850,11 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
             launch_enc_lmd(d_streams, d_slots, blk_total, d_outs, d_blocks, d_matches, d_pc, d_lmds, stq);
         }
     }
+    const int diag_stats = ctx_diag_stats(c);
     {
         StageTimer t(c, "enc_block");
         unsigned long long *d_cyc = nullptr;
-        if (getenv("LZFSE_MI_BLOCK_STATS") && eb_ensure(S, EB_DBG, 64)) {
+        if ((diag_stats & 1) && eb_ensure(S, EB_DBG, 64)) {
             d_cyc = (unsigned long long *)S.bufs[EB_DBG];
             E_TRY(hipMemsetAsync(d_cyc, 0, 64, stq));
         }
@@ -1631,14 +874,14 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         statuses[u] = ho[i].status;
         out_lens[u] = ho[i].status ? 0 : ho[i].out_len;
     }
-    if (getenv("LZFSE_MI_BLOCK_STATS") && S.bufs[EB_DBG]) {
+    if ((diag_stats & 1) && S.bufs[EB_DBG]) {
         unsigned long long hc[8];
         if (hipMemcpy(hc, S.bufs[EB_DBG], 64, hipMemcpyDeviceToHost) == hipSuccess)
             fprintf(stderr, "enc_block cycles/block: gather %llu lit_hist %llu normalize %llu tables %llu | per chunk pass: lookup %llu chains %llu pack+store %llu (blocks %u)\n",
                     hc[0] / blk_total, hc[1] / blk_total, hc[2] / blk_total, hc[3] / blk_total, hc[4] / blk_total, hc[5] / blk_total,
                     hc[6] / blk_total, blk_total);
     }
-    if (getenv("LZFSE_MI_WALK_STATS")) {
+    if (diag_stats & 2) {
         for (uint32_t i = 0; i < ns && i < 16; i++)
             fprintf(stderr, "walk[%u] n=%u segs=%u matches=%u ranges=%u true_iters=%u syncs=%u fallbacks=%u cycles=%llu\n", i, hs[i].n,
                     hs[i].n_seg, ho[i].n_matches, ho[i].n_ranges, ho[i].iters, ho[i].emits, ho[i].capped,
@@ -1647,38 +890,38 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     return LZFSE_MI_OK;
 }
 
-// Debug hook for stage-level parity tests (tests/test_gpu_encode.py): per-position results of
-// the match-finder stages for ONE stream resident in device memory. Not part of the public ABI.
-extern "C" int lzfse_mi_debug_candidates(lzfse_mi_ctx *c, const uint8_t *h_src, size_t n, uint32_t *h_prev, uint32_t *h_rec_xy) {
+#ifdef LZFSE_MI_DIAG
+// Debug hook of the diagnostic build for stage-level parity tests (tests/test_gpu_encode.py): the history rows and the
+// per-position candidate records of ONE stream. Not part of the ABI; the product library does not export it.
+extern "C" int lzfse_mi_debug_candidates(lzfse_mi_ctx *c, const uint8_t *h_src, size_t n, uint32_t *h_rows, uint32_t *h_rec_xy) {
     if (!c || n <= VN_CUTOFF || n > 0x7FFFFFFFull) return LZFSE_MI_BAD_ARGUMENT;
     hipStream_t stq = ctx_stream(c);
     EncScratch &S = ctx_enc(c);
-    EncStream e{};
-    e.src_off = 0; e.pos_base = 0; e.n = (uint32_t)n;
+    std::vector<EncStream> hs(1);
+    hs[0].src_off = 0; hs[0].pos_base = 0; hs[0].n = (uint32_t)n;
     std::vector<EncTile> ht;
-    for (uint32_t p = 0; p < e.n - 3; p += TILE_POS) ht.push_back({0u, p == 0 ? 1u : 0u, p, 0u});
-    uint32_t nt = (uint32_t)ht.size();
+    for (uint32_t p = 0; p < hs[0].n - 3; p += TILE_POS) ht.push_back({0u, p == 0 ? 1u : 0u, p, 0u});
+    std::vector<EncSpan> hspans;
+    plan_spans(hs, hspans);
+    const uint32_t nt = (uint32_t)ht.size(), nsp = (uint32_t)hspans.size();
     size_t padn = (n + 255) & ~(size_t)255;
     if (!eb_ensure(S, EB_STREAMS, sizeof(EncStream)) || !eb_ensure(S, EB_TILES, nt * sizeof(EncTile)) ||
-        !eb_ensure(S, EB_PREV, padn * 8) || !eb_ensure(S, EB_SUMMARY, (size_t)nt * ((2u << HASH_BITS) + 1) * 4) ||
+        !eb_ensure(S, EB_CAND4, padn * 16) || !eb_ensure(S, EB_SPANS, (size_t)nsp * sizeof(EncSpan)) ||
         !eb_ensure(S, EB_REC, padn * 8) || !eb_ensure(S, EB_STAGE, padn + 256) || !eb_ensure(S, EB_BITMAP, padn / 8 + 64))
         return LZFSE_MI_IO;
     uint8_t *d_src = (uint8_t *)S.bufs[EB_STAGE];
     E_TRY(hipMemcpyAsync(d_src, h_src, n, hipMemcpyHostToDevice, stq));
-    E_TRY(hipMemcpyAsync(S.bufs[EB_STREAMS], &e, sizeof e, hipMemcpyHostToDevice, stq));
+    E_TRY(hipMemcpyAsync(S.bufs[EB_STREAMS], hs.data(), sizeof(EncStream), hipMemcpyHostToDevice, stq));
     E_TRY(hipMemcpyAsync(S.bufs[EB_TILES], ht.data(), nt * sizeof(EncTile), hipMemcpyHostToDevice, stq));
-    uint32_t *dbg_summary = (uint32_t *)S.bufs[EB_SUMMARY];
-    uint32_t *dbg_flist = dbg_summary + (size_t)nt * (1u << HASH_BITS), *dbg_fcount = dbg_flist + (size_t)nt * (1u << HASH_BITS);
-    hipLaunchKernelGGL(enc_chain_kernel, dim3(nt), dim3(64), 0, stq, d_src, (EncStream *)S.bufs[EB_STREAMS], (EncTile *)S.bufs[EB_TILES], nt,
-                       (uint2 *)S.bufs[EB_PREV], dbg_summary, dbg_flist, dbg_fcount);
-    hipLaunchKernelGGL(enc_link_kernel, dim3((1u << HASH_BITS) / 256, nt), dim3(256), 0, stq, (EncStream *)S.bufs[EB_STREAMS],
-                       (EncTile *)S.bufs[EB_TILES], nt, (uint2 *)S.bufs[EB_PREV], dbg_summary, dbg_flist, dbg_fcount);
-    hipLaunchKernelGGL(enc_cand_kernel, dim3(((nt + 7) / 8) * 8 * CAND_BPT), dim3(256), 0, stq, d_src, (EncStream *)S.bufs[EB_STREAMS],
-                       (EncTile *)S.bufs[EB_TILES], nt, (uint2 *)S.bufs[EB_PREV], (uint2 *)S.bufs[EB_REC], (uint64_t *)S.bufs[EB_BITMAP], 0);
-    E_TRY(hipMemcpyAsync(h_prev, S.bufs[EB_PREV], (n - 3) * 8, hipMemcpyDeviceToHost, stq));  // {prev, value} pairs
+    E_TRY(hipMemcpyAsync(S.bufs[EB_SPANS], hspans.data(), (size_t)nsp * sizeof(EncSpan), hipMemcpyHostToDevice, stq));
+    launch_enc_table(d_src, (EncStream *)S.bufs[EB_STREAMS], (EncSpan *)S.bufs[EB_SPANS], nsp, (uint4 *)S.bufs[EB_CAND4], stq);
+    launch_enc_cand(d_src, (EncStream *)S.bufs[EB_STREAMS], (EncTile *)S.bufs[EB_TILES], nt, (uint4 *)S.bufs[EB_CAND4],
+                    (uint2 *)S.bufs[EB_REC], (uint64_t *)S.bufs[EB_BITMAP], stq);
+    E_TRY(hipMemcpyAsync(h_rows, S.bufs[EB_CAND4], (n - 3) * 16, hipMemcpyDeviceToHost, stq));  // 4 positions per position
     E_TRY(hipMemcpyAsync(h_rec_xy, S.bufs[EB_REC], (n - 3) * 8, hipMemcpyDeviceToHost, stq));
     E_TRY(hipStreamSynchronize(stq));
     return hipGetLastError() == hipSuccess ? LZFSE_MI_OK : LZFSE_MI_IO;
 }
+#endif
 
 }  // namespace lzmi

@@ -976,6 +976,24 @@ int lzo_candidates(const uint8_t *src, size_t n, uint32_t *match_idx, uint32_t *
     return LZO_OK;
 }
 
+/* Stage-0 dump for GPU parity: the candidate queue (history.rs:110-118 push returns the pre-insert row) of every
+ * position as if all positions were inserted in order, which is what the encoder does (frontend_bytes.rs:187,336-344).
+ * rows[4 i + c] = idx of candidate c (newest first), 0xFFFFFFFF for the reset sentinel (history.rs:72-84). */
+int lzo_table_rows(const uint8_t *src, size_t n, uint32_t *rows) {
+    if (n <= VN_CUTOFF || n > (size_t)0x7FFFFFFFu) return LZO_UNSUPPORTED;
+    history_t *table = (history_t *)malloc(sizeof(history_t) << HASH_BITS);
+    if (!table) return LZO_IO;
+    table_reset(table);
+    for (uint32_t i = 0; i + 4 <= n; i++) {
+        uint32_t val = ld32(src + i);
+        history_t queue = table_push(table, 0, val, i);
+        for (int c = 0; c < HASH_WIDTH; c++)
+            rows[4 * (size_t)i + c] = queue.q[c].idx >= 0x80000000u ? 0xFFFFFFFFu : queue.q[c].idx;
+    }
+    free(table);
+    return LZO_OK;
+}
+
 /* ================================================================== decoder */
 
 /* fse/decoder.rs:205-238 */

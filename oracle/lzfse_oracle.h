@@ -96,6 +96,8 @@ int lzo_decode_size(const uint8_t *src, size_t n, uint64_t *raw_len);
  * if none) and fwd_len[i]. Valid because every position is inserted exactly once in
  * order (frontend_bytes.rs:187,336-344). n must be > 4096 (Fse backend type). */
 int lzo_candidates(const uint8_t *src, size_t n, uint32_t *match_idx, uint32_t *fwd_len);
+/* candidate queue (4 positions, newest first, 0xFFFFFFFF = empty) of every position 0 .. n-4 */
+int lzo_table_rows(const uint8_t *src, size_t n, uint32_t *rows);
 
 /* Low-level restatements exported for known-answer tests. */
 void lzo_normalize_m1(uint16_t *weights, uint32_t n_weights, uint32_t in_total, uint32_t out_total);

@@ -36,3 +36,11 @@ def snappy_raw(oracle):
         assert hashlib.sha256(raw).digest() == open(f[:-6] + ".hash", "rb").read()
         out[name] = raw
     return out
+
+
+@pytest.fixture(scope="session")
+def diag_ctx():
+    """Context on the diagnostic build of the library (liblzfse_mi_diag.so): the LZFSE_MI_OPT_DIAG_* options that force a
+    code path exist there only. Tests that do not force anything use the product library."""
+    import lzfse_rust_amd as m
+    return m.Context(0, diag=True)

@@ -44,6 +44,8 @@ class Oracle:
         lib.lzo_decode_size.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
         lib.lzo_candidates.restype = C.c_int
         lib.lzo_candidates.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        lib.lzo_table_rows.restype = C.c_int
+        lib.lzo_table_rows.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         lib.lzo_normalize_m1.restype = None
         lib.lzo_normalize_m1.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
         lib.lzo_weights_store_v2.restype = C.c_uint32
@@ -127,6 +129,15 @@ class Oracle:
         if st != 0:
             raise OracleError(st)
         return mi[: a.size - 3], fl[: a.size - 3]
+
+
+    def table_rows(self, data):
+        a, p = self._buf(data)
+        rows = np.empty((a.size, 4), dtype=np.uint32)
+        st = self.lib.lzo_table_rows(p, a.size, rows.ctypes.data)
+        if st != 0:
+            raise OracleError(st)
+        return rows[: a.size - 3]
 
 
 class OracleError(Exception):

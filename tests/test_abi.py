@@ -76,6 +76,23 @@ def test_product_never_touches_oracle():
                 assert "oracle" not in txt.lower().replace("oracle/ (", "") or f == "codec.py" and False, (dirpath, f)
 
 
+def test_product_library_reads_no_environment_and_has_no_debug_hook():
+    """Debug knobs live in the diagnostic build only (liblzfse_mi_diag.so): the shipped library imports no getenv and
+    does not export the stage hook; the diagnostic one exports it."""
+    import shutil
+    import subprocess
+    from lzfse_rust_amd import build
+    build.build()
+    nm = shutil.which("nm") or "/usr/bin/nm"
+    und = subprocess.check_output([nm, "-D", "--undefined-only", build.LIB_PATH], text=True)
+    assert "getenv" not in und
+    prod = subprocess.check_output([nm, "-D", "--defined-only", build.LIB_PATH], text=True)
+    diag = subprocess.check_output([nm, "-D", "--defined-only", build.DIAG_LIB_PATH], text=True)
+    assert "lzfse_mi_debug_candidates" not in prod and "lzfse_mi_debug_candidates" in diag
+    for n in _declared_functions(os.path.join(ROOT, "include", "lzfse_mi.h")):
+        assert n in prod and n in diag, n
+
+
 def test_status_strings(lib):
     assert lib.lzfse_mi_status_string(0) == b"ok"
     assert b"LMD payload" in lib.lzfse_mi_status_string(22)

@@ -52,13 +52,13 @@ def test_config2_decode_64mib_oracle_stream(ctx, text64, text64_oracle_stream):
     assert hashlib.sha256(outs[0].tobytes()).digest() == hashlib.sha256(text64).digest()
 
 
-def test_config2_decode_64mib_tile_path(ctx, text64, text64_oracle_stream):
+def test_config2_decode_64mib_tile_path(diag_ctx, text64, text64_oracle_stream):
     """The same stream through the per-stream tile kernel (what a batch of many such streams takes)."""
-    os.environ["LZFSE_MI_LZ_JUMP"] = "0"
+    diag_ctx.set_option("diag_lz_path", 0)
     try:
-        outs, st = ctx.decode_batch([text64_oracle_stream])
+        outs, st = diag_ctx.decode_batch([text64_oracle_stream])
     finally:
-        del os.environ["LZFSE_MI_LZ_JUMP"]
+        diag_ctx.set_option("diag_lz_path", -1)
     assert st[0] == 0
     assert hashlib.sha256(outs[0].tobytes()).digest() == hashlib.sha256(text64).digest()
 

@@ -74,17 +74,17 @@ def test_damaged_multi_block_stream_status_codes(ctx, oracle, snappy_raw):
     _check_cases(ctx, oracle, cases, len(raw) + 4096)
 
 
-def test_damaged_streams_pointer_jumping_path(ctx, oracle, snappy_raw, golden_dir):
+def test_damaged_streams_pointer_jumping_path(diag_ctx, oracle, snappy_raw, golden_dir):
     raw = snappy_raw["urls.10K"]
     enc = oracle.encode(raw)
     base = open(os.path.join(golden_dir, "mutate", "vx2.lzfse"), "rb").read()
     rng = np.random.default_rng(5)
     cases = _mutations(enc, rng, 120, 40, 20) + _mutations(base, rng, 120, 40, 20)
-    os.environ["LZFSE_MI_LZ_JUMP"] = "1"
+    diag_ctx.set_option("diag_lz_path", 1)
     try:
-        _check_cases(ctx, oracle, cases, len(raw) + 4096)
+        _check_cases(diag_ctx, oracle, cases, len(raw) + 4096)
     finally:
-        del os.environ["LZFSE_MI_LZ_JUMP"]
+        diag_ctx.set_option("diag_lz_path", -1)
 
 
 def test_jump_path_fresh_scratch_odd_sizes(oracle):

@@ -62,16 +62,25 @@ def test_split_decode_statuses_per_stream(ctx, oracle, snappy_raw):
             assert s == 0 and o.tobytes() == r
 
 
-def test_split_lane_count_override(snappy_raw, oracle):
-    """LZFSE_MI_LANES_* are read when the first batch call of a process is made, so this only checks that the
-    default (2 lanes) leaves a result identical to a batch too small to be split."""
+def test_split_lane_count_option(snappy_raw, oracle):
+    """LZFSE_MI_OPT_ENCODE_LANES / _DECODE_LANES: every lane count leaves the bytes of an unsplit call."""
     import lzfse_rust_amd as m
     c = m.Context(0)
     r = snappy_raw["html"]
-    small, _ = c.encode_batch([r])             # never split
-    many, st = c.encode_batch([r] * 48)        # 4.9 MB, split
-    assert all(e == 0 for e in st)
-    assert all(o.tobytes() == small[0].tobytes() for o in many)
+    want = oracle.encode(r)
+    for lanes in (1, 2, 3, 4, 0):
+        c.set_option("encode_lanes", lanes)
+        c.set_option("decode_lanes", lanes)
+        many, st = c.encode_batch([r] * 96)        # 9.8 MB: enough for four lanes
+        assert all(e == 0 for e in st)
+        assert all(o.tobytes() == want for o in many)
+        back, st = c.decode_batch([want] * 96)
+        assert all(e == 0 for e in st) and all(o.tobytes() == r for o in back)
+    c.set_option("stagger", 0)
+    many, st = c.encode_batch([r] * 96)
+    assert all(e == 0 for e in st) and all(o.tobytes() == want for o in many)
+    with pytest.raises(m.LzfseError):
+        c.set_option("diag_lz_path", 1)   # the product library has no diagnostic options
 
 
 def test_many_mid_size_streams_take_the_per_stream_lz_path(ctx, snappy_raw):
