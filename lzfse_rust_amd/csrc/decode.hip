@@ -957,7 +957,7 @@ __global__ __launch_bounds__(JUMP_THREADS) void dec_jump_init_kernel(
     const BlockResult br = bres[b];
     const LmdRec *bl = lmds + d.lmd_base;
     if (br.status) {
-        int e = lmds_first_fault<JUMP_THREADS>(bl, br.ok_until, o0, ~0ull, sh);  // (jumping streams fit their destination)
+        int e = lmds_first_fault<JUMP_THREADS>(bl, br.ok_until, o0, in.dst_cap, sh);  // (a damaged block may overrun it)
         if (!e) e = br.status;
         if (tid == 0) atomicMin(&jerr[d.stream], (bi << 8) | (uint32_t)e);
         return;
