@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--replicas", type=int, default=256, help="copies of the 12-file corpus per GPU (256: 3072 streams, 752 MB)")
     ap.add_argument("--workload", default="snappy", choices=["snappy", "text64m", "chunks4m", "chunks1g"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lanes", type=int, default=0, help="sub-batches run side by side per call (0: library default, 1: unsplit)")
     args = ap.parse_args()
 
     import torch
@@ -93,6 +94,9 @@ def main():
     import lzfse_rust_amd as lz
     ctx = lz.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    if args.lanes:
+        ctx.set_option("encode_lanes", args.lanes)
+        ctx.set_option("decode_lanes", args.lanes)
 
     # ---- build the per-GPU batch (untimed) ----
     names, fixture_streams, hashes = load_corpus_streams()

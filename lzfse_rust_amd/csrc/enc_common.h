@@ -4,14 +4,12 @@
 
 namespace lzmi {
 
-constexpr uint32_t TILE_POS = 65536;        // positions per candidate tile (one XCD-local group of workgroups)
-constexpr uint32_t CAND_BPT = TILE_POS / 256;   // workgroups per tile
-constexpr int TB_PART_BITS = 4;             // the history table's buckets are cut into 2^4 partitions, one wave each
-constexpr int TB_PARTS = 1 << TB_PART_BITS;
+constexpr uint32_t TILE_POS = 65472;        // positions per chain tile: multiple of 64 and of CAND_P, offset + 1 fits u16
 constexpr uint32_t SEG = 2048;              // positions per speculative-parse segment
 constexpr uint32_t OVER = 512;              // overrun of a segment walker into the next segment
 constexpr uint32_t SEG_EV_CAP = (SEG + OVER) / 4 + 4;  // every emit advances literal_index by >= 4
-constexpr uint32_t NONE = 0xFFFFFFFFu;      // empty slot of a history row
+constexpr uint32_t NONE = 0xFFFFFFFFu;      // no previous position
+constexpr uint32_t NONE_TILE = 0xFFFFFFFEu; // no previous position inside the tile (link pending)
 constexpr uint32_t FCAP = 1024;             // cap of the forward length computed per position (>= GOOD_MATCH_LEN)
 constexpr uint32_t XCAP = 4096;             // cap of the exact per-lane extension in the segment walkers
 constexpr uint32_t BCAP = 32;               // cap of the backward length computed per position
@@ -23,7 +21,7 @@ __device__ __forceinline__ uint32_t bucket_of(uint32_t v) { return (v * 0x9E3779
 
 struct EncStream {       // one input stream (n > VN_CUTOFF) of the batch
     uint64_t src_off;    // offset of the stream in d_src
-    uint64_t pos_base;   // offset of the stream in the per-position arrays (cand4, rec)
+    uint64_t pos_base;   // offset of the stream in the per-position arrays (prev, rec)
     uint64_t dst_off, dst_cap;
     uint64_t lmd_base;   // offset into the LMD array
     uint64_t stage_base; // offset into the block staging area
@@ -65,12 +63,6 @@ struct EncTile {
     uint32_t pad;
 };
 
-struct EncSpan {         // unit of the history-table replay (enc_table_kernel)
-    uint32_t stream;
-    uint32_t first;      // first position inserted (warm-up from here, no output)
-    uint32_t begin, end; // positions [begin, end) get their candidate rows written
-};
-
 struct EncBlock {        // one bvx2 block (written by the walk kernel)
     uint64_t lmd_start;  // index into the LMD array
     uint64_t stage_off;  // staging offset of this block's bytes
@@ -101,14 +93,17 @@ __host__ __device__ inline uint32_t stage_need(uint32_t n_lit, uint32_t n_lmd) {
 
 
 // encode_match.hip
-void launch_enc_table(const uint8_t *src, const EncStream *streams, const EncSpan *spans, uint32_t n_spans, uint4 *cand4, hipStream_t st);
-void launch_enc_cand(const uint8_t *src, const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, const uint4 *cand4, uint2 *rec,
+void launch_enc_chain(const uint8_t *src, const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, uint2 *prev, uint32_t *summary,
+                      uint32_t *flist, uint32_t *fcount, hipStream_t st);
+void launch_enc_link(const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, uint2 *prev, const uint32_t *summary,
+                     const uint32_t *flist, const uint32_t *fcount, hipStream_t st);
+void launch_enc_cand(const uint8_t *src, const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, const uint2 *prev, uint2 *rec,
                      uint64_t *bitmap, hipStream_t st);
 
 // encode_parse.hip
-void launch_enc_spec(const uint8_t *src, const EncStream *streams, const uint2 *segs, uint32_t n_segs, const uint4 *cand4,
+void launch_enc_spec(const uint8_t *src, const EncStream *streams, const uint2 *segs, uint32_t n_segs, const uint2 *prev,
                      const uint2 *rec, const uint64_t *bitmap, SpecEvent *logs, SpecHeader *hdrs, hipStream_t st);
-void launch_enc_stitch(const uint8_t *src, const EncStream *streams, uint32_t ns, const uint2 *segs, uint32_t n_segs, const uint4 *cand4,
+void launch_enc_stitch(const uint8_t *src, const EncStream *streams, uint32_t ns, const uint2 *segs, uint32_t n_segs, const uint2 *prev,
                        const uint2 *rec, const uint64_t *bitmap, const SpecEvent *logs, const SpecHeader *hdrs, uint4 *sync,
                        RangeRec *ranges, MatchRec *gaps, EncStreamOut *outs, hipStream_t st);
 void launch_enc_compact(const EncStream *streams, const uint32_t *slot_stream, uint32_t n_slots, uint32_t ns, const EncStreamOut *outs,

@@ -1,6 +1,6 @@
 // Encode side of the MI355X LZFSE codec: hand-written HIP kernels for gfx950 (wave64).
 //
-// Match finding lives in encode_match.hip (history-table replay + per-position candidates), the parse in
+// Match finding lives in encode_match.hip (bucket chains + per-position candidates), the parse in
 // encode_parse.hip (speculative segment walks, stitching, block segmentation). Here:
 //
 //   enc_block_kernel   per bvx2 block: literal gather, histograms, normalize_m1 (weights.rs:
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(256) void enc_pack_kernel(const EncStream *__restri
 
 // ------------------------------------------------------------------------------------ host side
 
-enum { EB_STREAMS, EB_TILES, EB_CAND4, EB_SPANS, EB_REC, EB_LMDS, EB_BLOCKS, EB_OUTS, EB_STAGE, EB_SLOTS,
+enum { EB_STREAMS, EB_TILES, EB_PREV, EB_SUMMARY, EB_REC, EB_LMDS, EB_BLOCKS, EB_OUTS, EB_STAGE, EB_SLOTS,
        EB_BITMAP, EB_SEGS, EB_LOGS, EB_HDRS, EB_RANGES, EB_GAPS, EB_MATCHES, EB_PC, EB_PL, EB_RSLOTS, EB_SYNC, EB_RSUM, EB_DBG, EB_N };
 static_assert(EB_N <= 32, "EncScratch slots");
 
@@ -684,29 +684,6 @@ void enc_scratch_release(EncScratch &s) {
 }
 
 #define E_TRY(x) do { if ((x) != hipSuccess) return LZFSE_MI_IO; } while (0)
-
-// Spans of the history-table replay (encode_match.hip): a stream is one span unless that would leave the chip short of
-// waves (16 per span) or one wave with a much longer scan than the rest; further spans replay TB_WARM positions first.
-static void plan_spans(const std::vector<EncStream> &hs, std::vector<EncSpan> &spans) {
-    uint64_t total = 0;
-    for (const EncStream &e : hs) total += e.n - 3;
-    // aim at >= 160 spans (2 560 waves, a little over what the chip holds at 9 waves per CU); never below 512 Ki positions,
-    // where the 256 Ki warm-up would cost more than the parallelism is worth
-    uint64_t span_len = (total / 160 + 65535) & ~65535ull;
-    if (span_len < (512u << 10)) span_len = 512u << 10;
-    for (uint32_t si = 0; si < hs.size(); si++) {
-        const uint32_t n_pos = hs[si].n - 3;
-        uint32_t parts = (uint32_t)((n_pos + span_len - 1) / span_len);
-        if (parts > 1 && n_pos - (uint64_t)(parts - 1) * span_len < span_len / 2) parts--;  // no short tail span
-        if (parts < 1) parts = 1;
-        const uint32_t len = ((n_pos + parts - 1) / parts + 63) & ~63u;
-        for (uint32_t k = 0; k < parts; k++) {
-            const uint32_t begin = k * len, end = (k + 1 == parts || begin + len > n_pos) ? n_pos : begin + len;
-            if (begin >= n_pos) break;
-            spans.push_back({si, begin > 262144u ? begin - 262144u : 0u, begin, end});
-        }
-    }
-}
 
 int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, const uint64_t *src_off,
                      const uint64_t *src_len, uint8_t *d_dst, const uint64_t *dst_off, const uint64_t *dst_cap,
@@ -735,7 +712,6 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     // longest streams first: per-stream serial stages of the longest stream bound the batch
     std::stable_sort(hs.begin(), hs.end(), [](const EncStream &a, const EncStream &b) { return a.n > b.n; });
     std::vector<EncTile> ht;
-    std::vector<EncSpan> hspans;
     std::vector<uint32_t> hslots, hrslots;
     std::vector<uint2> hsegs;
     uint64_t pos_total = 0, lmd_total = 0, stage_total = 0, match_total = 0;
@@ -770,11 +746,10 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         stage_total += e.stage_cap;
         match_total += e.match_cap;
     }
-    plan_spans(hs, hspans);
-    const uint32_t nt = (uint32_t)ht.size(), nseg = (uint32_t)hsegs.size(), nsp = (uint32_t)hspans.size();
+    const uint32_t nt = (uint32_t)ht.size(), nseg = (uint32_t)hsegs.size();
 
     if (!eb_ensure(S, EB_STREAMS, ns * sizeof(EncStream)) || !eb_ensure(S, EB_TILES, nt * sizeof(EncTile)) ||
-        !eb_ensure(S, EB_CAND4, pos_total * 16) || !eb_ensure(S, EB_SPANS, (size_t)nsp * sizeof(EncSpan)) ||
+        !eb_ensure(S, EB_PREV, pos_total * 8) || !eb_ensure(S, EB_SUMMARY, (size_t)nt * ((2u << HASH_BITS) + 1) * 4) ||
         !eb_ensure(S, EB_REC, pos_total * 8) || !eb_ensure(S, EB_LMDS, lmd_total * 8) ||
         !eb_ensure(S, EB_BLOCKS, (size_t)blk_total * sizeof(EncBlock)) || !eb_ensure(S, EB_OUTS, ns * sizeof(EncStreamOut)) ||
         !eb_ensure(S, EB_STAGE, stage_total + 256) || !eb_ensure(S, EB_SLOTS, (size_t)blk_total * 4) ||
@@ -789,8 +764,9 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         return LZFSE_MI_IO;
     EncStream *d_streams = (EncStream *)S.bufs[EB_STREAMS];
     EncTile *d_tiles = (EncTile *)S.bufs[EB_TILES];
-    EncSpan *d_spans = (EncSpan *)S.bufs[EB_SPANS];
-    uint4 *d_cand4 = (uint4 *)S.bufs[EB_CAND4];
+    uint2 *d_prev = (uint2 *)S.bufs[EB_PREV];
+    uint32_t *d_summary = (uint32_t *)S.bufs[EB_SUMMARY];
+    uint32_t *d_flist = d_summary + (size_t)nt * (1u << HASH_BITS), *d_fcount = d_flist + (size_t)nt * (1u << HASH_BITS);
     uint2 *d_rec = (uint2 *)S.bufs[EB_REC];
     uint2 *d_lmds = (uint2 *)S.bufs[EB_LMDS];
     EncBlock *d_blocks = (EncBlock *)S.bufs[EB_BLOCKS];
@@ -800,7 +776,6 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     uint64_t *d_bitmap = (uint64_t *)S.bufs[EB_BITMAP];
     E_TRY(hipMemcpyAsync(d_streams, hs.data(), ns * sizeof(EncStream), hipMemcpyHostToDevice, stq));
     E_TRY(hipMemcpyAsync(d_tiles, ht.data(), nt * sizeof(EncTile), hipMemcpyHostToDevice, stq));
-    E_TRY(hipMemcpyAsync(d_spans, hspans.data(), (size_t)nsp * sizeof(EncSpan), hipMemcpyHostToDevice, stq));
     E_TRY(hipMemcpyAsync(d_slots, hslots.data(), (size_t)blk_total * 4, hipMemcpyHostToDevice, stq));
     E_TRY(hipMemsetAsync(d_outs, 0, ns * sizeof(EncStreamOut), stq));
     E_TRY(hipMemsetAsync(d_bitmap, 0, pos_total / 8 + 64, stq));
@@ -810,13 +785,17 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         if (gi->state.load() == 1) (void)hipStreamWaitEvent(stq, gi->ev, 0);
     }
     {
-        StageTimer t(c, "enc_table");
-        launch_enc_table(d_src, d_streams, d_spans, nsp, d_cand4, stq);
+        StageTimer t(c, "enc_chain");
+        launch_enc_chain(d_src, d_streams, d_tiles, nt, d_prev, d_summary, d_flist, d_fcount, stq);
+    }
+    {
+        StageTimer t(c, "enc_link");
+        launch_enc_link(d_streams, d_tiles, nt, d_prev, d_summary, d_flist, d_fcount, stq);
     }
     if (LaneGate *go = ctx_gate_out(c)) go->state.store(hipEventRecord(go->ev, stq) == hipSuccess ? 1 : 2);
     {
         StageTimer t(c, "enc_cand");
-        launch_enc_cand(d_src, d_streams, d_tiles, nt, d_cand4, d_rec, d_bitmap, stq);
+        launch_enc_cand(d_src, d_streams, d_tiles, nt, d_prev, d_rec, d_bitmap, stq);
     }
     {
         uint2 *d_segs = (uint2 *)S.bufs[EB_SEGS];
@@ -829,11 +808,11 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         E_TRY(hipMemcpyAsync(d_rslots, hrslots.data(), (size_t)range_total * 4, hipMemcpyHostToDevice, stq));
         {
             StageTimer t(c, "enc_spec");
-            launch_enc_spec(d_src, d_streams, d_segs, nseg, d_cand4, d_rec, d_bitmap, d_logs, d_hdrs, stq);
+            launch_enc_spec(d_src, d_streams, d_segs, nseg, d_prev, d_rec, d_bitmap, d_logs, d_hdrs, stq);
         }
         {
             StageTimer t(c, "enc_stitch");
-            launch_enc_stitch(d_src, d_streams, ns, d_segs, nseg, d_cand4, d_rec, d_bitmap, d_logs, d_hdrs, (uint4 *)S.bufs[EB_SYNC], d_ranges, d_gaps,
+            launch_enc_stitch(d_src, d_streams, ns, d_segs, nseg, d_prev, d_rec, d_bitmap, d_logs, d_hdrs, (uint4 *)S.bufs[EB_SYNC], d_ranges, d_gaps,
                               d_outs, stq);
         }
         {
@@ -891,33 +870,33 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
 }
 
 #ifdef LZFSE_MI_DIAG
-// Debug hook of the diagnostic build for stage-level parity tests (tests/test_gpu_encode.py): the history rows and the
+// Debug hook of the diagnostic build for stage-level parity tests (tests/test_gpu_encode.py): the chain links and the
 // per-position candidate records of ONE stream. Not part of the ABI; the product library does not export it.
-extern "C" int lzfse_mi_debug_candidates(lzfse_mi_ctx *c, const uint8_t *h_src, size_t n, uint32_t *h_rows, uint32_t *h_rec_xy) {
+extern "C" int lzfse_mi_debug_candidates(lzfse_mi_ctx *c, const uint8_t *h_src, size_t n, uint32_t *h_prev, uint32_t *h_rec_xy) {
     if (!c || n <= VN_CUTOFF || n > 0x7FFFFFFFull) return LZFSE_MI_BAD_ARGUMENT;
     hipStream_t stq = ctx_stream(c);
     EncScratch &S = ctx_enc(c);
-    std::vector<EncStream> hs(1);
-    hs[0].src_off = 0; hs[0].pos_base = 0; hs[0].n = (uint32_t)n;
+    EncStream e{};
+    e.src_off = 0; e.pos_base = 0; e.n = (uint32_t)n;
     std::vector<EncTile> ht;
-    for (uint32_t p = 0; p < hs[0].n - 3; p += TILE_POS) ht.push_back({0u, p == 0 ? 1u : 0u, p, 0u});
-    std::vector<EncSpan> hspans;
-    plan_spans(hs, hspans);
-    const uint32_t nt = (uint32_t)ht.size(), nsp = (uint32_t)hspans.size();
+    for (uint32_t p = 0; p < e.n - 3; p += TILE_POS) ht.push_back({0u, p == 0 ? 1u : 0u, p, 0u});
+    const uint32_t nt = (uint32_t)ht.size();
     size_t padn = (n + 255) & ~(size_t)255;
     if (!eb_ensure(S, EB_STREAMS, sizeof(EncStream)) || !eb_ensure(S, EB_TILES, nt * sizeof(EncTile)) ||
-        !eb_ensure(S, EB_CAND4, padn * 16) || !eb_ensure(S, EB_SPANS, (size_t)nsp * sizeof(EncSpan)) ||
+        !eb_ensure(S, EB_PREV, padn * 8) || !eb_ensure(S, EB_SUMMARY, (size_t)nt * ((2u << HASH_BITS) + 1) * 4) ||
         !eb_ensure(S, EB_REC, padn * 8) || !eb_ensure(S, EB_STAGE, padn + 256) || !eb_ensure(S, EB_BITMAP, padn / 8 + 64))
         return LZFSE_MI_IO;
     uint8_t *d_src = (uint8_t *)S.bufs[EB_STAGE];
     E_TRY(hipMemcpyAsync(d_src, h_src, n, hipMemcpyHostToDevice, stq));
-    E_TRY(hipMemcpyAsync(S.bufs[EB_STREAMS], hs.data(), sizeof(EncStream), hipMemcpyHostToDevice, stq));
+    E_TRY(hipMemcpyAsync(S.bufs[EB_STREAMS], &e, sizeof e, hipMemcpyHostToDevice, stq));
     E_TRY(hipMemcpyAsync(S.bufs[EB_TILES], ht.data(), nt * sizeof(EncTile), hipMemcpyHostToDevice, stq));
-    E_TRY(hipMemcpyAsync(S.bufs[EB_SPANS], hspans.data(), (size_t)nsp * sizeof(EncSpan), hipMemcpyHostToDevice, stq));
-    launch_enc_table(d_src, (EncStream *)S.bufs[EB_STREAMS], (EncSpan *)S.bufs[EB_SPANS], nsp, (uint4 *)S.bufs[EB_CAND4], stq);
-    launch_enc_cand(d_src, (EncStream *)S.bufs[EB_STREAMS], (EncTile *)S.bufs[EB_TILES], nt, (uint4 *)S.bufs[EB_CAND4],
-                    (uint2 *)S.bufs[EB_REC], (uint64_t *)S.bufs[EB_BITMAP], stq);
-    E_TRY(hipMemcpyAsync(h_rows, S.bufs[EB_CAND4], (n - 3) * 16, hipMemcpyDeviceToHost, stq));  // 4 positions per position
+    uint32_t *sm = (uint32_t *)S.bufs[EB_SUMMARY];
+    uint32_t *fl = sm + (size_t)nt * (1u << HASH_BITS), *fc = fl + (size_t)nt * (1u << HASH_BITS);
+    launch_enc_chain(d_src, (EncStream *)S.bufs[EB_STREAMS], (EncTile *)S.bufs[EB_TILES], nt, (uint2 *)S.bufs[EB_PREV], sm, fl, fc, stq);
+    launch_enc_link((EncStream *)S.bufs[EB_STREAMS], (EncTile *)S.bufs[EB_TILES], nt, (uint2 *)S.bufs[EB_PREV], sm, fl, fc, stq);
+    launch_enc_cand(d_src, (EncStream *)S.bufs[EB_STREAMS], (EncTile *)S.bufs[EB_TILES], nt, (uint2 *)S.bufs[EB_PREV], (uint2 *)S.bufs[EB_REC],
+                    (uint64_t *)S.bufs[EB_BITMAP], stq);
+    E_TRY(hipMemcpyAsync(h_prev, S.bufs[EB_PREV], (n - 3) * 8, hipMemcpyDeviceToHost, stq));  // {prev, value} pairs
     E_TRY(hipMemcpyAsync(h_rec_xy, S.bufs[EB_REC], (n - 3) * 8, hipMemcpyDeviceToHost, stq));
     E_TRY(hipStreamSynchronize(stq));
     return hipGetLastError() == hipSuccess ? LZFSE_MI_OK : LZFSE_MI_IO;

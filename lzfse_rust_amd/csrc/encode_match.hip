@@ -1,128 +1,132 @@
 // Match finding of the MI355X LZFSE encoder: hand-written HIP kernels for gfx950 (wave64).
 //
-// The reference keeps a history table of 2^14 buckets x 4 entries, newest first (encode/history.rs:15-118). At
-// position i it copies the row of bucket(src[i..i+4]) (the candidate queue), shift-inserts i, and scans the queue
-// newest -> oldest (encode/frontend_bytes.rs:183-244). Every position is inserted exactly once and in order
-// (frontend_bytes.rs:187,336-344), so the queue a position sees is a pure function of src[0..i+3]:
+// The reference's encoder is a serial greedy/lazy parse over a 4-way, 2^14-bucket history
+// table (encode/frontend_bytes.rs:160-268, encode/history.rs:15-118). Its table state before
+// position i is a pure function of src[0..i+3] because every position is inserted exactly once,
+// in order (frontend_bytes.rs:187,336-344). That makes the expensive part position-parallel:
 //
-//   enc_table_kernel   replays the table itself. The buckets are cut into 16 partitions; one wave per partition
-//                      and span keeps its 1 024 rows (16 KiB) in LDS, scans the span's positions in order, picks
-//                      those that hash into its partition and writes, for each, the row it found: the position's
-//                      four candidates, 16 bytes. No chains, no dependent hops later on.
-//   enc_cand_kernel    one lane per position: distance gate with the reference's *break* (frontend_bytes.rs:
-//                      222-224), forward length of every candidate (match_kit/match_fast.rs:22-49), best on forward
-//                      length with ties to the newest (:226), backward length of the winner (:61-89), both capped
+//   enc_chain_kernel   per 64 Ki-position tile: prev[i] = previous position in the same bucket
+//                      (history.rs:221-224 hash, fse/object.rs:38-43), exact, in-order, with a
+//                      16 384-entry last-seen table in LDS and ballot matching inside a wave
+//   enc_link_kernel    first occurrences of a tile: link to earlier tiles (window 262 139)
+//   enc_cand_kernel    per position: walk <= 4 chain entries newest->oldest with the reference's
+//                      gates (frontend_bytes.rs:214-231), forward LCP (match_kit/match_fast.rs:
+//                      22-49) and un-gated backward LCS (:61-89), both capped
+//
+// (A replay of the 4-entry table itself -- bucket-partitioned tables in LDS fed by a stable multi-split of the positions,
+// writing every position's four candidates -- was built and measured in round 2: it removes the dependent hops from
+// enc_cand_kernel but costs more than the chains it replaces)
 #include "enc_common.h"
 
 namespace lzmi {
 
-// ------------------------------------------------------------------------------------ history table
+// ------------------------------------------------------------------------------------ chains
 
-// A span is a run of positions of one stream whose rows one set of TB_PARTS waves produces. A long stream is cut into
-// several spans so that the serial scan of each stays short; every span but the first of a stream replays the
-// TB_WARM positions before it without output. That reproduces the row entries within the match window exactly
-// (any candidate a position of the span may use lies < 262 140 positions back, fse/constants.rs:42); older entries
-// are missing, which changes nothing: the candidate scan stops at the first entry beyond the window, and an empty
-// slot stops it as well (history.rs:72-84: the reference's sentinel fails the same distance test).
-constexpr uint32_t TB_ROWS = 1u << (HASH_BITS - TB_PART_BITS);   // rows of one partition
-constexpr uint32_t TB_WARM = 262144;
-static_assert(TB_WARM >= MAX_D_VALUE && TB_WARM % 64 == 0, "warm-up covers the match window");
-constexpr int TB_BATCH = 16;  // 64-position steps whose source values are fetched together
-
-__global__ __launch_bounds__(64) void enc_table_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
-                                                       const EncSpan *__restrict__ spans, uint32_t n_spans,
-                                                       uint4 *__restrict__ cand4) {
-    __shared__ uint4 table[TB_ROWS];       // row = the bucket's four newest positions, newest first
-    __shared__ uint32_t ring_pos[128];     // positions of this partition waiting for their table step
-    __shared__ uint16_t ring_key[128];     // ... and their row index
-    // all partitions of a span on one XCD (workgroups are dealt to the 8 XCDs round-robin): the span's source bytes are
-    // fetched into one L2 instead of eight
-    const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const uint32_t span = (slot >> TB_PART_BITS) * 8 + xcd, part = slot & (TB_PARTS - 1);
-    if (span >= n_spans) return;
-    const EncSpan sp = spans[span];
-    const EncStream st = streams[sp.stream];
-    const uint8_t *s = src + st.src_off;
-    uint4 *out = cand4 + st.pos_base;
+// One wave per tile. Positions are processed in order, 64 per step; the nearest previous
+// position with the same bucket is either a lower lane of the same step (found with 14 ballots)
+// or the LDS last-seen entry written by earlier steps.
+__global__ __launch_bounds__(64) void enc_chain_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
+                                                       const EncTile *__restrict__ tiles, uint32_t n_tiles,
+                                                       uint2 *__restrict__ prev, uint32_t *__restrict__ summary,
+                                                       uint32_t *__restrict__ flist, uint32_t *__restrict__ fcount) {
+    __shared__ uint16_t last[1u << HASH_BITS];  // offset in tile + 1, 0 = none
+    const uint32_t t = blockIdx.x;
+    if (t >= n_tiles) return;
+    const EncTile tl = tiles[t];
+    const EncStream st = streams[tl.stream];
     const int lane = e_lane();
+    for (uint32_t k = lane; k < (1u << HASH_BITS); k += 64) last[k] = 0;
+    const uint8_t *s = src + st.src_off;
+    uint2 *pv = prev + st.pos_base;  // {previous position in the bucket, 4-byte value at this position}
+    const uint32_t n_pos = st.n - 3;  // positions 0 .. n-4 are hashed (frontend_bytes.rs:166-170)
+    const uint32_t t_end = tl.start + TILE_POS < n_pos ? tl.start + TILE_POS : n_pos;
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
-    for (uint32_t k = lane; k < TB_ROWS; k += 64) table[k] = make_uint4(NONE, NONE, NONE, NONE);
+    uint32_t *fl = flist + (uint64_t)t * (1u << HASH_BITS);
+    uint32_t n_first = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-
-    // one table step: the next `cnt` (<= 64) waiting positions, one per lane, in position order
-    auto table_step = [&](uint32_t first, uint32_t cnt) {
-        const bool have = (uint32_t)lane < cnt;
-        const uint32_t e = (first + (uint32_t)lane) & 127u;
-        const uint32_t p = ring_pos[e], k = ring_key[e] & (TB_ROWS - 1);
-        const uint4 row = table[k];
-        // lanes of this step that share my row: they see each other's insertions (history.rs:110-118 push = shift)
-        uint64_t same = __ballot(have);
+    // 16 steps (1024 positions) per batch: the source values of a batch are loaded together, so the wave
+    // waits for memory once per batch instead of once per step (a wait also drains the link stores)
+    constexpr int CH_STEPS = 16;
+    for (uint32_t pb = tl.start; pb < t_end; pb += 64 * CH_STEPS) {
+        uint32_t vv[CH_STEPS];
 #pragma unroll
-        for (int b = 0; b < (int)(HASH_BITS - TB_PART_BITS); b++) {
-            const uint64_t bb = __ballot((k >> b) & 1);
-            same &= ((k >> b) & 1) ? bb : ~bb;
-        }
-        const uint64_t lower = same & lt_mask;
-        uint4 c = row;
-        if (__ballot(have && lower != 0)) {
-            // the r lower lanes of my row were inserted before me: they are my newest candidates, nearest lane first
-            uint64_t rem = lower;
-            uint32_t pp[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int lj = rem ? 63 - __builtin_clzll(rem) : lane;
-                pp[j] = __shfl(p, lj);
-                if (!rem) pp[j] = NONE;
-                rem &= ~(1ull << lj);
-            }
-            const uint32_t r = (uint32_t)__popcll(lower);
-            if (r == 1) c = make_uint4(pp[0], row.x, row.y, row.z);
-            else if (r == 2) c = make_uint4(pp[0], pp[1], row.x, row.y);
-            else if (r == 3) c = make_uint4(pp[0], pp[1], pp[2], row.x);
-            else if (r >= 4) c = make_uint4(pp[0], pp[1], pp[2], pp[3]);
-        }
-        if (have && p >= sp.begin) out[p] = c;
-        if (have && ((same >> lane) >> 1) == 0) table[k] = make_uint4(p, c.x, c.y, c.z);  // the row's last lane writes it back
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    };
-
-    uint32_t n_in = 0, n_done = 0;  // ring counters (uniform): appended, processed
-    for (uint32_t pb = sp.first; pb < sp.end; pb += 64 * TB_BATCH) {
-        uint32_t vv[TB_BATCH];
-#pragma unroll
-        for (int j = 0; j < TB_BATCH; j++) {
+        for (int j = 0; j < CH_STEPS; j++) {
             const uint32_t q = pb + 64 * j + lane;
-            vv[j] = q < sp.end ? ld_u32(s + q) : 0u;
+            vv[j] = q < t_end ? ld_u32(s + q) : 0u;
         }
 #pragma unroll
-        for (int j = 0; j < TB_BATCH; j++) {
-            const uint32_t p = pb + 64 * j + lane;
-            const uint32_t key = bucket_of(vv[j]);
-            const bool own = p < sp.end && (key >> (HASH_BITS - TB_PART_BITS)) == part;
-            const uint64_t m = __ballot(own);
-            if (m) {
-                if (own) {
-                    const uint32_t e = (n_in + (uint32_t)__popcll(m & lt_mask)) & 127u;
-                    ring_pos[e] = p;
-                    ring_key[e] = (uint16_t)key;
+        for (int j = 0; j < CH_STEPS; j++) {
+            const uint32_t p0 = pb + 64 * j;
+            if (p0 >= t_end) continue;  // (not break: the loop must stay fully unrolled, vv[] lives in registers)
+            const uint32_t p = p0 + lane;
+            const bool valid = p < t_end;
+            const uint32_t v = vv[j];
+            const uint32_t key = bucket_of(v);
+            const uint32_t old = last[key];
+            const uint32_t mine = p - tl.start + 1;
+            // fast path: every lane writes its own entry and reads it back; if all read their own value no
+            // two lanes of this step share a bucket and the entry read before the write is the link
+            if (valid) last[key] = (uint16_t)mine;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t chk = last[key];
+            uint32_t pr = old ? (tl.start + old - 1) : NONE_TILE;
+            if (__ballot(valid && chk != mine)) {
+                // some lanes collide: find the nearest lower lane with the same bucket by 14 ballots
+                uint64_t same = __ballot(valid);
+#pragma unroll
+                for (int b = 0; b < (int)HASH_BITS; b++) {
+                    uint64_t bb = __ballot((key >> b) & 1);
+                    same &= ((key >> b) & 1) ? bb : ~bb;
                 }
-                n_in += (uint32_t)__popcll(m);
-                if (n_in - n_done >= 64) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    table_step(n_done, 64);
-                    n_done += 64;
-                }
+                const uint64_t lower = same & lt_mask;
+                if (lower) pr = p0 + (63 - __builtin_clzll(lower));
+                if (valid && (same >> lane) >> 1 == 0) last[key] = (uint16_t)mine;  // newest of its bucket wins
             }
+            // first occurrence of its bucket in the tile: the link into earlier tiles is made by enc_link_kernel
+            // from this list (offset | bucket << 16); the first tile of a stream has nothing before it
+            const bool first = valid && pr == NONE_TILE;
+            if (tl.start == 0) { if (first) pr = NONE; }
+            else {
+                const uint64_t fm = __ballot(first);
+                if (first) fl[n_first + (uint32_t)__popcll(fm & lt_mask)] = (p - tl.start) | (key << 16);
+                n_first += (uint32_t)__popcll(fm);
+            }
+            if (valid) pv[p] = make_uint2(pr, v);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
-    if (n_in > n_done) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        table_step(n_done, n_in - n_done);
+    if (lane == 0) fcount[t] = n_first;
+    uint32_t *sm = summary + (uint64_t)t * (1u << HASH_BITS);
+    for (uint32_t k = lane; k < (1u << HASH_BITS); k += 64) {
+        uint32_t o = last[k];
+        sm[k] = o ? tl.start + o - 1 : NONE;
     }
+}
+
+// Cross-tile links: a bucket's first occurrence in a tile (listed by enc_chain_kernel) points at the newest
+// occurrence in an earlier tile of the same stream. Anything further back than 5 tiles is outside the
+// 262 139-byte window (fse/constants.rs:42) and would end the candidate scan anyway.
+__global__ void enc_link_kernel(const EncStream *__restrict__ streams, const EncTile *__restrict__ tiles, uint32_t n_tiles,
+                                uint2 *__restrict__ prev, const uint32_t *__restrict__ summary,
+                                const uint32_t *__restrict__ flist, const uint32_t *__restrict__ fcount) {
+    constexpr uint32_t BPT = (1u << HASH_BITS) / 256;  // workgroups per tile
+    const uint32_t t = blockIdx.x / BPT;
+    const uint32_t e = (blockIdx.x % BPT) * blockDim.x + threadIdx.x;
+    if (t >= n_tiles || e >= fcount[t]) return;
+    const EncTile tl = tiles[t];
+    const EncStream st = streams[tl.stream];
+    const uint32_t ent = flist[(uint64_t)t * (1u << HASH_BITS) + e];
+    const uint32_t p = tl.start + (ent & 0xFFFF), key = ent >> 16;
+    uint32_t r = NONE;
+    const uint32_t t_idx = tl.start / TILE_POS;  // tile index inside the stream
+    for (uint32_t back = 1; back <= 5 && back <= t_idx; back++) {
+        uint32_t sv = summary[(uint64_t)(t - back) * (1u << HASH_BITS) + key];
+        if (sv != NONE) { r = sv; break; }
+    }
+    prev[st.pos_base + p].x = r;
 }
 
 // ------------------------------------------------------------------------------------ candidates
@@ -146,19 +150,20 @@ __device__ __forceinline__ uint32_t lcp_fwd(const uint8_t *s, uint32_t a, uint32
 
 // rec[i] = { dist | bwd << 18 | capped << 31 , fwd_len }  ; fwd_len == 0: no match at i
 //
-// One lane per position. Step 0 compares the first 16 bytes of every candidate (a candidate is a match iff its first
-// four bytes are equal: history.rs Item.val == val). Lanes whose candidates are still equal after that are grouped
-// into runs of consecutive positions with the same distance in the same slot (the inside of one long match): only the
-// head of a run goes on comparing, the followers derive LCP(i + t, c + t) = LCP(i, c) - t. Heads still equal after
-// CAND_C1 bytes are extended by groups of CAND_GL lanes. Repetitive data costs O(1) per position.
+// One lane per position, hops in lock-step. A lane compares at most CAND_C1 bytes on its own. Lanes
+// that are still equal there are grouped into runs of consecutive positions with the same distance
+// (the inside of one long match): only the head of a run is extended, by the whole wave, and the
+// followers derive LCP(i + t, c + t) = LCP(i, c) - t. Repetitive data costs O(1) per position.
 constexpr uint32_t CAND_C1 = 64;
 constexpr int CAND_GL = 8;  // lanes per group of the long-match work list
+constexpr uint32_t CAND_BPT = (TILE_POS + 255) / 256;  // workgroups per tile
 
 __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
-                                                       const EncTile *__restrict__ tiles, uint32_t n_tiles, const uint4 *__restrict__ cand4,
+                                                       const EncTile *__restrict__ tiles, uint32_t n_tiles, const uint2 *__restrict__ prev,
                                                        uint2 *__restrict__ rec, uint64_t *__restrict__ bitmap) {
     // Workgroups are handed to the 8 XCDs round-robin. All workgroups of one tile go to the same XCD, so the
-    // source bytes a tile gathers from (its own 64 KB + the 256 KB window before it) stay in that XCD's 4 MB L2.
+    // link records and source bytes a tile gathers from (its own 0.5 MB + the 2 MB window before it) stay in
+    // that XCD's 4 MB L2 instead of being spread over all eight.
     __shared__ uint32_t q_i[4][256], q_c[4][256];  // per-wave work list of phase 3: position, candidate
     __shared__ uint16_t q_id[4][256], q_res[4][256];
     __shared__ uint32_t q_dist[4][256], q_tab[4][64];  // distance of a listed head; first head per distance hash
@@ -173,8 +178,10 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
     if (tl.start + bx * blockDim.x >= n_pos) return;  // block-uniform
     const bool valid = i < n_pos && i < tl.start + TILE_POS;
     const uint8_t *s = src + st.src_off;
+    const uint2 *pv = prev + st.pos_base;
     const int lane = e_lane();
-    const uint4 self = valid ? cand4[st.pos_base + i] : make_uint4(NONE, NONE, NONE, NONE);
+    const uint2 self = valid ? pv[i] : make_uint2(NONE, 0);
+    const uint32_t v = self.y;
     const uint32_t max_total = valid ? n - i : 0;
     const uint32_t cap_total = max_total < FCAP ? max_total : FCAP;
     const uint32_t c1 = cap_total < CAND_C1 ? cap_total : CAND_C1;
@@ -196,60 +203,28 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
         __builtin_amdgcn_wave_barrier();
     }
     const uint32_t *win = s_win[threadIdx.x >> 6];
-    // ---- phase 1: the candidate queue, newest -> oldest; the scan STOPS at the first entry beyond the window
-    // (frontend_bytes.rs:222-224: break, not skip) or at an empty slot ----
+    // ---- phase 1: follow the chain (<= 4 dependent 8-byte gathers: next link + value) ----
     uint32_t cc[4] = {NONE, NONE, NONE, NONE};
     uint32_t ln[4] = {0, 0, 0, 0};
     {
-        const uint32_t cq[4] = {self.x, self.y, self.z, self.w};
         bool alive = valid;
+        uint32_t c = self.x;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            if (alive && (cq[q] == NONE || i - cq[q] > MAX_D_VALUE)) alive = false;
-            if (alive) cc[q] = cq[q];
-        }
-    }
-    // ---- step 0: the first 16 bytes of every candidate, all loads of the step in flight together (each sits alone in
-    // its branch and is consumed branch-free afterwards; a load next to its use inside a branch is waited for there).
-    // Fewer than 4 equal bytes: not a match (the table entry's value differs). Consecutive positions inside one match
-    // see the same distance in the same slot, so their loads fall into the same cache lines. ----
-    bool tail[4] = {false, false, false, false};
-    {
-        const bool room = 16 <= max_total;
-        const uint4 zero4 = make_uint4(0, 0, 0, 0);
-        uint4 a = zero4, bq[4] = {zero4, zero4, zero4, zero4};
-        bool go[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) { go[k] = cc[k] != NONE && room; tail[k] = cc[k] != NONE && !room; }
-        if (go[0] || go[1] || go[2] || go[3]) {
-            const uint32_t wo = 32u + (uint32_t)lane, q = wo >> 2, sh = (wo & 3) * 8;
-            const uint32_t d0 = win[q], d1 = win[q + 1], d2 = win[q + 2], d3 = win[q + 3], d4 = win[q + 4];
-            a = make_uint4(__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh),
-                           __builtin_amdgcn_alignbit(d3, d2, sh), __builtin_amdgcn_alignbit(d4, d3, sh));
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (go[k]) bq[k] = ld_u128(s + cc[k]);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint64_t lo = ((uint64_t)(a.y ^ bq[k].y) << 32) | (a.x ^ bq[k].x);
-            const uint64_t hi = ((uint64_t)(a.w ^ bq[k].w) << 32) | (a.z ^ bq[k].z);
-            const uint32_t mlo = lo ? (uint32_t)(__builtin_ctzll(lo | (1ull << 63)) >> 3) : 16u;
-            const uint32_t mhi = hi ? 8 + (uint32_t)(__builtin_ctzll(hi | (1ull << 63)) >> 3) : 16u;
-            uint32_t m = mlo < mhi ? mlo : mhi;
-            m = m < c1 ? m : c1;
-            ln[k] = (go[k] && m >= 4) ? m : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (tail[k]) {  // within 16 bytes of the stream's end
-                const uint32_t m = lcp_fwd(s, i, cc[k], 0, c1);
-                ln[k] = m >= 4 ? m : 0u;
+            if (alive) {
+                if (c == NONE || i - c > MAX_D_VALUE) alive = false;  // frontend_bytes.rs:222-224: stop, not skip
+                else {
+                    const uint2 rc = pv[c];
+                    if (rc.y == v) { cc[q] = c; ln[q] = 4; }
+                    c = rc.x;
+                }
             }
+        }
     }
-    // ---- runs: LCP(i + t, c + t) = LCP(i, c) - t as long as every position in between is itself a match with that
-    // distance in that slot. Only the first lane of such a run (its head) compares further bytes; the followers derive
-    // their length from the head's. ----
+    // ---- runs: consecutive positions inside one match see the same distance in the same chain slot, and
+    // LCP(i + t, c + t) = LCP(i, c) - t. Only the first lane of such a run (its head) compares bytes; the
+    // followers derive their length from the head's. The kernel is bound by the number of cache lines its
+    // divergent loads touch, and on compressible data most equal candidates are followers. ----
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
     bool fol[4];
 #pragma unroll
@@ -258,14 +233,18 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
         const uint32_t dlo = __shfl_up(dk, 1);
         fol[k] = ln[k] != 0 && lane > 0 && dlo == dk;
     }
-    // ---- phase 2: heads that matched all 16 bytes go on, 16 bytes per candidate and step, up to CAND_C1 ----
+    // ---- phase 2: forward lengths of all heads together, 16 bytes per candidate and step, so the loads of a
+    // step are in flight at the same time ----
     {
-        bool act[4];
+        bool act[4], tail[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) { act[k] = ln[k] == 16 && !fol[k] && c1 > 16 && !tail[k]; tail[k] = false; }
+        for (int k = 0; k < 4; k++) { act[k] = ln[k] != 0 && !fol[k] && c1 > 4; tail[k] = false; }
 #pragma unroll 1
-        for (uint32_t off = 16; off < CAND_C1; off += 16) {
+        for (uint32_t off = 4; off < CAND_C1; off += 16) {
             if (!__any(act[0] || act[1] || act[2] || act[3])) break;
+            // All five loads of a step are issued before the first use: each sits alone in its branch (idle
+            // lanes issue nothing) and the lengths are updated without branches afterwards. A load next to its
+            // use inside a branch would be waited for there, one candidate after the other.
             const bool room = off + 16 <= max_total;
             bool go[4];
 #pragma unroll
@@ -273,7 +252,7 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
             const uint4 zero4 = make_uint4(0, 0, 0, 0);
             uint4 a = zero4, bq[4] = {zero4, zero4, zero4, zero4};
             if (go[0] || go[1] || go[2] || go[3]) {
-                const uint32_t wo = 32u + (uint32_t)lane + off, q = wo >> 2, sh = (wo & 3) * 8;  // wo + 16 <= 32 + 63 + 48 + 16 < 192
+                const uint32_t wo = 32u + (uint32_t)lane + off, q = wo >> 2, sh = (wo & 3) * 8;  // wo + 16 <= 32 + 63 + 52 + 16 < 192
                 const uint32_t d0 = win[q], d1 = win[q + 1], d2 = win[q + 2], d3 = win[q + 3], d4 = win[q + 4];
                 a = make_uint4(__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh),
                                __builtin_amdgcn_alignbit(d3, d2, sh), __builtin_amdgcn_alignbit(d4, d3, sh));
@@ -379,9 +358,9 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
                         xl = ((uint64_t)(a.y ^ bq.y) << 32) | (a.x ^ bq.x);
                         xh = ((uint64_t)(a.w ^ bq.w) << 32) | (a.z ^ bq.z);
                     } else {
-                        for (uint32_t tt = 0; it_i + o + tt < n; tt++) {
-                            const uint64_t x = (uint64_t)(s[it_i + o + tt] ^ s[it_c + o + tt]);
-                            if (tt < 8) xl |= x << (8 * tt); else xh |= x << (8 * (tt - 8));
+                        for (uint32_t t = 0; it_i + o + t < n; t++) {
+                            const uint64_t x = (uint64_t)(s[it_i + o + t] ^ s[it_c + o + t]);
+                            if (t < 8) xl |= x << (8 * t); else xh |= x << (8 * (t - 8));
                         }
                     }
                 }
@@ -422,7 +401,6 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
             const uint64_t below = hm & lt_mask;
             const int h = below ? 63 - __builtin_clzll(below) : 0;
             const uint32_t hl = __shfl(len, h);
-            // (every lane between the head and this one is a match with this distance: hl >= lane - h + 4)
             if (fol[k]) len = hl - (uint32_t)(lane - h);
         }
         if (len) {
@@ -440,7 +418,7 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
         const uint32_t bmax = best_idx < BCAP ? best_idx : BCAP;
         uint32_t bw = 0;
         if (best_len && !bfol) {
-            // common suffix with this position's side read from the window (8 bytes per step, at most BCAP = 32 back)
+            // lcs_bwd with this position's side read from the window (8 bytes per step, at most BCAP = 32 back)
             uint32_t len = 0;
             bool open = true;
             while (open && len + 8 <= bmax) {
@@ -477,15 +455,23 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
 
 // ------------------------------------------------------------------------------------ launchers
 
-void launch_enc_table(const uint8_t *src, const EncStream *streams, const EncSpan *spans, uint32_t n_spans, uint4 *cand4, hipStream_t st) {
-    if (!n_spans) return;
-    hipLaunchKernelGGL(enc_table_kernel, dim3(((n_spans + 7) / 8) * 8 * TB_PARTS), dim3(64), 0, st, src, streams, spans, n_spans, cand4);
+void launch_enc_chain(const uint8_t *src, const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, uint2 *prev, uint32_t *summary,
+                      uint32_t *flist, uint32_t *fcount, hipStream_t st) {
+    if (!n_tiles) return;
+    hipLaunchKernelGGL(enc_chain_kernel, dim3(n_tiles), dim3(64), 0, st, src, streams, tiles, n_tiles, prev, summary, flist, fcount);
 }
 
-void launch_enc_cand(const uint8_t *src, const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, const uint4 *cand4, uint2 *rec,
+void launch_enc_link(const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, uint2 *prev, const uint32_t *summary,
+                     const uint32_t *flist, const uint32_t *fcount, hipStream_t st) {
+    if (!n_tiles) return;
+    hipLaunchKernelGGL(enc_link_kernel, dim3(n_tiles * ((1u << HASH_BITS) / 256)), dim3(256), 0, st, streams, tiles, n_tiles, prev, summary, flist,
+                       fcount);
+}
+
+void launch_enc_cand(const uint8_t *src, const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, const uint2 *prev, uint2 *rec,
                      uint64_t *bitmap, hipStream_t st) {
     if (!n_tiles) return;
-    hipLaunchKernelGGL(enc_cand_kernel, dim3(((n_tiles + 7) / 8) * 8 * CAND_BPT), dim3(256), 0, st, src, streams, tiles, n_tiles, cand4, rec, bitmap);
+    hipLaunchKernelGGL(enc_cand_kernel, dim3(((n_tiles + 7) / 8) * 8 * CAND_BPT), dim3(256), 0, st, src, streams, tiles, n_tiles, prev, rec, bitmap);
 }
 
 }  // namespace lzmi

@@ -17,18 +17,18 @@ def ctx():
 
 
 def gpu_candidates(ctx, raw):
-    """(history rows, candidate records) of one stream from the diagnostic build's stage hook."""
+    """(chain links, candidate records) of one stream from the diagnostic build's stage hook."""
     from lzfse_rust_amd import _native
     L = _native.lib(diag=True)
     f = L.lzfse_mi_debug_candidates
     f.restype = C.c_int
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     a = np.frombuffer(raw, dtype=np.uint8)
-    rows = np.zeros((a.size - 3, 4), dtype=np.uint32)
+    prev = np.zeros((a.size - 3, 2), dtype=np.uint32)  # {prev, value} pairs
     rec = np.zeros((a.size - 3, 2), dtype=np.uint32)
-    st = f(ctx._h, a.ctypes.data, a.size, rows.ctypes.data, rec.ctypes.data)
+    st = f(ctx._h, a.ctypes.data, a.size, prev.ctypes.data, rec.ctypes.data)
     assert st == 0
-    return rows, rec
+    return prev[:, 0], rec
 
 
 def synth_cases():
@@ -54,29 +54,22 @@ def synth_cases():
 
 
 def test_candidate_stage_matches_oracle(diag_ctx, oracle, snappy_raw):
-    """enc_table / enc_cand vs the oracle: the history row every position sees (history.rs push) and the as-if-visited
-    find_match at every position. The 3 MiB case is cut into several table spans (warm-up replay)."""
+    """enc_chain / enc_link / enc_cand vs the oracle: the bucket chain of every position equals the newest entry of the
+    history row it sees (history.rs push), and the as-if-visited find_match at every position. The 3 MiB case spans
+    48 chain tiles (links across tiles)."""
     from oracle_py import seq_masked
     cases = dict(synth_cases())
     for k in ("html", "alice29.txt", "kppkn.gtb", "urls.10K"):
         cases[k] = snappy_raw[k]
-    cases["spans"] = (snappy_raw["lcet10.txt"] + seq_masked(3, 0x03030303, 200000)) * 5
+    cases["tiles"] = (snappy_raw["lcet10.txt"] + seq_masked(3, 0x03030303, 200000)) * 5
     for name, raw in cases.items():
         mi, fl = oracle.candidates(raw)
-        rows, rec = gpu_candidates(diag_ctx, raw)
+        prev, rec = gpu_candidates(diag_ctx, raw)
         want = oracle.table_rows(raw)
         n = len(raw) - 3
-        # the candidate scan stops at the first entry that is empty or beyond the window (frontend_bytes.rs:222-224):
-        # entries after that point are never looked at, and a span's warm-up does not reproduce them
-        pos = np.arange(n, dtype=np.int64)[:, None]
-        dead_w = (want == 0xFFFFFFFF) | (pos - want.astype(np.int64) > 262139)
-        dead_g = (rows == 0xFFFFFFFF) | (pos - rows.astype(np.int64) > 262139)
-        live_w = np.cumsum(dead_w, axis=1) == 0
-        live_g = np.cumsum(dead_g, axis=1) == 0
-        assert (live_w == live_g).all(), name
-        assert (rows[live_w] == want[live_w]).all(), name
-        if n <= 512 * 1024:
-            assert (rows == want).all(), name   # a single span replays the table exactly
+        # prev[i] = newest entry of the row, as long as it lies within the 5-tile link horizon (beyond the match window)
+        near = (want[:, 0] != 0xFFFFFFFF) & (np.arange(n, dtype=np.int64) - want[:, 0].astype(np.int64) <= 262139)
+        assert (prev[near] == want[near, 0]).all(), name
         idx = np.arange(n, dtype=np.int64)
         fwd = rec[:, 1]
         dist = rec[:, 0] & 0x3FFFF
