@@ -1,20 +1,29 @@
 #!/usr/bin/env python3
-"""Headline benchmark: encode+decode MB/s on the Snappy corpus (BASELINE.json), per GPU and
-aggregated over --gpus N ranks (one process per GPU, weak scaling, no collectives on the
-data path: independent streams are sharded across ranks).
+"""Headline benchmark: encode+decode MB/s on the Snappy corpus (BASELINE.json), per GPU and aggregated over --gpus N
+ranks. One process per GPU; `python bench.py --gpus N` starts its N workers itself (or runs as one rank under
+torchrun); independent streams are sharded across ranks, no collective on the data path (RCCL only carries the timing
+barrier / max-reduce and the result metadata).
 
-A step = one pass of the hot path over one batch of synthetic-layout input: `replicas` copies
-of the 12 Snappy files as independent LZFSE streams, encode (raw -> streams) then decode
-(streams -> raw), inputs and outputs resident in HBM. value = raw bytes through the
-encode+decode round trip per second (10^6 bytes/s), whole job.
+A step = one pass of the hot path over one batch: encode (raw -> streams) then decode (streams -> raw), inputs and
+outputs resident in HBM. value = raw bytes through the encode+decode round trip per second (10^6 bytes/s), whole job.
 
-Prints ONE JSON line (rank 0). Extra keys: roofline, cpu_baseline, encode/decode splits.
+Workloads (--workload):
+  snappy    the 12 Snappy files x --replicas copies per GPU as independent streams (the metric's config; weak scaling)
+  chunks1g  ONE 1 GiB input cut into 256 x 4 MiB streams, chunk c -> rank c mod N (BASELINE config 5; strong scaling);
+            every chunk stream is compared (SHA-256) with the list rank 0 produces alone
+  text64m   64 MiB of text as ONE stream per GPU (configs 2 / 3)
+  chunks4m  256 MiB of text as 64 x 4 MiB streams per GPU
+
+Prints ONE JSON line (rank 0). Besides the contract's keys: roofline (dominant kernel, per launch over the timed
+region + one exclusive unsplit pass), cpu_baseline (the C restatement of lzfse_rust's CPU path on this box's cores),
+pcie_inclusive, copy_peak, encode/decode splits.
 """
 import argparse
 import glob
 import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -67,6 +76,58 @@ def synth_text(n_bytes, seed=1):
     return b"".join(parts)[:n_bytes]
 
 
+def corpus_1g(seed=1):
+    """1 GiB = 16 copies of 64 MiB of synthetic text, each copy perturbed in one byte out of 251
+    so that the copies do not match each other. The same bytes on every rank."""
+    base = np.frombuffer(synth_text(64 << 20, seed=seed), dtype=np.uint8)
+    out = np.empty(16 * base.size, dtype=np.uint8)
+    for c in range(16):
+        a = out[c * base.size:(c + 1) * base.size]
+        a[:] = base
+        a[c % 251::251] ^= np.uint8(1 + c)
+    return out
+
+
+class GpuCodec:
+    """The product's host-pointer batch API in the shape lzfse_rust_amd.sharding wants."""
+
+    def __init__(self, ctx, max_batch=64):
+        self.ctx, self.max_batch = ctx, max_batch
+
+    def encode_batch(self, raws):
+        out = []
+        for i in range(0, len(raws), self.max_batch):
+            o, st = self.ctx.encode_batch(raws[i:i + self.max_batch])
+            assert all(s == 0 for s in st), st
+            out += [x.tobytes() for x in o]
+        return out
+
+    def decode_batch(self, encs, raw_lens):
+        out = []
+        for i in range(0, len(encs), self.max_batch):
+            o, st = self.ctx.decode_batch(encs[i:i + self.max_batch], caps=raw_lens[i:i + self.max_batch])
+            assert all(s == 0 for s in st), st
+            out += [x.tobytes() for x in o]
+        return out
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` from a plain shell: start one fresh worker per GPU (nothing in this process has touched
+    the GPU or torch.cuda) and hand back the first non-zero exit code. Workers rendezvous on 127.0.0.1."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rcs = [p.wait() for p in procs]
+    return next((rc for rc in rcs if rc), 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,8 +136,14 @@ def main():
     ap.add_argument("--replicas", type=int, default=256, help="copies of the 12-file corpus per GPU (256: 3072 streams, 752 MB)")
     ap.add_argument("--workload", default="snappy", choices=["snappy", "text64m", "chunks4m", "chunks1g"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the exclusive pass, PCIe-inclusive and copy-peak measurements")
     ap.add_argument("--lanes", type=int, default=0, help="sub-batches run side by side per call (0: library default, 1: unsplit)")
+    ap.add_argument("--per-file", type=int, default=0, metavar="R",
+                    help="instead of the headline run: Criterion-style table, each Snappy file alone as a batch of R copies")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -84,22 +151,30 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: run `python bench.py --gpus N` from a plain shell, or "
+                 f"`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
     import lzfse_rust_amd as lz
+    from lzfse_rust_amd import sharding
     ctx = lz.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     if args.lanes:
         ctx.set_option("encode_lanes", args.lanes)
         ctx.set_option("decode_lanes", args.lanes)
 
-    # ---- build the per-GPU batch (untimed) ----
     names, fixture_streams, hashes = load_corpus_streams()
+    if args.per_file:
+        per_file_table(ctx, torch, dev, names, fixture_streams, args.per_file)
+        return
+
+    # ---- build the per-GPU batch (untimed) ----
+    scaling = "weak"
     if args.workload == "snappy":
         raws_np, st = ctx.decode_batch(fixture_streams)  # product decoder recovers the raw corpus
         assert all(s == 0 for s in st)
@@ -107,82 +182,58 @@ def main():
         for r, h, n in zip(raws, hashes, names):
             assert hashlib.sha256(r).digest() == h, n
         batch_raw = raws * args.replicas
-        workload = f"snappy corpus (12 files, {sum(map(len, raws))} B) x {args.replicas} replicas as independent streams, encode+decode"
+        workload = f"snappy corpus (12 files, {sum(map(len, raws))} B) x {args.replicas} replicas per GPU as independent streams, encode+decode"
     elif args.workload == "text64m":
         batch_raw = [synth_text(64 << 20, seed=1 + rank)]
-        workload = "64 MiB synthetic enwik-style text, ONE stream, encode+decode"
+        workload = "64 MiB synthetic enwik-style text, ONE stream per GPU, encode+decode"
     elif args.workload == "chunks1g":
-        # 1 GiB per GPU cut at 4 MiB = 256 independent streams. 16 copies of 64 MiB of
-        # synthetic text, each copy perturbed in one byte out of 251 so that copies do not match each other
-        base = np.frombuffer(synth_text(64 << 20, seed=1 + rank), dtype=np.uint8)
-        batch_raw = []
-        for c in range(16):
-            a = base.copy()
-            a[c % 251::251] ^= np.uint8(1 + c)
-            batch_raw += [a[i:i + (4 << 20)].tobytes() for i in range(0, a.size, 4 << 20)]
-        workload = "1 GiB synthetic text (16 perturbed copies of 64 MiB) cut into 256 independent 4 MiB streams, encode+decode"
+        # strong scaling: the same 1 GiB on every rank, chunk c -> rank c mod world
+        scaling = "strong"
+        data = corpus_1g(seed=1)
+        bounds = sharding.chunk_bounds(data.size, sharding.CHUNK_BYTES)
+        mine = sharding.shard(len(bounds), rank, world)
+        batch_raw = [data[o:o + n].tobytes() for o, n in (bounds[c] for c in mine)]
+        workload = (f"ONE 1 GiB input (16 perturbed copies of 64 MiB synthetic text) cut into {len(bounds)} independent 4 MiB "
+                    f"streams, chunk c -> rank c mod {world}, encode+decode")
+        # untimed: the sharded result equals what ONE encoder makes of the same chunks (per-chunk SHA-256)
+        report = sharding.process_shard(data, sharding.CHUNK_BYTES, rank, world, GpuCodec(ctx))
+        reports = sharding.gather_reports(report, world, dist)
+        if rank == 0:
+            merged = sharding.merge_reports(reports, len(bounds))
+            if world > 1:
+                sharding.check_against(merged, sharding.process_shard(data, sharding.CHUNK_BYTES, 0, 1, GpuCodec(ctx)))
+        del data
     else:
         t = synth_text(256 << 20, seed=1 + rank)
         batch_raw = [t[i:i + (4 << 20)] for i in range(0, len(t), 4 << 20)]
-        workload = "256 MiB synthetic text cut into 64 independent 4 MiB streams, encode+decode"
+        workload = "256 MiB synthetic text cut into 64 independent 4 MiB streams per GPU, encode+decode"
     n_streams = len(batch_raw)
     raw_total = sum(len(r) for r in batch_raw)
 
-    def layout(lens, align=256):
-        off, o = [], 0
-        for n in lens:
-            off.append(o)
-            o += (n + align - 1) // align * align
-        return np.array(off, dtype=np.uint64), o
-
-    raw_len = np.array([len(r) for r in batch_raw], dtype=np.uint64)
-    raw_off, raw_bytes_padded = layout(raw_len)
-    enc_cap = np.array([lz.encode_bound(int(n)) for n in raw_len], dtype=np.uint64)
-    enc_off, enc_bytes_padded = layout(enc_cap)
-    h_raw = np.zeros(raw_bytes_padded + 256, dtype=np.uint8)
-    for r, o in zip(batch_raw, raw_off):
-        h_raw[int(o):int(o) + len(r)] = np.frombuffer(r, dtype=np.uint8)
-    d_raw = torch.from_numpy(h_raw).to(dev)
-    d_enc = torch.zeros(enc_bytes_padded + 256, dtype=torch.uint8, device=dev)
-    d_dec = torch.zeros(raw_bytes_padded + 256, dtype=torch.uint8, device=dev)
-
+    B = DeviceBatch(torch, dev, lz, batch_raw)
     # encode once (untimed) to learn stream sizes and to verify the round trip bit-exactly
-    enc_len, est = ctx.encode_batch_device(d_raw.data_ptr(), raw_off, raw_len, d_enc.data_ptr(), enc_off, enc_cap)
-    have_encode = bool((est == 0).all())
-    if not have_encode:
-        # encode kernels unavailable: decode the fixture streams instead (reported in the JSON)
-        assert args.workload == "snappy", "encode path required for this workload"
-        fs = fixture_streams * args.replicas
-        enc_len = np.array([len(s) for s in fs], dtype=np.uint64)
-        enc_off, tot = layout(enc_len)
-        h_enc = np.zeros(tot + 256, dtype=np.uint8)
-        for s, o in zip(fs, enc_off):
-            h_enc[int(o):int(o) + len(s)] = np.frombuffer(s, dtype=np.uint8)
-        d_enc = torch.from_numpy(h_enc).to(dev)
-    dec_len, dst_ = ctx.decode_batch_device(d_enc.data_ptr(), enc_off, enc_len, d_dec.data_ptr(), raw_off, raw_len)
+    enc_len, est = ctx.encode_batch_device(B.d_raw.data_ptr(), B.raw_off, B.raw_len, B.d_enc.data_ptr(), B.enc_off, B.enc_cap)
+    assert (est == 0).all(), est
+    dec_len, dst_ = ctx.decode_batch_device(B.d_enc.data_ptr(), B.enc_off, enc_len, B.d_dec.data_ptr(), B.raw_off, B.raw_len)
     assert (dst_ == 0).all(), dst_
-    assert (dec_len == raw_len).all()
-    assert torch.equal(d_dec[:raw_bytes_padded], d_raw[:raw_bytes_padded]), "round trip mismatch"
+    assert (dec_len == B.raw_len).all()
+    assert torch.equal(B.d_dec[:B.raw_padded], B.d_raw[:B.raw_padded]), "round trip mismatch"
     comp_total = int(enc_len.sum())
 
     def step(timed):
-        t_e = t_d = 0.0
         kern = {}
-        if have_encode:
-            t0 = time.perf_counter()
-            _, s1 = ctx.encode_batch_device(d_raw.data_ptr(), raw_off, raw_len, d_enc.data_ptr(), enc_off, enc_cap)
-            torch.cuda.synchronize()
-            t_e = time.perf_counter() - t0
-            if timed:
-                for k, v in ctx.timings().items():
-                    kern[k] = v
         t0 = time.perf_counter()
-        _, s2 = ctx.decode_batch_device(d_enc.data_ptr(), enc_off, enc_len, d_dec.data_ptr(), raw_off, raw_len)
+        ctx.encode_batch_device(B.d_raw.data_ptr(), B.raw_off, B.raw_len, B.d_enc.data_ptr(), B.enc_off, B.enc_cap)
+        torch.cuda.synchronize()
+        t_e = time.perf_counter() - t0
+        if timed:
+            kern.update(ctx.timings())
+        t0 = time.perf_counter()
+        ctx.decode_batch_device(B.d_enc.data_ptr(), B.enc_off, enc_len, B.d_dec.data_ptr(), B.raw_off, B.raw_len)
         torch.cuda.synchronize()
         t_d = time.perf_counter() - t0
         if timed:
-            for k, v in ctx.timings().items():
-                kern[k] = v
+            kern.update(ctx.timings())
         return t_e, t_d, kern
 
     def barrier():
@@ -197,8 +248,7 @@ def main():
     barrier()
     t_start = time.perf_counter()
     te = td = 0.0
-    kern_ms = {}
-    kern_n = {}
+    kern_ms, kern_n = {}, {}
     for _ in range(args.steps):
         a, b, k = step(True)
         te += a
@@ -210,32 +260,30 @@ def main():
     elapsed = time.perf_counter() - t_start
 
     stats = torch.tensor([elapsed, te, td], dtype=torch.float64, device=dev)
+    totals = torch.tensor([raw_total, comp_total, n_streams], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+        dist.all_reduce(totals, op=dist.ReduceOp.SUM)
     elapsed, te, td = stats.tolist()
+    raw_all, comp_all, streams_all = (int(x) for x in totals.tolist())
 
     if rank == 0:
-        total_raw_all = raw_total * world * args.steps
-        value = total_raw_all / elapsed / 1e6
+        value = raw_all * args.steps / elapsed / 1e6
         # dominant kernel by accumulated device time (HIP events on the launch stream)
         dom = max(kern_ms, key=kern_ms.get)
         dom_avg_ms = kern_ms[dom] / max(kern_n[dom], 1)
         is_dec = dom.startswith("dec")
-        # HBM traffic of that kernel per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE runs of this same default workload, profiles/r01_pmc_traffic.json; KiB -> bytes, raw figures)
-        traffic = None
-        try:
-            if args.workload == "snappy" and args.replicas == 256:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                key = [k for k in pm if k.startswith(dom + "_kernel")]
-                if key:
-                    traffic = int(sum(pm[k]["hbm_bytes_raw"] * pm[k]["launches"] for k in key) / sum(pm[k]["launches"] for k in key))
-        except Exception:
-            traffic = None
-        # B_dec = compressed_in + raw_out ; B_enc = raw_in + compressed_out, per step; a batch call may be cut into
-        # sub-batches that run side by side (split batches), so one launch covers bytes-per-step x steps / launches
+        # B_dec = compressed_in + raw_out ; B_enc = raw_in + compressed_out, per step (this rank); a batch call may be cut
+        # into sub-batches that run side by side (split batches), so one launch covers bytes-per-step / launches
         alg_bytes = int((comp_total + raw_total) * args.steps / max(kern_n[dom], 1))
         achieved = alg_bytes / (dom_avg_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": pmc_traffic(dom, args),
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_avg_ms, 4),
+                "direction": "decode" if is_dec else "encode",
+                # the launches of one step overlap on the device (sub-batches side by side): a per-launch duration under
+                # co-scheduling is not an exclusive kernel time; see exclusive_* below for one unsplit pass
+                "launches_per_step": round(kern_n[dom] / args.steps, 2)}
         out = {
             "metric": "encode+decode MB/s on Snappy corpus",
             "value": round(value, 2),
@@ -245,59 +293,252 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic" if args.workload != "snappy" else "snappy corpus fixtures replicated (weights n/a)",
-            "config": {"workload": workload, "streams_per_gpu": n_streams, "raw_bytes_per_gpu_step": raw_total,
-                       "compressed_bytes_per_gpu_step": comp_total, "encode_on_gpu": have_encode},
-            "encode_MBps": round(raw_total * world * args.steps / te / 1e6, 2) if te > 0 else None,
-            "decode_MBps": round(raw_total * world * args.steps / td / 1e6, 2),
+            "config": {"workload": workload, "streams_all_gpus": streams_all, "raw_bytes_per_step_all_gpus": raw_all,
+                       "compressed_bytes_per_step_all_gpus": comp_all, "streams_rank0": n_streams, "raw_bytes_rank0": raw_total},
+            "encode_MBps": round(raw_all * args.steps / te / 1e6, 2),
+            "decode_MBps": round(raw_all * args.steps / td / 1e6, 2),
             "kernel_ms_per_step": {k: round(v / args.steps, 4) for k, v in sorted(kern_ms.items())},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_avg_ms, 4),
-                         "direction": "decode" if is_dec else "encode",
-                         # a batch call runs its sub-batches side by side (split batches): the launches of
-                         # this kernel overlap on the device, so the chip-wide rate is about launches-per-step times
-                         # the per-launch figure above
-                         "launches_per_step": round(kern_n[dom] / args.steps, 2),
-                         "achieved_all_lanes": round(achieved * kern_n[dom] / args.steps, 3)},
+            "roofline": roof,
         }
+        if not args.no_extras:
+            # one UNSPLIT pass (one launch per kernel, nothing co-scheduled): exclusive kernel durations
+            ctx.set_option("encode_lanes", 1)
+            ctx.set_option("decode_lanes", 1)
+            step(False)
+            _, _, kx = step(True)
+            ctx.set_option("encode_lanes", args.lanes)
+            ctx.set_option("decode_lanes", args.lanes)
+            ex_ms = kx[dom][0] / max(kx[dom][1], 1)
+            roof["exclusive_launch_ms"] = round(ex_ms, 4)
+            roof["exclusive_achieved"] = round((comp_total + raw_total) / (ex_ms * 1e-3) / 1e9, 3)
+            roof["exclusive_frac"] = round(roof["exclusive_achieved"] / HBM_PEAK_GBPS, 6)
+            out["exclusive_kernel_ms"] = {k: round(v[0], 4) for k, v in sorted(kx.items())}
+            out["copy_peak"] = copy_peak(torch, dev)
+            out["pcie_inclusive"] = pcie_inclusive(ctx, lz, batch_raw)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(batch_raw[:12] if args.workload == "snappy" else [batch_raw[0][:8 << 20]])
-        print(json.dumps(out))
+            sample = batch_raw[:12] if args.workload == "snappy" else [batch_raw[0][:8 << 20]]
+            out["cpu_baseline"] = cpu_baseline(sample)
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
+class DeviceBatch:
+    """Streams of a batch laid out 256-byte aligned in device buffers (inputs, encoded, decoded)."""
+
+    def __init__(self, torch, dev, lz, batch_raw):
+        def layout(lens, align=256):
+            off, o = [], 0
+            for n in lens:
+                off.append(o)
+                o += (n + align - 1) // align * align
+            return np.array(off, dtype=np.uint64), o
+        self.raw_len = np.array([len(r) for r in batch_raw], dtype=np.uint64)
+        self.raw_off, self.raw_padded = layout(self.raw_len)
+        self.enc_cap = np.array([lz.encode_bound(int(n)) for n in self.raw_len], dtype=np.uint64)
+        self.enc_off, enc_padded = layout(self.enc_cap)
+        h_raw = np.zeros(self.raw_padded + 256, dtype=np.uint8)
+        for r, o in zip(batch_raw, self.raw_off):
+            h_raw[int(o):int(o) + len(r)] = np.frombuffer(r, dtype=np.uint8)
+        self.d_raw = torch.from_numpy(h_raw).to(dev)
+        self.d_enc = torch.zeros(enc_padded + 256, dtype=torch.uint8, device=dev)
+        self.d_dec = torch.zeros(self.raw_padded + 256, dtype=torch.uint8, device=dev)
+
+
+def kernel_source_sha():
+    """Identity of the kernels a PMC pass was taken on: SHA-256 over the HIP sources (the GPU box has no .git)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "lzfse_rust_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(dom, args):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE runs of this same default command, profiles/r02_pmc_traffic.json). Only reported when that file was taken
+    on exactly the kernel sources of this build (source_sha) and for the default workload; otherwise null."""
+    try:
+        if args.workload != "snappy" or args.replicas != 256 or args.lanes:
+            return None
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        if pm.get("source_sha") != kernel_source_sha():
+            return None
+        key = [k for k in pm["kernels"] if k.startswith(dom + "_kernel")]
+        if not key:
+            return None
+        return int(sum(pm["kernels"][k]["hbm_bytes_raw"] * pm["kernels"][k]["launches"] for k in key) /
+                   sum(pm["kernels"][k]["launches"] for k in key))
+    except Exception:
+        return None
+
+
+def copy_peak(torch, dev):
+    """Measured device copy rate (read + write bytes / time) beside the 8 TB/s spec."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=dev)
+    b = torch.empty(n, dtype=torch.uint8, device=dev)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    return {"GBps": round(2 * n / (ms * 1e-3) / 1e9, 1), "what": "torch uint8 device-to-device copy of 1 GiB, read + write bytes"}
+
+
+def pcie_inclusive(ctx, lz, batch_raw):
+    """The host-pointer entry points (what the Rust shim binds): pageable host buffers in, pinned staging, one H2D and one
+    D2H per batch, results back in host memory. Never `value`."""
+    import ctypes as C
+    sample = batch_raw[:384]
+    n = len(sample)
+    raw = sum(len(r) for r in sample)
+    arrs = [np.frombuffer(r, dtype=np.uint8) for r in sample]
+    L = ctx._lib
+
+    def call(fn, srcs, caps):
+        outs = [np.empty(int(c), dtype=np.uint8) for c in caps]
+        sp = (C.c_void_p * n)(*[a.ctypes.data for a in srcs])
+        sl = (C.c_size_t * n)(*[a.size for a in srcs])
+        dp = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        dc = (C.c_size_t * n)(*[int(c) for c in caps])
+        ol = (C.c_size_t * n)()
+        st = (C.c_int * n)()
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            rc = fn(ctx._h, n, sp, sl, dp, dc, ol, st)
+            best = min(best, time.perf_counter() - t0)
+        assert rc == 0 and all(s == 0 for s in st)
+        return [o[:ol[i]] for i, o in enumerate(outs)], best
+    encs, t_e = call(L.lzfse_mi_encode_batch, arrs, [lz.encode_bound(a.size) for a in arrs])
+    _, t_d = call(L.lzfse_mi_decode_batch, encs, [a.size for a in arrs])
+    return {"encode_MBps": round(raw / t_e / 1e6, 1), "decode_MBps": round(raw / t_d / 1e6, 1),
+            "sample": f"{n} streams, {raw} raw bytes through lzfse_mi_encode_batch / _decode_batch (host pointers), best of 3"}
+
+
 def cpu_baseline(sample):
-    """The oracle (C restatement of lzfse_rust's CPU path; the reference itself cannot be built:
-    no Rust toolchain) timed single-threaded on this box's host cores for ~10 s."""
+    """The oracle (C restatement of lzfse_rust's CPU path; the reference itself cannot be built: no Rust toolchain)
+    timed on this box's host cores: one thread (comparable with the reference README's `rust` column), then one
+    thread per core over independent streams. About 20 s in all."""
+    from concurrent.futures import ThreadPoolExecutor
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_py import Oracle
     o = Oracle("liblzfse_oracle_native.so")
     encs = [o.encode(r) for r in sample]
     nbytes = sum(len(r) for r in sample)
-    t0 = time.perf_counter()
-    n = 0
-    te = td = 0.0
-    while time.perf_counter() - t0 < 10.0:
-        a = time.perf_counter()
-        for r in sample:
-            o.encode(r)
-        b = time.perf_counter()
-        for e, r in zip(encs, sample):
-            o.decode(e, cap=len(r), as_array=True)
-        c = time.perf_counter()
-        te += b - a
-        td += c - b
-        n += 1
-    return {"value": round(nbytes * n / (te + td) / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port",
-            "encode_MBps": round(nbytes * n / te / 1e6, 2), "decode_MBps": round(nbytes * n / td / 1e6, 2),
-            "sample": f"{len(sample)} stream(s), {nbytes} raw bytes, encode+decode repeated {n}x (~10 s), 1 thread, "
-                      "gcc -O3 -march=native C restatement of lzfse_rust's slice path"}
+
+    def run(threads, budget):
+        work = list(zip(sample, encs))
+        if threads > 1:
+            work = work * (threads // max(len(sample), 1) + 1)
+        wbytes = sum(len(r) for r, _ in work)
+        pool = ThreadPoolExecutor(threads) if threads > 1 else None
+        mp = pool.map if pool else map
+        t0 = time.perf_counter()
+        n = 0
+        te = td = 0.0
+        while time.perf_counter() - t0 < budget:
+            a = time.perf_counter()
+            list(mp(lambda w: o.encode(w[0]), work))          # ctypes releases the GIL inside the C call
+            b = time.perf_counter()
+            list(mp(lambda w: o.decode(w[1], cap=len(w[0]), as_array=True), work))
+            c = time.perf_counter()
+            te += b - a
+            td += c - b
+            n += 1
+        if pool:
+            pool.shutdown()
+        return wbytes * n / (te + td) / 1e6, wbytes * n / te / 1e6, wbytes * n / td / 1e6, n
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    v1, e1, d1, n1 = run(1, 8.0)
+    vn, en, dn, nn = run(cores, 10.0) if cores > 1 else (v1, e1, d1, n1)
+    return {"value": round(vn, 2), "unit": "MB/s", "cores": cores, "kind": "port",
+            "encode_MBps": round(en, 2), "decode_MBps": round(dn, 2),
+            "single_thread": {"value": round(v1, 2), "encode_MBps": round(e1, 2), "decode_MBps": round(d1, 2)},
+            "sample": f"{len(sample)} stream(s), {nbytes} raw bytes, encode+decode repeated for ~8 s on 1 thread and ~10 s on "
+                      f"{cores} threads (independent streams per thread); gcc -O3 -march=native C restatement of "
+                      "lzfse_rust's slice path (oracle/)"}
+
+
+# README.md:155-176 of the reference: Criterion, i5-2500K, single thread, MiB/s of raw bytes, column `rust` (decode, encode)
+README_I5_2500K = {
+    "html": (945.7, 118.9), "urls.10K": (552.5, 74.2), "fireworks.jpeg": (355.0, 61.5), "paper-100k.pdf": (429.0, 63.9),
+    "html_x_4": (3174.4, 457.2), "alice29.txt": (344.7, 55.1), "asyoulik.txt": (319.7, 51.2), "lcet10.txt": (371.0, 58.5),
+    "plrabn12.txt": (304.0, 49.7), "geo.protodata": (1254.1, 140.9), "kppkn.gtb": (425.4, 74.8),
+}
+
+
+def per_file_table(ctx, torch, dev, names, fixture_streams, R):
+    """BASELINE config 4: each Snappy file by itself (bench/src/bench.rs:181-193,279-283 decode/encode pairs), as a batch of
+    R independent copies resident in HBM; beside the published i5-2500K numbers and the CPU port on this box (1 thread)."""
+    import lzfse_rust_amd as lz
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_py import Oracle
+    o = Oracle("liblzfse_oracle_native.so")
+    raws_np, st = ctx.decode_batch(fixture_streams)
+    assert all(s == 0 for s in st)
+    rows = []
+    for name, r in zip(names, raws_np):
+        raw = r.tobytes()
+        B = DeviceBatch(torch, dev, lz, [raw] * R)
+        enc_len, est = ctx.encode_batch_device(B.d_raw.data_ptr(), B.raw_off, B.raw_len, B.d_enc.data_ptr(), B.enc_off, B.enc_cap)
+        assert (est == 0).all()
+        want = o.encode(raw)
+        got = B.d_enc[int(B.enc_off[0]):int(B.enc_off[0]) + int(enc_len[0])].cpu().numpy().tobytes()
+        assert got == want, name   # bit-exact vs the CPU port
+        te, td = [], []
+        for _ in range(7):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ctx.encode_batch_device(B.d_raw.data_ptr(), B.raw_off, B.raw_len, B.d_enc.data_ptr(), B.enc_off, B.enc_cap)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            _, dst_ = ctx.decode_batch_device(B.d_enc.data_ptr(), B.enc_off, enc_len, B.d_dec.data_ptr(), B.raw_off, B.raw_len)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            assert (dst_ == 0).all()
+            te.append(t1 - t0)
+            td.append(t2 - t1)
+        assert torch.equal(B.d_dec[:B.raw_padded], B.d_raw[:B.raw_padded]), name
+        te, td = np.array(te[2:]), np.array(td[2:])   # two warm-up samples dropped
+        # CPU port, one thread, ~0.5 s per direction
+        t0 = time.perf_counter()
+        k = 0
+        while time.perf_counter() - t0 < 0.5:
+            o.encode(raw)
+            k += 1
+        ce = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        j = 0
+        while time.perf_counter() - t0 < 0.5:
+            o.decode(want, cap=len(raw), as_array=True)
+            j += 1
+        cd = time.perf_counter() - t0
+        mib = 1 << 20
+        pub = README_I5_2500K.get(name)
+        rows.append({
+            "file": name, "raw_bytes": len(raw), "compressed_bytes": len(want), "copies": R,
+            "gpu_encode_MiBps": round(len(raw) * R / te.mean() / mib, 1), "gpu_encode_sd_pct": round(100 * te.std() / te.mean(), 1),
+            "gpu_decode_MiBps": round(len(raw) * R / td.mean() / mib, 1), "gpu_decode_sd_pct": round(100 * td.std() / td.mean(), 1),
+            "gpu_encode_GBps": round(len(raw) * R / te.mean() / 1e9, 2), "gpu_decode_GBps": round(len(raw) * R / td.mean() / 1e9, 2),
+            "cpu_port_encode_MiBps": round(len(raw) * k / ce / mib, 1), "cpu_port_decode_MiBps": round(len(raw) * j / cd / mib, 1),
+            "readme_i5_2500k_decode_MiBps": pub[0] if pub else None, "readme_i5_2500k_encode_MiBps": pub[1] if pub else None,
+        })
+    print(json.dumps({"table": "snappy per file (BASELINE config 4)", "copies_per_batch": R, "protocol":
+                      "each file alone as R independent streams resident in HBM, 2 warm-up + 5 samples, mean and sd; wall time of "
+                      "the batch call incl. host orchestration; outputs bit-exact vs the CPU port; CPU port = oracle/, 1 thread",
+                      "rows": rows}), flush=True)
 
 
 if __name__ == "__main__":
