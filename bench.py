@@ -312,10 +312,11 @@ def main():
             _, _, kx = step(True)
             ctx.set_option("encode_lanes", args.lanes)
             ctx.set_option("decode_lanes", args.lanes)
-            ex_ms = kx[dom][0] / max(kx[dom][1], 1)
-            roof["exclusive_launch_ms"] = round(ex_ms, 4)
-            roof["exclusive_achieved"] = round((comp_total + raw_total) / (ex_ms * 1e-3) / 1e9, 3)
-            roof["exclusive_frac"] = round(roof["exclusive_achieved"] / HBM_PEAK_GBPS, 6)
+            if dom in kx:   # (an unsplit call may take another LZ path than its sub-batches did)
+                ex_ms = kx[dom][0] / max(kx[dom][1], 1)
+                roof["exclusive_launch_ms"] = round(ex_ms, 4)
+                roof["exclusive_achieved"] = round((comp_total + raw_total) / (ex_ms * 1e-3) / 1e9, 3)
+                roof["exclusive_frac"] = round(roof["exclusive_achieved"] / HBM_PEAK_GBPS, 6)
             out["exclusive_kernel_ms"] = {k: round(v[0], 4) for k, v in sorted(kx.items())}
             out["copy_peak"] = copy_peak(torch, dev)
             out["pcie_inclusive"] = pcie_inclusive(ctx, lz, batch_raw)

@@ -20,6 +20,12 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#if defined(__GNUC__) || defined(__clang__)
+#define LZFSE_MI_API __attribute__((visibility("default")))   /* the library is built with -fvisibility=hidden */
+#else
+#define LZFSE_MI_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -64,14 +70,14 @@ enum {
  * not thread-safe; distinct contexts are independent. Results never depend on prior calls. */
 typedef struct lzfse_mi_ctx lzfse_mi_ctx;
 
-int lzfse_mi_create(int device, lzfse_mi_ctx **out);
-void lzfse_mi_destroy(lzfse_mi_ctx *ctx);
-const char *lzfse_mi_status_string(int status);
-const char *lzfse_mi_version(void);
+LZFSE_MI_API int lzfse_mi_create(int device, lzfse_mi_ctx **out);
+LZFSE_MI_API void lzfse_mi_destroy(lzfse_mi_ctx *ctx);
+LZFSE_MI_API const char *lzfse_mi_status_string(int status);
+LZFSE_MI_API const char *lzfse_mi_version(void);
 
 /* Use an existing HIP stream (hipStream_t passed as void*, e.g. torch's current stream).
  * NULL restores the context's own stream. */
-int lzfse_mi_set_stream(lzfse_mi_ctx *ctx, void *hip_stream);
+LZFSE_MI_API int lzfse_mi_set_stream(lzfse_mi_ctx *ctx, void *hip_stream);
 
 /* Tuning knobs. A large batch call is cut into sub-batches ("lanes") that run side by side on their own HIP streams
  * (several stages are latency-bound); results never depend on these. The LZFSE_MI_OPT_DIAG_* options exist in the
@@ -85,40 +91,40 @@ enum {
     LZFSE_MI_OPT_DIAG_LZ_TILE = 101, /* -1: by stream count, 0: 256-thread / 8 KiB tile, 1: 1024-thread / 32 KiB tile */
     LZFSE_MI_OPT_DIAG_STATS = 102    /* bit mask: per-stage statistics on stderr */
 };
-int lzfse_mi_set_option(lzfse_mi_ctx *ctx, int option, int64_t value);
+LZFSE_MI_API int lzfse_mi_set_option(lzfse_mi_ctx *ctx, int option, int64_t value);
 
 /* Upper bound of the encoded size of an n-byte input (fse/constants.rs:54-69: every full
  * bvx2 block carries >= 39 996 raw bytes and costs <= 54 bits per LMD + 10 bits per literal). */
-size_t lzfse_mi_encode_bound(size_t n);
+LZFSE_MI_API size_t lzfse_mi_encode_bound(size_t n);
 
 /* ---- host-pointer entry points: exactly what the Rust shim binds ---------------------- */
 
 /* encode_bytes: writes the complete stream (blocks + bvx$) for src[0..n) at dst, never more
  * than cap bytes; *out_len = bytes written (the u64 the Rust method returns). */
-int lzfse_mi_encode(lzfse_mi_ctx *ctx, const uint8_t *src, size_t n, uint8_t *dst, size_t cap,
+LZFSE_MI_API int lzfse_mi_encode(lzfse_mi_ctx *ctx, const uint8_t *src, size_t n, uint8_t *dst, size_t cap,
                     size_t *out_len);
 
 /* decode_bytes: src[0..n) must be one complete stream ending exactly at bvx$ + 4 bytes
  * (decoder.rs:90-96). *out_len = raw bytes written. LZFSE_MI_BUFFER_OVERFLOW if cap is short;
  * size dst with lzfse_mi_decode_size. */
-int lzfse_mi_decode(lzfse_mi_ctx *ctx, const uint8_t *src, size_t n, uint8_t *dst, size_t cap,
+LZFSE_MI_API int lzfse_mi_decode(lzfse_mi_ctx *ctx, const uint8_t *src, size_t n, uint8_t *dst, size_t cap,
                     size_t *out_len);
 
 /* The size classes the reference keeps on the host CPU (encode/frontend_bytes.rs:63-111): n <= 20 -> one bvx-
  * block, 21..=4096 -> one bvxn block (or bvx- when not smaller), then bvx$. Pure host code, no context needed;
  * lzfse_mi_encode / _batch / _batch_device route inputs of this size class here themselves. n > 4096 is
  * LZFSE_MI_BAD_ARGUMENT (those inputs are bvx2 and belong to the device path). */
-int lzfse_mi_encode_small(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *out_len);
+LZFSE_MI_API int lzfse_mi_encode_small(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *out_len);
 
 /* Header walk on the host: sum of n_raw_bytes of all blocks. */
-int lzfse_mi_decode_size(const uint8_t *src, size_t n, uint64_t *raw_len);
+LZFSE_MI_API int lzfse_mi_decode_size(const uint8_t *src, size_t n, uint64_t *raw_len);
 
 /* Many independent streams per call (the unit of GPU parallelism). The
  * return value reports call-level failures only; statuses[i] is per stream. */
-int lzfse_mi_encode_batch(lzfse_mi_ctx *ctx, size_t count, const uint8_t *const *srcs,
+LZFSE_MI_API int lzfse_mi_encode_batch(lzfse_mi_ctx *ctx, size_t count, const uint8_t *const *srcs,
                           const size_t *lens, uint8_t *const *dsts, const size_t *caps,
                           size_t *out_lens, int *statuses);
-int lzfse_mi_decode_batch(lzfse_mi_ctx *ctx, size_t count, const uint8_t *const *srcs,
+LZFSE_MI_API int lzfse_mi_decode_batch(lzfse_mi_ctx *ctx, size_t count, const uint8_t *const *srcs,
                           const size_t *lens, uint8_t *const *dsts, const size_t *caps,
                           size_t *out_lens, int *statuses);
 
@@ -127,18 +133,18 @@ int lzfse_mi_decode_batch(lzfse_mi_ctx *ctx, size_t count, const uint8_t *const 
  * call on this context (index 0 for the single-stream calls); 0 when the stream's status carries none.
  * VnErrorKind::BadPayloadCount(u32) (src/vn/error_kind.rs:11) is raised by the reference's encoder-side constructor
  * only (vn/block.rs:16-22) and cannot occur on this path. */
-int lzfse_mi_last_error_detail(lzfse_mi_ctx *ctx, size_t stream_index, uint32_t *detail);
+LZFSE_MI_API int lzfse_mi_last_error_detail(lzfse_mi_ctx *ctx, size_t stream_index, uint32_t *detail);
 
 /* ---- device-resident entry points (inputs and outputs already in HBM) ----------------- */
 /* Stream i reads d_src[src_off[i] .. src_off[i] + src_len[i]) and writes at
  * d_dst[dst_off[i] ..], at most dst_cap[i] bytes. Offset/length arrays are HOST arrays.
  * out_lens / statuses are HOST arrays filled when the call returns (the call synchronises
  * the context's stream once at its end). */
-int lzfse_mi_decode_batch_device(lzfse_mi_ctx *ctx, size_t count, const void *d_src,
+LZFSE_MI_API int lzfse_mi_decode_batch_device(lzfse_mi_ctx *ctx, size_t count, const void *d_src,
                                  const uint64_t *src_off, const uint64_t *src_len, void *d_dst,
                                  const uint64_t *dst_off, const uint64_t *dst_cap,
                                  uint64_t *out_lens, int *statuses);
-int lzfse_mi_encode_batch_device(lzfse_mi_ctx *ctx, size_t count, const void *d_src,
+LZFSE_MI_API int lzfse_mi_encode_batch_device(lzfse_mi_ctx *ctx, size_t count, const void *d_src,
                                  const uint64_t *src_off, const uint64_t *src_len, void *d_dst,
                                  const uint64_t *dst_off, const uint64_t *dst_cap,
                                  uint64_t *out_lens, int *statuses);
@@ -153,8 +159,8 @@ typedef struct lzfse_mi_timings {
     float ms[LZFSE_MI_MAX_STAGES];
     uint64_t launches[LZFSE_MI_MAX_STAGES];
 } lzfse_mi_timings;
-int lzfse_mi_enable_timing(lzfse_mi_ctx *ctx, int enable);
-int lzfse_mi_get_timings(lzfse_mi_ctx *ctx, lzfse_mi_timings *out);
+LZFSE_MI_API int lzfse_mi_enable_timing(lzfse_mi_ctx *ctx, int enable);
+LZFSE_MI_API int lzfse_mi_get_timings(lzfse_mi_ctx *ctx, lzfse_mi_timings *out);
 
 #ifdef __cplusplus
 }

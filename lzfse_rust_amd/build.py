@@ -41,7 +41,7 @@ def _build_one(path, defines, verbose):
     cc = _hipcc()
     tag = "diag" if defines else "prod"
     os.makedirs(_OBJ, exist_ok=True)
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + defines
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fvisibility=hidden"] + defines
 
     def compile_one(src):
         obj = os.path.join(_OBJ, f"{tag}_{os.path.splitext(src)[0]}.o")

@@ -11,9 +11,10 @@
 #include <cstring>
 #include <new>
 #include <vector>
-#include <thread>
-#include <system_error>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
+#include <thread>
 
 #include "common.h"
 #include "internal.h"
@@ -57,6 +58,49 @@ struct HostBuf {  // pinned staging
 
 #define LZFSE_MI_MAX_LANES 4
 
+namespace {
+// One helper thread per shadow context, alive as long as the context: a split batch call hands it a sub-batch and
+// waits for it, instead of creating and joining threads per call.
+class LaneWorker {
+  public:
+    LaneWorker() : th_([this] { loop(); }) {}
+    ~LaneWorker() {
+        { std::lock_guard<std::mutex> g(m_); quit_ = true; }
+        cv_.notify_all();
+        if (th_.joinable()) th_.join();
+    }
+    void submit(std::function<void()> job) {
+        { std::lock_guard<std::mutex> g(m_); job_ = std::move(job); busy_ = true; }
+        cv_.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [&] { return !busy_; });
+    }
+  private:
+    void loop() {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return quit_ || (busy_ && job_); });
+                if (quit_) return;
+                job = std::move(job_);
+                job_ = nullptr;
+            }
+            job();
+            { std::lock_guard<std::mutex> g(m_); busy_ = false; }
+            cv_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::function<void()> job_;
+    bool busy_ = false, quit_ = false;
+    std::thread th_;   // last member: the thread starts when everything above exists
+};
+}  // namespace
+
 struct lzfse_mi_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -68,8 +112,8 @@ struct lzfse_mi_ctx {
     // encode scratch (encode.hip)
     EncScratch enc;
     // host-pointer API staging
-    DevBuf d_in, d_out;
-    HostBuf h_in, h_out;
+    DevBuf d_in, d_out, d_small;
+    HostBuf h_in, h_out, h_small;
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
@@ -79,6 +123,7 @@ struct lzfse_mi_ctx {
     lzfse_mi_timings last{};
     // second lane of a split batch call: own stream, scratch and timers (created on first use)
     lzfse_mi_ctx *shadow[LZFSE_MI_MAX_LANES - 1] = {};
+    LaneWorker *worker[LZFSE_MI_MAX_LANES - 1] = {};         // helper thread of shadow[k] (created with it)
     lzmi::LaneGate gates[LZFSE_MI_MAX_LANES - 1];            // owned by the main context
     lzmi::LaneGate *gate_in = nullptr, *gate_out = nullptr;  // set per lane for the duration of a split encode
     hipEvent_t split_ev = nullptr;
@@ -148,6 +193,18 @@ static void timing_end(lzfse_mi_ctx *c) {
 
 #define HIP_TRY(x) do { if ((x) != hipSuccess) { return LZFSE_MI_IO; } } while (0)
 
+// b[b_off ..] = a[a_off ..] for len bytes, one workgroup per descriptor: gathers the small inputs of a batch into one
+// staging buffer and scatters their encoded streams back
+struct SmallDesc {
+    uint64_t a_off, b_off;
+    uint32_t len, pad;
+};
+__global__ void small_copy_kernel(const uint8_t *__restrict__ a, uint8_t *__restrict__ b, const SmallDesc *__restrict__ desc, uint32_t n) {
+    if (blockIdx.x >= n) return;
+    const SmallDesc d = desc[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < d.len; i += blockDim.x) b[d.b_off + i] = a[d.a_off + i];
+}
+
 extern "C" {
 
 #ifdef LZFSE_MI_DIAG
@@ -213,17 +270,19 @@ int lzfse_mi_create(int device, lzfse_mi_ctx **out) {
 
 void lzfse_mi_destroy(lzfse_mi_ctx *c) {
     if (!c) return;
+    for (auto &w : c->worker) { delete w; w = nullptr; }
     for (auto &s : c->shadow) { if (s) lzfse_mi_destroy(s); s = nullptr; }
     (void)hipSetDevice(c->device);
     if (c->split_ev) (void)hipEventDestroy(c->split_ev);
     for (auto &g : c->gates) if (g.ev) (void)hipEventDestroy(g.ev);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->d_streams, &c->d_walk, &c->d_plan, &c->d_blocks, &c->d_bres, &c->d_sres,
-                      &c->d_lmds, &c->d_lits, &c->d_origin, &c->d_jerr, &c->d_wcache, &c->d_in, &c->d_out})
+                      &c->d_lmds, &c->d_lits, &c->d_origin, &c->d_jerr, &c->d_wcache, &c->d_in, &c->d_out, &c->d_small})
         b->release();
     enc_scratch_release(c->enc);
     c->h_in.release();
     c->h_out.release();
+    c->h_small.release();
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -480,26 +539,48 @@ static int encode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
     if (count > 0x7FFFFFFFu) return LZFSE_MI_BAD_ARGUMENT;
     HIP_TRY(hipSetDevice(c->device));
     c->detail.assign(count, 0u);
+    // ---- inputs <= 4096 bytes: the reference's host-side size classes (raw / LZVN, frontend_bytes.rs:63-111). All of
+    // them travel together: one gather kernel + one D2H, the host encoder, one H2D + one scatter kernel, queued in
+    // front of the device pipeline of the large streams (whose final synchronisation covers the copies back).
+    std::vector<size_t> small;
+    for (size_t i = 0; i < count; i++)
+        if (src_len[i] <= VN_CUTOFF) small.push_back(i);
+    std::vector<int> small_status(small.size(), 0);
+    std::vector<uint64_t> small_len(small.size(), 0);
+    if (!small.empty()) {
+        constexpr size_t SLOT = 4096 + 256;   // a stream of <= 4096 bytes never encodes to more than n + 24 bytes
+        const size_t ns = small.size();
+        if (!c->d_small.ensure(2 * ns * SLOT + ns * sizeof(SmallDesc)) || !c->h_small.ensure(2 * ns * SLOT + ns * sizeof(SmallDesc)))
+            return LZFSE_MI_IO;
+        uint8_t *d_in = (uint8_t *)c->d_small.p, *d_out = d_in + ns * SLOT;
+        SmallDesc *d_desc = (SmallDesc *)(d_out + ns * SLOT);
+        uint8_t *h_in = (uint8_t *)c->h_small.p, *h_out = h_in + ns * SLOT;
+        SmallDesc *hd = (SmallDesc *)(h_out + ns * SLOT);   // descriptors in pinned memory too: the copies are asynchronous
+        for (size_t k = 0; k < ns; k++) hd[k] = {src_off[small[k]], (uint64_t)k * SLOT, (uint32_t)src_len[small[k]], 0u};
+        HIP_TRY(hipMemcpyAsync(d_desc, hd, ns * sizeof(SmallDesc), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(small_copy_kernel, dim3((unsigned)ns), dim3(256), 0, c->stream, (const uint8_t *)d_src, d_in, d_desc, (uint32_t)ns);
+        HIP_TRY(hipMemcpyAsync(h_in, d_in, ns * SLOT, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (size_t k = 0; k < ns; k++) {
+            size_t n = 0;
+            const size_t i = small[k];
+            small_status[k] = lzfse_mi_encode_small(h_in + k * SLOT, (size_t)src_len[i], h_out + k * SLOT, SLOT, &n);
+            if (small_status[k] == 0 && n > dst_cap[i]) small_status[k] = LZFSE_MI_BUFFER_OVERFLOW;
+            small_len[k] = small_status[k] ? 0 : n;
+            hd[k] = {(uint64_t)k * SLOT, dst_off[i], (uint32_t)small_len[k], 0u};
+        }
+        HIP_TRY(hipMemcpyAsync(d_out, h_out, ns * SLOT, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_desc, hd, ns * sizeof(SmallDesc), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(small_copy_kernel, dim3((unsigned)ns), dim3(256), 0, c->stream, (const uint8_t *)d_out, (uint8_t *)d_dst, d_desc, (uint32_t)ns);
+    }
     timing_begin(c);
     int r = enc_batch_device(c, (uint32_t)count, (const uint8_t *)d_src, src_off, src_len, (uint8_t *)d_dst,
                              dst_off, dst_cap, out_lens, statuses);
     timing_end(c);
     if (r) return r;
-    // inputs <= 4096 bytes: the reference's host-side size classes (raw / LZVN), encoded on the host
-    uint8_t in[4096], out[4096 + 64];
-    for (size_t i = 0; i < count; i++) {
-        if (src_len[i] > VN_CUTOFF) continue;
-        if (src_len[i]) HIP_TRY(hipMemcpyAsync(in, (const uint8_t *)d_src + src_off[i], src_len[i], hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        size_t n = 0;
-        statuses[i] = lzfse_mi_encode_small(in, (size_t)src_len[i], out, sizeof out, &n);
-        if (statuses[i] == 0 && n > dst_cap[i]) statuses[i] = LZFSE_MI_BUFFER_OVERFLOW;
-        out_lens[i] = 0;
-        if (statuses[i] == 0) {
-            HIP_TRY(hipMemcpyAsync((uint8_t *)d_dst + dst_off[i], out, n, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            out_lens[i] = n;
-        }
+    if (!small.empty()) {
+        HIP_TRY(hipStreamSynchronize(c->stream));   // (a batch of small inputs only: nothing else has waited for the copies)
+        for (size_t k = 0; k < small.size(); k++) { statuses[small[k]] = small_status[k]; out_lens[small[k]] = small_len[k]; }
     }
     return LZFSE_MI_OK;
 }
@@ -536,7 +617,11 @@ static int split_batch(lzfse_mi_ctx *c, batch_dev_fn one, int lanes, bool stagge
     if (hipSetDevice(c->device) != hipSuccess) return LZFSE_MI_IO;
     if (!c->split_ev && hipEventCreateWithFlags(&c->split_ev, hipEventDisableTiming) != hipSuccess) c->split_ev = nullptr;
     for (int k = 0; k + 1 < lanes; k++)
-        if (!c->shadow[k] && lzfse_mi_create(c->device, &c->shadow[k]) != LZFSE_MI_OK) { c->shadow[k] = nullptr; lanes = k + 1; break; }
+        if (!c->shadow[k]) {
+            if (lzfse_mi_create(c->device, &c->shadow[k]) != LZFSE_MI_OK) { c->shadow[k] = nullptr; lanes = k + 1; break; }
+            c->worker[k] = new (std::nothrow) LaneWorker();
+            if (!c->worker[k]) { lzfse_mi_destroy(c->shadow[k]); c->shadow[k] = nullptr; lanes = k + 1; break; }
+        }
     if (lanes < 2 || !c->split_ev) return unsplit();
     struct Part {
         std::vector<size_t> idx;
@@ -574,7 +659,7 @@ static int split_batch(lzfse_mi_ctx *c, batch_dev_fn one, int lanes, bool stagge
         lzfse_mi_ctx *cx = k == 0 ? c : c->shadow[k - 1];
         cx->gate_in = (stagger && k > 0) ? &c->gates[k - 1] : nullptr;
         cx->gate_out = (stagger && k + 1 < lanes) ? &c->gates[k] : nullptr;
-        if (cx->gate_out) cx->gate_out->state.store(0);
+        if (cx->gate_out) cx->gate_out->arm();
     }
     c->detail_out.assign(count, 0u);
     auto run = [&](lzfse_mi_ctx *cx, Part &p) {
@@ -582,19 +667,18 @@ static int split_batch(lzfse_mi_ctx *c, batch_dev_fn one, int lanes, bool stagge
         p.rc = one(cx, p.idx.size(), d_src, p.so.data(), p.sl.data(), d_dst, p.dof.data(), p.dc.data(), p.ol.data(), p.st.data());
         for (size_t k = 0; k < p.idx.size() && k < cx->detail.size(); k++) c->detail_out[p.idx[k]] = cx->detail[k];
     };
-    std::vector<std::thread> helpers;
-    size_t started = 0;
-    try {
-        for (int k = 0; k + 1 < lanes; k++) { helpers.emplace_back(run, c->shadow[k], std::ref(part[(size_t)k + 1])); started++; }
-    } catch (const std::system_error &) {
+    const size_t started = (size_t)lanes - 1;
+    for (int k = 0; k + 1 < lanes; k++) {
+        lzfse_mi_ctx *cx = c->shadow[k];
+        Part *pp = &part[(size_t)k + 1];
+        c->worker[k]->submit([&run, cx, pp] { run(cx, *pp); });
     }
     run(c, part[0]);
-    for (auto &h : helpers) h.join();
+    for (int k = 0; k + 1 < lanes; k++) c->worker[k]->wait();
     for (int k = 0; k < lanes; k++) {
         lzfse_mi_ctx *cx = k == 0 ? c : c->shadow[k - 1];
         cx->gate_in = cx->gate_out = nullptr;
     }
-    for (size_t k = started + 1; k < part.size(); k++) run(c, part[k]);  // lanes whose thread could not be started
     int rc = 0;
     for (Part &p : part) {
         for (size_t k = 0; k < p.idx.size(); k++) { out_lens[p.idx[k]] = p.ol[k]; statuses[p.idx[k]] = p.st[k]; }

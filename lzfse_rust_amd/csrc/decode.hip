@@ -441,8 +441,10 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
         const uint32_t s_home = lane < 4 ? (uint32_t)lane : 256u, s_inc = lane < 4 ? 4u : 0u;
         uint32_t sidx = s_home;
         uint64_t win = n_groups ? bw_window(w) : 0;
+        // the lookup of step g + 1 needs only the state, so it is issued before the window of step g + 1 is fetched: the
+        // two LDS round trips of a step overlap instead of following each other
+        uint32_t ent = u_tab[state];
         for (uint32_t g = 0; g < n_groups; g++) {
-            const uint32_t ent = u_tab[state];
             const uint32_t k = ent & 0xFF;
             const int32_t delta = (int32_t)(int16_t)(ent >> 16);
             uint32_t pre = k;
@@ -450,7 +452,9 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
             pre += dpp_shr<2>(pre);  // inclusive prefix over lanes 0..3
             const uint32_t bits = (uint32_t)(win >> ((64 - pre) & 63)) & ((1u << k) - 1u);  // pre == 0 only with k == 0
             state = (uint32_t)((int32_t)bits + delta) & 1023u;
-            stg_lit[sidx] = (uint8_t)(ent >> 8);
+            const uint32_t sym = ent >> 8;
+            ent = u_tab[state];
+            stg_lit[sidx] = (uint8_t)sym;
             sidx += s_inc;
             bw_advance(w, read_lane(pre, 3));
             win = bw_step_window(w);
@@ -500,8 +504,8 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
             if (nz) carry_d = read_lane(vd, 63 - __builtin_clzll(nz));
         };
         uint64_t win = n ? bw_window(w) : 0;
+        uint2 ent = v_tab[tbase + state];   // (looked up one step ahead of its window, see the literal loop)
         for (uint32_t i = 0; i < n; i++) {
-            const uint2 ent = v_tab[tbase + state];
             const uint32_t k = ent.x & 0xFF, vb = (ent.x >> 8) & 0xFF;
             const int32_t delta = (int32_t)(int16_t)(ent.x >> 16);
             uint32_t pre = k + vb;
@@ -512,7 +516,9 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
             const uint32_t extra = x & ((1u << vb) - 1u);
             const uint32_t sb = (x >> vb) & ((1u << k) - 1u);
             state = (uint32_t)((int32_t)sb + delta) & smask;
-            stg_lmd[sidx] = ent.y + extra;
+            const uint32_t value = ent.y + extra;
+            ent = v_tab[tbase + state];
+            stg_lmd[sidx] = value;
             sidx += s_inc;
             bw_advance(w, read_lane(pre, 2));
             win = bw_step_window(w);

@@ -14,8 +14,6 @@
 #include <cstdlib>
 #include <vector>
 
-#include <thread>
-
 #include "enc_common.h"
 
 struct lzfse_mi_ctx;
@@ -693,7 +691,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     // whatever path leaves this function, the next lane of a split call must not be left waiting
     struct GateRelease {
         LaneGate *g;
-        ~GateRelease() { if (g) { int e = 0; g->state.compare_exchange_strong(e, 2); } }
+        ~GateRelease() { if (g) g->open(2); }
     } gate_release{ctx_gate_out(c)};
     std::vector<EncStream> hs;
     for (uint32_t i = 0; i < count; i++) {
@@ -781,8 +779,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     E_TRY(hipMemsetAsync(d_bitmap, 0, pos_total / 8 + 64, stq));
     if (LaneGate *gi = ctx_gate_in(c)) {
         // lane of a split call: start when the previous lane has queued its candidate kernel (LaneGate, internal.h)
-        for (int spins = 0; gi->state.load() == 0 && spins < 2000000; spins++) std::this_thread::yield();
-        if (gi->state.load() == 1) (void)hipStreamWaitEvent(stq, gi->ev, 0);
+        if (gi->wait() == 1) (void)hipStreamWaitEvent(stq, gi->ev, 0);
     }
     {
         StageTimer t(c, "enc_chain");
@@ -792,7 +789,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         StageTimer t(c, "enc_link");
         launch_enc_link(d_streams, d_tiles, nt, d_prev, d_summary, d_flist, d_fcount, stq);
     }
-    if (LaneGate *go = ctx_gate_out(c)) go->state.store(hipEventRecord(go->ev, stq) == hipSuccess ? 1 : 2);
+    if (LaneGate *go = ctx_gate_out(c)) go->open(hipEventRecord(go->ev, stq) == hipSuccess ? 1 : 2);
     {
         StageTimer t(c, "enc_cand");
         launch_enc_cand(d_src, d_streams, d_tiles, nt, d_prev, d_rec, d_bitmap, stq);
@@ -872,7 +869,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
 #ifdef LZFSE_MI_DIAG
 // Debug hook of the diagnostic build for stage-level parity tests (tests/test_gpu_encode.py): the chain links and the
 // per-position candidate records of ONE stream. Not part of the ABI; the product library does not export it.
-extern "C" int lzfse_mi_debug_candidates(lzfse_mi_ctx *c, const uint8_t *h_src, size_t n, uint32_t *h_prev, uint32_t *h_rec_xy) {
+extern "C" LZFSE_MI_API int lzfse_mi_debug_candidates(lzfse_mi_ctx *c, const uint8_t *h_src, size_t n, uint32_t *h_prev, uint32_t *h_rec_xy) {
     if (!c || n <= VN_CUTOFF || n > 0x7FFFFFFFull) return LZFSE_MI_BAD_ARGUMENT;
     hipStream_t stq = ctx_stream(c);
     EncScratch &S = ctx_enc(c);

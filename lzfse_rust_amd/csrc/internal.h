@@ -2,7 +2,9 @@
 #pragma once
 #include "common.h"
 
-#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 
 struct lzfse_mi_ctx;
 
@@ -22,7 +24,16 @@ hipStream_t ctx_stream(lzfse_mi_ctx *c);
 // throughput-bound stage instead of both lanes doing the same thing at the same time.
 struct LaneGate {
     hipEvent_t ev = nullptr;
-    std::atomic<int> state{0};  // 0: pending, 1: ev recorded, 2: released without an event
+    std::mutex m;
+    std::condition_variable cv;
+    int state = 0;  // 0: pending, 1: ev recorded, 2: released without an event
+    void arm() { std::lock_guard<std::mutex> g(m); state = 0; }
+    void open(int s) { { std::lock_guard<std::mutex> g(m); if (state == 0) state = s; } cv.notify_all(); }
+    int wait() {  // bounded: a lane that never gets there (an error path) must not hang its successor
+        std::unique_lock<std::mutex> g(m);
+        cv.wait_for(g, std::chrono::seconds(2), [&] { return state != 0; });
+        return state;
+    }
 };
 LaneGate *ctx_gate_in(lzfse_mi_ctx *c);
 LaneGate *ctx_gate_out(lzfse_mi_ctx *c);

@@ -5,7 +5,7 @@ reference, frontend_bytes.rs:113-119, so chunks are independent); chunk c goes t
 collective exists: ranks only exchange result metadata (sizes, hashes) at the end. The chunk framing is this build's own:
 a plain LzfseDecoder decodes each chunk but not their concatenation (EOS rule, decoder.rs:93-95).
 
-bench.py (one process per GPU) and tests/test_multirank.py (two gloo ranks on CPU, codec stood in) run the same
+bench.py (one process per GPU) and tests/test_multirank.py (two gloo ranks on CPU, a CPU codec stood in) run the same
 functions below; only the codec object differs.
 """
 import hashlib
@@ -59,8 +59,8 @@ def merge_reports(reports, n_chunks):
 
 
 def check_against(merged, reference):
-    """Per-chunk equality of the gathered streams with a reference list made by ONE encoder (rank 0's, or the oracle's
-    in the CPU test): same lengths, same SHA-256."""
+    """Per-chunk equality of the gathered streams with a reference list made by ONE encoder (rank 0's; the CPU test
+    injects its own): same lengths, same SHA-256."""
     bad = [c for c in sorted(reference) if merged.get(c) != tuple(reference[c])]
     if bad:
         raise AssertionError(f"{len(bad)} chunk streams differ from the reference list: {bad[:8]}")

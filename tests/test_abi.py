@@ -117,3 +117,34 @@ def test_small_size_classes_match_oracle(lib, oracle):
     assert m.encode_small(b"test") == bytes([0x62, 0x76, 0x78, 0x2d, 4, 0, 0, 0, 0x74, 0x65, 0x73, 0x74, 0x62, 0x76, 0x78, 0x24])
     with pytest.raises(m.LzfseError):
         m.encode_small(bytes(4097))
+
+
+def _build_c_driver(tmp_path):
+    import subprocess
+    from lzfse_rust_amd import build
+    build.build()
+    exe = str(tmp_path / "abi_driver")
+    libdir = os.path.dirname(build.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "abi_driver.c"), "-L", libdir, "-llzfse_mi", "-Wl,-rpath," + libdir, "-o", exe])
+    return exe
+
+
+def test_header_is_c_and_c_driver_links(tmp_path):
+    """include/lzfse_mi.h compiles as C11 with -Wall -Wextra -Werror and a plain C caller links against the library.
+    Without a GPU the driver must stop at lzfse_mi_create with LZFSE_MI_NO_DEVICE (exit code 3), never fall back."""
+    import subprocess
+    import torch
+    exe = _build_c_driver(tmp_path)
+    rc = subprocess.run([exe], capture_output=True, text=True)
+    assert rc.returncode == (0 if torch.cuda.is_available() else 3), (rc.returncode, rc.stdout, rc.stderr)
+
+
+@pytest.mark.gpu
+def test_c_driver_round_trip_on_gpu(tmp_path):
+    """create / encode / decode_size / decode / error detail / batch / destroy from C, no Python in the data path."""
+    import subprocess
+    exe = _build_c_driver(tmp_path)
+    rc = subprocess.run([exe], capture_output=True, text=True)
+    assert rc.returncode == 0, (rc.returncode, rc.stdout, rc.stderr)
+    assert "abi driver ok" in rc.stdout
