@@ -149,6 +149,19 @@ LZFSE_MI_API int lzfse_mi_encode_batch_device(lzfse_mi_ctx *ctx, size_t count, c
                                  const uint64_t *dst_off, const uint64_t *dst_cap,
                                  uint64_t *out_lens, int *statuses);
 
+/* ---- chunked container, one process driving several devices ------------- */
+/* A large input is cut into `chunk`-byte pieces (0 = LZFSE_MI_CHUNK_DEFAULT), each encoded as its own complete LZFSE
+ * stream; chunk c is handled by ctxs[c mod n_ctx] (one context per device: the chunks are independent, nothing is
+ * exchanged between devices). The frame is this build's own (magic "LZMC", chunk table, streams back to back): a plain
+ * LzfseDecoder decodes each chunk stream, not the frame. What the lzfoo-like CLI (python -m lzfse_rust_amd.cli) writes. */
+#define LZFSE_MI_CHUNK_DEFAULT ((size_t)4 << 20)
+LZFSE_MI_API size_t lzfse_mi_chunked_bound(size_t n, size_t chunk);
+LZFSE_MI_API int lzfse_mi_encode_chunked(lzfse_mi_ctx *const *ctxs, int n_ctx, const uint8_t *src, size_t n, size_t chunk,
+                                         uint8_t *dst, size_t cap, size_t *out_len);
+LZFSE_MI_API int lzfse_mi_decode_chunked_size(const uint8_t *src, size_t n, uint64_t *raw_len);
+LZFSE_MI_API int lzfse_mi_decode_chunked(lzfse_mi_ctx *const *ctxs, int n_ctx, const uint8_t *src, size_t n, uint8_t *dst,
+                                         size_t cap, size_t *out_len);
+
 /* ---- measurement ---------------------------------------------------------------------- */
 /* Per-kernel device time of the LAST batch call on this context, measured with HIP events
  * recorded on the stream the kernels were launched on. names[i] points at static strings. */

@@ -20,7 +20,8 @@ _SYMBOLS = [
     "lzfse_mi_encode_bound", "lzfse_mi_encode", "lzfse_mi_decode", "lzfse_mi_decode_size",
     "lzfse_mi_encode_batch", "lzfse_mi_decode_batch", "lzfse_mi_decode_batch_device",
     "lzfse_mi_encode_batch_device", "lzfse_mi_enable_timing", "lzfse_mi_get_timings", "lzfse_mi_encode_small",
-    "lzfse_mi_last_error_detail", "lzfse_mi_set_option",
+    "lzfse_mi_last_error_detail", "lzfse_mi_set_option", "lzfse_mi_chunked_bound", "lzfse_mi_encode_chunked",
+    "lzfse_mi_decode_chunked_size", "lzfse_mi_decode_chunked",
 ]
 
 
@@ -77,6 +78,14 @@ def _load(path):
     L.lzfse_mi_enable_timing.argtypes = [vp, C.c_int]
     L.lzfse_mi_get_timings.restype = C.c_int
     L.lzfse_mi_get_timings.argtypes = [vp, C.POINTER(Timings)]
+    L.lzfse_mi_chunked_bound.restype = sz
+    L.lzfse_mi_chunked_bound.argtypes = [sz, sz]
+    L.lzfse_mi_encode_chunked.restype = C.c_int
+    L.lzfse_mi_encode_chunked.argtypes = [C.POINTER(vp), C.c_int, vp, sz, sz, vp, sz, C.POINTER(sz)]
+    L.lzfse_mi_decode_chunked_size.restype = C.c_int
+    L.lzfse_mi_decode_chunked_size.argtypes = [vp, sz, u64p]
+    L.lzfse_mi_decode_chunked.restype = C.c_int
+    L.lzfse_mi_decode_chunked.argtypes = [C.POINTER(vp), C.c_int, vp, sz, vp, sz, C.POINTER(sz)]
     L.lzfse_mi_set_option.restype = C.c_int
     L.lzfse_mi_set_option.argtypes = [vp, C.c_int, C.c_int64]
     return L

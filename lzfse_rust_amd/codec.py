@@ -183,3 +183,34 @@ def encode_bytes(src, dst):
 
 def decode_bytes(src, dst):
     return LzfseDecoder().decode_bytes(src, dst)
+
+
+# ---- chunked container over one or several devices (include/lzfse_mi.h, chunked section) ----
+
+def _ctx_array(contexts):
+    arr = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    return arr
+
+
+def encode_chunked(contexts, src, chunk=0):
+    """One large input -> "LZMC" frame of independent LZFSE streams, chunk c on contexts[c mod len(contexts)]."""
+    lib = contexts[0]._lib
+    a = np.frombuffer(src, dtype=np.uint8) if not isinstance(src, np.ndarray) else src
+    cap = lib.lzfse_mi_chunked_bound(a.size, chunk)
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    _check(lib.lzfse_mi_encode_chunked(_ctx_array(contexts), len(contexts), a.ctypes.data if a.size else None, a.size, chunk,
+                                       out.ctypes.data, cap, C.byref(n)))
+    return out[: n.value]
+
+
+def decode_chunked(contexts, frame):
+    lib = contexts[0]._lib
+    a = np.frombuffer(frame, dtype=np.uint8) if not isinstance(frame, np.ndarray) else frame
+    raw = C.c_uint64(0)
+    _check(lib.lzfse_mi_decode_chunked_size(a.ctypes.data if a.size else None, a.size, C.byref(raw)))
+    out = np.empty(max(raw.value, 1), dtype=np.uint8)
+    n = C.c_size_t(0)
+    _check(lib.lzfse_mi_decode_chunked(_ctx_array(contexts), len(contexts), a.ctypes.data, a.size, out.ctypes.data, raw.value,
+                                       C.byref(n)))
+    return out[: n.value]
