@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the exclusive pass, PCIe-inclusive and copy-peak measurements")
     ap.add_argument("--lanes", type=int, default=0, help="sub-batches run side by side per call (0: library default, 1: unsplit)")
+    ap.add_argument("--skip-verify", action="store_true", help=argparse.SUPPRESS)  # timing of deliberately broken ablation builds
     ap.add_argument("--per-file", type=int, default=0, metavar="R",
                     help="instead of the headline run: Criterion-style table, each Snappy file alone as a batch of R copies")
     args = ap.parse_args()
@@ -215,9 +216,10 @@ def main():
     enc_len, est = ctx.encode_batch_device(B.d_raw.data_ptr(), B.raw_off, B.raw_len, B.d_enc.data_ptr(), B.enc_off, B.enc_cap)
     assert (est == 0).all(), est
     dec_len, dst_ = ctx.decode_batch_device(B.d_enc.data_ptr(), B.enc_off, enc_len, B.d_dec.data_ptr(), B.raw_off, B.raw_len)
-    assert (dst_ == 0).all(), dst_
-    assert (dec_len == B.raw_len).all()
-    assert torch.equal(B.d_dec[:B.raw_padded], B.d_raw[:B.raw_padded]), "round trip mismatch"
+    assert args.skip_verify or (dst_ == 0).all(), dst_
+    if not args.skip_verify:
+        assert (dec_len == B.raw_len).all()
+        assert torch.equal(B.d_dec[:B.raw_padded], B.d_raw[:B.raw_padded]), "round trip mismatch"
     comp_total = int(enc_len.sum())
 
     def step(timed):
