@@ -154,7 +154,7 @@ __device__ __forceinline__ uint32_t lcp_fwd(const uint8_t *s, uint32_t a, uint32
 // that are still equal there are grouped into runs of consecutive positions with the same distance
 // (the inside of one long match): only the head of a run is extended, by the whole wave, and the
 // followers derive LCP(i + t, c + t) = LCP(i, c) - t. Repetitive data costs O(1) per position.
-constexpr uint32_t CAND_C1 = 64;
+constexpr uint32_t CAND_C1 = 20;   // a lane compares 4 + 16 bytes on its own (one step); measured best of 20 / 36 / 64
 constexpr int CAND_GL = 8;  // lanes per group of the long-match work list
 constexpr uint32_t CAND_BPT = (TILE_POS + 255) / 256;  // workgroups per tile
 
@@ -296,8 +296,8 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
         }
         uint32_t total = 0;
         if (any_more) {
-            // Heads of the wave with the same distance lie inside one match (they are < 64 positions apart and
-            // each is >= 64 long): LCP(i2, i2 - d) = LCP(i0, i0 - d) + i0 - i2. One of them is measured.
+            // Heads of the wave with the same distance that are < CAND_C1 positions apart lie inside one match (each is
+            // >= CAND_C1 long): LCP(i2, i2 - d) = LCP(i0, i0 - d) + i0 - i2. One of them is measured.
             q_tab[wv][lane] = 0xFFFFFFFFu;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -315,7 +315,10 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
                 if (more[k]) {
                     const uint32_t dk = i - cc[k];
                     lead[k] = q_tab[wv][(dk * 0x9E3779B1u) >> 26];
-                    dep[k] = lead[k] != (uint32_t)(k * 64 + lane) && q_dist[wv][lead[k]] == dk;
+                    // (the two heads must lie within the CAND_C1 bytes one of them has verified to be inside one match)
+                    const int gap = (int)(lead[k] & 63) - lane;
+                    dep[k] = lead[k] != (uint32_t)(k * 64 + lane) && q_dist[wv][lead[k]] == dk &&
+                             (uint32_t)(gap < 0 ? -gap : gap) < CAND_C1;
                 }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
