@@ -667,7 +667,8 @@ __device__ int vn_decode_serial(const uint8_t *p, uint64_t avail, uint32_t n_raw
     }
 }
 
-constexpr uint32_t SHORT_COPY = 24;  // copies up to this many bytes are done by the owning lane
+constexpr uint32_t SHORT_COPY = 24;
+constexpr int JUMP_SWEEPS = 3;   // jumping sweeps over a thread's unresolved bytes per workgroup barrier  // copies up to this many bytes are done by the owning lane
 
 template <int NT, int TILE>
 __global__ __launch_bounds__(NT) void dec_lz_kernel(
@@ -871,14 +872,18 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
                 const uint32_t dm = s_dm[tid];
                 uint32_t um = dm;  // owned bytes whose origin is not known to be final yet
                 for (;;) {
-                    for (uint32_t m2 = um; m2; m2 &= m2 - 1) {
-                        const uint32_t k = (uint32_t)__builtin_ctz(m2), b = tid + (k << NTS);
-                        const uint32_t o = s_org[b];
-                        if (!((s_dm[o & (NT - 1)] >> (o >> NTS)) & 1u)) { um &= ~(1u << k); continue; }
-                        const uint32_t o1 = s_org[o];
-                        if (!((s_dm[o1 & (NT - 1)] >> (o1 >> NTS)) & 1u)) { s_org[b] = (uint16_t)o1; um &= ~(1u << k); continue; }
-                        s_org[b] = s_org[o1];
-                    }
+                    // several sweeps per barrier: a sweep may already see what other threads resolved in this round (every
+                    // value ever stored names a byte with the same final content), and the barrier is the expensive part
+#pragma unroll 1
+                    for (int sweep = 0; sweep < JUMP_SWEEPS && um; sweep++)
+                        for (uint32_t m2 = um; m2; m2 &= m2 - 1) {
+                            const uint32_t k = (uint32_t)__builtin_ctz(m2), b = tid + (k << NTS);
+                            const uint32_t o = s_org[b];
+                            if (!((s_dm[o & (NT - 1)] >> (o >> NTS)) & 1u)) { um &= ~(1u << k); continue; }
+                            const uint32_t o1 = s_org[o];
+                            if (!((s_dm[o1 & (NT - 1)] >> (o1 >> NTS)) & 1u)) { s_org[b] = (uint16_t)o1; um &= ~(1u << k); continue; }
+                            s_org[b] = s_org[o1];
+                        }
                     if (!__syncthreads_or(um != 0)) break;
                 }
                 for (uint32_t m2 = dm; m2; m2 &= m2 - 1) {
