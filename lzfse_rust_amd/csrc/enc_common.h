@@ -19,6 +19,13 @@ __device__ __forceinline__ int e_lane() { return threadIdx.x & 63; }
 __device__ __forceinline__ uint32_t e_readlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 __device__ __forceinline__ uint32_t bucket_of(uint32_t v) { return (v * 0x9E3779B1u) >> (32 - HASH_BITS); }
 
+// Link record of a position (4 bytes): distance to the previous position of its bucket (18 bits: 0 = none within the
+// match window, fse/constants.rs:42) | 14 check bits of the position's own 4 bytes (a second hash: entries of one bucket
+// whose bytes differ agree in them with probability 2^-14; the byte compare, which starts at byte 0, settles it).
+__device__ __forceinline__ uint32_t link_make(uint32_t dist, uint32_t v) { return dist | (((v * 0x85EBCA6Bu) >> 18) << 18); }
+__device__ __forceinline__ uint32_t link_dist(uint32_t r) { return r & 0x3FFFFu; }
+__device__ __forceinline__ uint32_t link_chk(uint32_t r) { return r >> 18; }
+
 struct EncStream {       // one input stream (n > VN_CUTOFF) of the batch
     uint64_t src_off;    // offset of the stream in d_src
     uint64_t pos_base;   // offset of the stream in the per-position arrays (prev, rec)
@@ -93,17 +100,17 @@ __host__ __device__ inline uint32_t stage_need(uint32_t n_lit, uint32_t n_lmd) {
 
 
 // encode_match.hip
-void launch_enc_chain(const uint8_t *src, const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, uint2 *prev, uint32_t *summary,
+void launch_enc_chain(const uint8_t *src, const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, uint32_t *prev, uint32_t *summary,
                       uint32_t *flist, uint32_t *fcount, hipStream_t st);
-void launch_enc_link(const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, uint2 *prev, const uint32_t *summary,
+void launch_enc_link(const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, uint32_t *prev, const uint32_t *summary,
                      const uint32_t *flist, const uint32_t *fcount, hipStream_t st);
-void launch_enc_cand(const uint8_t *src, const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, const uint2 *prev, uint2 *rec,
+void launch_enc_cand(const uint8_t *src, const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, const uint32_t *prev, uint2 *rec,
                      uint64_t *bitmap, hipStream_t st);
 
 // encode_parse.hip
-void launch_enc_spec(const uint8_t *src, const EncStream *streams, const uint2 *segs, uint32_t n_segs, const uint2 *prev,
+void launch_enc_spec(const uint8_t *src, const EncStream *streams, const uint2 *segs, uint32_t n_segs, const uint32_t *prev,
                      const uint2 *rec, const uint64_t *bitmap, SpecEvent *logs, SpecHeader *hdrs, hipStream_t st);
-void launch_enc_stitch(const uint8_t *src, const EncStream *streams, uint32_t ns, const uint2 *segs, uint32_t n_segs, const uint2 *prev,
+void launch_enc_stitch(const uint8_t *src, const EncStream *streams, uint32_t ns, const uint2 *segs, uint32_t n_segs, const uint32_t *prev,
                        const uint2 *rec, const uint64_t *bitmap, const SpecEvent *logs, const SpecHeader *hdrs, uint4 *sync,
                        RangeRec *ranges, MatchRec *gaps, EncStreamOut *outs, hipStream_t st);
 void launch_enc_compact(const EncStream *streams, const uint32_t *slot_stream, uint32_t n_slots, uint32_t ns, const EncStreamOut *outs,

@@ -5,7 +5,7 @@
 // position i is a pure function of src[0..i+3] because every position is inserted exactly once,
 // in order (frontend_bytes.rs:187,336-344). That makes the expensive part position-parallel:
 //
-//   enc_chain_kernel   per 64 Ki-position tile: prev[i] = previous position in the same bucket
+//   enc_chain_kernel   per 64 Ki-position tile: link[i] = distance to the previous position in the same bucket
 //                      (history.rs:221-224 hash, fse/object.rs:38-43), exact, in-order, with a
 //                      16 384-entry last-seen table in LDS and ballot matching inside a wave
 //   enc_link_kernel    first occurrences of a tile: link to earlier tiles (window 262 139)
@@ -27,7 +27,7 @@ namespace lzmi {
 // or the LDS last-seen entry written by earlier steps.
 __global__ __launch_bounds__(64) void enc_chain_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
                                                        const EncTile *__restrict__ tiles, uint32_t n_tiles,
-                                                       uint2 *__restrict__ prev, uint32_t *__restrict__ summary,
+                                                       uint32_t *__restrict__ prev, uint32_t *__restrict__ summary,
                                                        uint32_t *__restrict__ flist, uint32_t *__restrict__ fcount) {
     __shared__ uint16_t last[1u << HASH_BITS];  // offset in tile + 1, 0 = none
     const uint32_t t = blockIdx.x;
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(64) void enc_chain_kernel(const uint8_t *__restrict
     const int lane = e_lane();
     for (uint32_t k = lane; k < (1u << HASH_BITS); k += 64) last[k] = 0;
     const uint8_t *s = src + st.src_off;
-    uint2 *pv = prev + st.pos_base;  // {previous position in the bucket, 4-byte value at this position}
+    uint32_t *pv = prev + st.pos_base;  // link records (enc_common.h): distance to the previous position of the bucket | check bits
     const uint32_t n_pos = st.n - 3;  // positions 0 .. n-4 are hashed (frontend_bytes.rs:166-170)
     const uint32_t t_end = tl.start + TILE_POS < n_pos ? tl.start + TILE_POS : n_pos;
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(64) void enc_chain_kernel(const uint8_t *__restrict
                 if (first) fl[n_first + (uint32_t)__popcll(fm & lt_mask)] = (p - tl.start) | (key << 16);
                 n_first += (uint32_t)__popcll(fm);
             }
-            if (valid) pv[p] = make_uint2(pr, v);
+            if (valid) pv[p] = link_make((pr == NONE || pr == NONE_TILE) ? 0u : p - pr, v);  // (inside a tile: < 65 536)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64) void enc_chain_kernel(const uint8_t *__restrict
 // occurrence in an earlier tile of the same stream. Anything further back than 5 tiles is outside the
 // 262 139-byte window (fse/constants.rs:42) and would end the candidate scan anyway.
 __global__ void enc_link_kernel(const EncStream *__restrict__ streams, const EncTile *__restrict__ tiles, uint32_t n_tiles,
-                                uint2 *__restrict__ prev, const uint32_t *__restrict__ summary,
+                                uint32_t *__restrict__ prev, const uint32_t *__restrict__ summary,
                                 const uint32_t *__restrict__ flist, const uint32_t *__restrict__ fcount) {
     constexpr uint32_t BPT = (1u << HASH_BITS) / 256;  // workgroups per tile
     const uint32_t t = blockIdx.x / BPT;
@@ -126,7 +126,7 @@ __global__ void enc_link_kernel(const EncStream *__restrict__ streams, const Enc
         uint32_t sv = summary[(uint64_t)(t - back) * (1u << HASH_BITS) + key];
         if (sv != NONE) { r = sv; break; }
     }
-    prev[st.pos_base + p].x = r;
+    if (r != NONE && p - r <= MAX_D_VALUE) prev[st.pos_base + p] |= p - r;   // (the chain kernel left distance 0 here)
 }
 
 // ------------------------------------------------------------------------------------ candidates
@@ -154,12 +154,12 @@ __device__ __forceinline__ uint32_t lcp_fwd(const uint8_t *s, uint32_t a, uint32
 // that are still equal there are grouped into runs of consecutive positions with the same distance
 // (the inside of one long match): only the head of a run is extended, by the whole wave, and the
 // followers derive LCP(i + t, c + t) = LCP(i, c) - t. Repetitive data costs O(1) per position.
-constexpr uint32_t CAND_C1 = 20;   // a lane compares 4 + 16 bytes on its own (one step); measured best of 20 / 36 / 64
+constexpr uint32_t CAND_C1 = 16;   // a lane compares 16 bytes on its own (one step, from byte 0); measured best of 16..64
 constexpr int CAND_GL = 8;  // lanes per group of the long-match work list
 constexpr uint32_t CAND_BPT = (TILE_POS + 255) / 256;  // workgroups per tile
 
 __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
-                                                       const EncTile *__restrict__ tiles, uint32_t n_tiles, const uint2 *__restrict__ prev,
+                                                       const EncTile *__restrict__ tiles, uint32_t n_tiles, const uint32_t *__restrict__ prev,
                                                        uint2 *__restrict__ rec, uint64_t *__restrict__ bitmap) {
     // Workgroups are handed to the 8 XCDs round-robin. All workgroups of one tile go to the same XCD, so the
     // link records and source bytes a tile gathers from (its own 0.5 MB + the 2 MB window before it) stay in
@@ -178,10 +178,9 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
     if (tl.start + bx * blockDim.x >= n_pos) return;  // block-uniform
     const bool valid = i < n_pos && i < tl.start + TILE_POS;
     const uint8_t *s = src + st.src_off;
-    const uint2 *pv = prev + st.pos_base;
+    const uint32_t *pv = prev + st.pos_base;
     const int lane = e_lane();
-    const uint2 self = valid ? pv[i] : make_uint2(NONE, 0);
-    const uint32_t v = self.y;
+    const uint32_t self = valid ? pv[i] : 0u;
     const uint32_t max_total = valid ? n - i : 0;
     const uint32_t cap_total = max_total < FCAP ? max_total : FCAP;
     const uint32_t c1 = cap_total < CAND_C1 ? cap_total : CAND_C1;
@@ -203,20 +202,23 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
         __builtin_amdgcn_wave_barrier();
     }
     const uint32_t *win = s_win[threadIdx.x >> 6];
-    // ---- phase 1: follow the chain (<= 4 dependent 8-byte gathers: next link + value) ----
+    // ---- phase 1: follow the chain (<= 4 dependent 4-byte gathers: a link record holds the distance to the next entry and
+    // 14 check bits of the entry's own 4 bytes). Equal check bits = candidate; the byte compare starts at byte 0, so the
+    // rare entry whose check bits agree by chance (2^-14) is dropped there: history.rs Item.val == val, exactly. ----
     uint32_t cc[4] = {NONE, NONE, NONE, NONE};
     uint32_t ln[4] = {0, 0, 0, 0};
     {
         bool alive = valid;
-        uint32_t c = self.x;
+        uint32_t c = i, rc = self;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             if (alive) {
-                if (c == NONE || i - c > MAX_D_VALUE) alive = false;  // frontend_bytes.rs:222-224: stop, not skip
+                const uint32_t d = link_dist(rc);
+                if (d == 0 || i - (c - d) > MAX_D_VALUE) alive = false;  // frontend_bytes.rs:222-224: stop, not skip
                 else {
-                    const uint2 rc = pv[c];
-                    if (rc.y == v) { cc[q] = c; ln[q] = 4; }
-                    c = rc.x;
+                    c -= d;
+                    rc = pv[c];
+                    if (link_chk(rc) == link_chk(self)) { cc[q] = c; ln[q] = 4; }   // (4: provisional until step 0 has looked)
                 }
             }
         }
@@ -226,7 +228,9 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
     // followers derive their length from the head's. The kernel is bound by the number of cache lines its
     // divergent loads touch, and on compressible data most equal candidates are followers. ----
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
-    bool fol[4];
+    bool fol[4], prov[4];   // prov: candidate by its check bits (before the bytes were looked at)
+#pragma unroll
+    for (int k = 0; k < 4; k++) prov[k] = ln[k] != 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint32_t dk = ln[k] ? i - cc[k] : NONE;
@@ -238,9 +242,9 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
     {
         bool act[4], tail[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) { act[k] = ln[k] != 0 && !fol[k] && c1 > 4; tail[k] = false; }
+        for (int k = 0; k < 4; k++) { act[k] = ln[k] != 0 && !fol[k]; tail[k] = false; }
 #pragma unroll 1
-        for (uint32_t off = 4; off < CAND_C1; off += 16) {
+        for (uint32_t off = 0; off < CAND_C1; off += 16) {
             if (!__any(act[0] || act[1] || act[2] || act[3])) break;
             // All five loads of a step are issued before the first use: each sits alone in its branch (idle
             // lanes issue nothing) and the lengths are updated without branches afterwards. A load next to its
@@ -271,6 +275,7 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
                 uint32_t nl = off + m;
                 const bool stop = m < 16 || nl >= c1;
                 nl = nl < c1 ? nl : c1;
+                if (nl < 4) nl = 0;   // the entry's 4 bytes differ: its check bits agreed by chance
                 tail[k] = tail[k] || (act[k] && !room);
                 ln[k] = go[k] ? nl : ln[k];
                 act[k] = go[k] && !stop;
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
         }
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            if (tail[k]) ln[k] = lcp_fwd(s, i, cc[k], ln[k], c1);  // within 80 bytes of the stream's end
+            if (tail[k]) { const uint32_t m = lcp_fwd(s, i, cc[k], 0, c1); ln[k] = m >= 4 ? m : 0u; }  // within 16 bytes of the stream's end
     }
     // ---- phase 3: heads still equal after CAND_C1 bytes go to a per-wave work list and are extended by groups
     // of CAND_GL lanes, 16 bytes per lane and step, several heads at a time (up to FCAP + 64, so that 63
@@ -398,13 +403,19 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
     for (int k = 0; k < 4; k++) {
         uint32_t len = ln[k];
         const uint32_t c = cc[k];
-        const bool head = len != 0 && !fol[k];
+        const bool head = prov[k] && !fol[k];   // (a head whose check bits agreed by chance has len 0: its followers measure themselves)
         const uint64_t hm = __ballot(head);
         if (__any(fol[k])) {
             const uint64_t below = hm & lt_mask;
             const int h = below ? 63 - __builtin_clzll(below) : 0;
             const uint32_t hl = __shfl(len, h);
-            if (fol[k]) len = hl - (uint32_t)(lane - h);
+            // LCP(i + t, c + t) = LCP(i, c) - t holds while t < LCP(i, c). Every lane between the head and this one has
+            // equal check bits; should the head's turn out a chance hit (< 4 + t bytes), this lane measures for itself.
+            if (fol[k]) {
+                const uint32_t tt = (uint32_t)(lane - h);
+                if (hl >= tt + 4) len = hl - tt;
+                else { const uint32_t m = lcp_fwd(s, i, c, 0, cap_total); len = m >= 4 ? m : 0u; }
+            }
         }
         if (len) {
             if (len > cap_total) len = cap_total;
@@ -458,20 +469,20 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
 
 // ------------------------------------------------------------------------------------ launchers
 
-void launch_enc_chain(const uint8_t *src, const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, uint2 *prev, uint32_t *summary,
+void launch_enc_chain(const uint8_t *src, const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, uint32_t *prev, uint32_t *summary,
                       uint32_t *flist, uint32_t *fcount, hipStream_t st) {
     if (!n_tiles) return;
     hipLaunchKernelGGL(enc_chain_kernel, dim3(n_tiles), dim3(64), 0, st, src, streams, tiles, n_tiles, prev, summary, flist, fcount);
 }
 
-void launch_enc_link(const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, uint2 *prev, const uint32_t *summary,
+void launch_enc_link(const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, uint32_t *prev, const uint32_t *summary,
                      const uint32_t *flist, const uint32_t *fcount, hipStream_t st) {
     if (!n_tiles) return;
     hipLaunchKernelGGL(enc_link_kernel, dim3(n_tiles * ((1u << HASH_BITS) / 256)), dim3(256), 0, st, streams, tiles, n_tiles, prev, summary, flist,
                        fcount);
 }
 
-void launch_enc_cand(const uint8_t *src, const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, const uint2 *prev, uint2 *rec,
+void launch_enc_cand(const uint8_t *src, const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, const uint32_t *prev, uint2 *rec,
                      uint64_t *bitmap, hipStream_t st) {
     if (!n_tiles) return;
     hipLaunchKernelGGL(enc_cand_kernel, dim3(((n_tiles + 7) / 8) * 8 * CAND_BPT), dim3(256), 0, st, src, streams, tiles, n_tiles, prev, rec, bitmap);

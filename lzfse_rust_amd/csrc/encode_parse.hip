@@ -141,7 +141,7 @@ __device__ uint32_t st_wave_lcs_bwd(const uint8_t *s, uint32_t a, uint32_t b, ui
 // record is capped can have its exact lengths computed by the whole wave (one request at a time).
 __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
                                                       const uint2 *__restrict__ segs, uint32_t n_segs,
-                                                      const uint2 *__restrict__ prev, const uint2 *__restrict__ rec,
+                                                      const uint32_t *__restrict__ prev, const uint2 *__restrict__ rec,
                                                       const uint64_t *__restrict__ bitmap, SpecEvent *__restrict__ logs,
                                                       SpecHeader *__restrict__ hdrs) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -197,21 +197,21 @@ __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict_
             const uint32_t q_stream = e_readlane(sg.x, L), q_p = e_readlane(p, L);
             const EncStream &qs = streams[q_stream];
             const uint8_t *s = src + qs.src_off;
-            const uint2 *pv = prev + qs.pos_base;
+            const uint32_t *pv = prev + qs.pos_base;
             const uint32_t maxl = qs.n - q_p;
             const uint32_t lim = maxl < XCAP ? maxl : XCAP;
-            const uint2 self = pv[q_p];
-            uint32_t best_len = 0, best_idx = 0, c = self.x;
+            const uint32_t v = ld_u32(s + q_p);
+            uint32_t best_len = 0, best_idx = 0, c = q_p, d = link_dist(pv[q_p]);
             bool over = false;
-            for (int q = 0; q < 4 && c != NONE; q++) {  // frontend_bytes.rs:214-231
+            for (int q = 0; q < 4 && d != 0; q++) {  // frontend_bytes.rs:214-231
+                c -= d;
                 if (q_p - c > MAX_D_VALUE) break;
-                const uint2 rc = pv[c];
-                if (rc.y == self.y) {
+                if (ld_u32(s + c) == v) {
                     uint32_t len = st_wave_lcp_fwd(s, q_p, c, 4, lim);
                     if (len == lim && lim < maxl) over = true;
                     if (len > best_len) { best_len = len; best_idx = c; }
                 }
-                c = rc.x;
+                d = link_dist(pv[c]);
             }
             const uint32_t bl = st_wave_lcs_bwd(s, q_p, best_idx, best_idx < BCAP ? best_idx : BCAP);
             if (lane == L) {
@@ -343,7 +343,7 @@ __device__ __forceinline__ void sx_gap_event(Stitch &x, uint32_t lit_before, uin
 
 // One wave per stream; control flow and values are wave-uniform.
 __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
-                                                        uint32_t n_streams, const uint2 *__restrict__ prev,
+                                                        uint32_t n_streams, const uint32_t *__restrict__ prev,
                                                         const uint2 *__restrict__ rec, const uint64_t *__restrict__ bitmap,
                                                         const SpecEvent *__restrict__ logs, const SpecHeader *__restrict__ hdrs,
                                                         const uint4 *__restrict__ sync, RangeRec *__restrict__ ranges,
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
     if (si >= n_streams) return;
     const EncStream &es = streams[si];
     const uint8_t *s = src + es.src_off;
-    const uint2 *pv = prev + es.pos_base;
+    const uint32_t *pv = prev + es.pos_base;
     const uint2 *r = rec + es.pos_base;
     const uint64_t *bm = bitmap + (es.pos_base >> 6);
     const uint32_t n = es.n, end = n - 3, K = es.n_seg;
@@ -439,14 +439,15 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
         uint32_t midx = p - dist;
         if (rr.x & REC_CAPPED) {
             // exact forward part of find_match (frontend_bytes.rs:214-231) by the whole wave
-            uint32_t v = ld_u32(s + p), best_len = 0, best_idx = 0, c = pv[p].x;
-            for (int q = 0; q < 4 && c != NONE; q++) {
+            uint32_t v = ld_u32(s + p), best_len = 0, best_idx = 0, c = p, d = link_dist(pv[p]);
+            for (int q = 0; q < 4 && d != 0; q++) {
+                c -= d;
                 if (p - c > MAX_D_VALUE) break;
                 if (ld_u32(s + c) == v) {
                     uint32_t len = st_wave_lcp_fwd(s, p, c, 4, n - p);
                     if (len > best_len) { best_len = len; best_idx = c; }
                 }
-                c = pv[c].x;
+                d = link_dist(pv[c]);
             }
             fwd = best_len; midx = best_idx; dist = p - midx;
             bw = st_wave_lcs_bwd(s, p, midx, midx < BCAP ? midx : BCAP);
@@ -823,13 +824,13 @@ __global__ __launch_bounds__(256) void enc_lmd_kernel(const EncStream *__restric
 
 // ------------------------------------------------------------------------------------ launchers
 
-void launch_enc_spec(const uint8_t *src, const EncStream *streams, const uint2 *segs, uint32_t n_segs, const uint2 *prev,
+void launch_enc_spec(const uint8_t *src, const EncStream *streams, const uint2 *segs, uint32_t n_segs, const uint32_t *prev,
                      const uint2 *rec, const uint64_t *bitmap, SpecEvent *logs, SpecHeader *hdrs, hipStream_t st) {
     if (!n_segs) return;
     hipLaunchKernelGGL(enc_spec_kernel, dim3((n_segs + 63) / 64), dim3(64), 0, st, src, streams, segs, n_segs, prev, rec, bitmap, logs,
                        hdrs);
 }
-void launch_enc_stitch(const uint8_t *src, const EncStream *streams, uint32_t ns, const uint2 *segs, uint32_t n_segs, const uint2 *prev,
+void launch_enc_stitch(const uint8_t *src, const EncStream *streams, uint32_t ns, const uint2 *segs, uint32_t n_segs, const uint32_t *prev,
                        const uint2 *rec, const uint64_t *bitmap, const SpecEvent *logs, const SpecHeader *hdrs, uint4 *sync,
                        RangeRec *ranges, MatchRec *gaps, EncStreamOut *outs, hipStream_t st) {
     hipLaunchKernelGGL(enc_sync_kernel, dim3((n_segs + 63) / 64), dim3(64), 0, st, streams, segs, n_segs, logs, hdrs, sync);

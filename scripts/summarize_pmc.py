@@ -2,7 +2,8 @@
 FETCH_SIZE / WRITE_SIZE are in KiB (MI355X_MICROARCH.md, HBM section); on gfx950 FETCH_SIZE reads one half
 of the bytes of wide (16 B/lane) coalesced streaming reads - both the raw and the x2-corrected read
 figure are kept, the corrected one only applies to streaming kernels."""
-import csv, glob, json, sys, collections
+import csv, glob, json, os, sys, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def collect(d, counter):
     out = collections.defaultdict(lambda: [0.0, 0])
@@ -22,7 +23,11 @@ for k in sorted(set(fetch) | set(write)):
     f = fetch.get(k, (0, 0)); w = write.get(k, (0, 0))
     res[k] = {"launches": max(f[1], w[1]), "fetch_bytes_raw": f[0] * 1024, "fetch_bytes_x2": f[0] * 2048,
               "write_bytes": w[0] * 1024, "hbm_bytes_raw": (f[0] + w[0]) * 1024}
-json.dump(res, open(sys.argv[3], 'w'), indent=1)
+import bench
+# stamped with the identity of the kernel sources it was taken on: bench.py reports roofline.traffic only for these
+json.dump({"source_sha": bench.kernel_source_sha(), "command": "python bench.py --steps 2 --warmup 1 (default workload: snappy x 256)",
+           "units": "bytes per launch, averaged over the launches of the run; FETCH_SIZE / WRITE_SIZE KiB -> bytes, raw",
+           "kernels": res}, open(sys.argv[3], 'w'), indent=1)
 for k, v in res.items():
     if k.startswith(('enc_', 'dec_')):
         print(f"{k:28s} launches {v['launches']:4d} fetch {v['fetch_bytes_raw']/1e6:9.1f} MB write {v['write_bytes']/1e6:9.1f} MB")

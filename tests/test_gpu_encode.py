@@ -24,11 +24,13 @@ def gpu_candidates(ctx, raw):
     f.restype = C.c_int
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     a = np.frombuffer(raw, dtype=np.uint8)
-    prev = np.zeros((a.size - 3, 2), dtype=np.uint32)  # {prev, value} pairs
+    link = np.zeros(a.size - 3, dtype=np.uint32)  # link records: distance (18 bits) | check bits
     rec = np.zeros((a.size - 3, 2), dtype=np.uint32)
-    st = f(ctx._h, a.ctypes.data, a.size, prev.ctypes.data, rec.ctypes.data)
+    st = f(ctx._h, a.ctypes.data, a.size, link.ctypes.data, rec.ctypes.data)
     assert st == 0
-    return prev[:, 0], rec
+    dist = (link & 0x3FFFF).astype(np.int64)
+    prev = np.where(dist != 0, np.arange(a.size - 3, dtype=np.int64) - dist, -1)
+    return prev, rec
 
 
 def synth_cases():
@@ -70,6 +72,7 @@ def test_candidate_stage_matches_oracle(diag_ctx, oracle, snappy_raw):
         # prev[i] = newest entry of the row, as long as it lies within the 5-tile link horizon (beyond the match window)
         near = (want[:, 0] != 0xFFFFFFFF) & (np.arange(n, dtype=np.int64) - want[:, 0].astype(np.int64) <= 262139)
         assert (prev[near] == want[near, 0]).all(), name
+        assert (prev[~near] == -1).all(), name   # nothing, or nothing within the window
         idx = np.arange(n, dtype=np.int64)
         fwd = rec[:, 1]
         dist = rec[:, 0] & 0x3FFFF
