@@ -154,7 +154,7 @@ __device__ __forceinline__ uint32_t lcp_fwd(const uint8_t *s, uint32_t a, uint32
 // that are still equal there are grouped into runs of consecutive positions with the same distance
 // (the inside of one long match): only the head of a run is extended, by the whole wave, and the
 // followers derive LCP(i + t, c + t) = LCP(i, c) - t. Repetitive data costs O(1) per position.
-constexpr uint32_t CAND_C1 = 16;   // a lane compares 16 bytes on its own (one step, from byte 0); measured best of 16..64
+constexpr uint32_t CAND_C1 = 12;   // a lane compares 12 bytes on its own: what one dword-aligned 16-byte load holds of a candidate
 constexpr int CAND_GL = 8;  // lanes per group of the long-match work list
 constexpr uint32_t CAND_BPT = (TILE_POS + 255) / 256;  // workgroups per tile
 
@@ -237,49 +237,36 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
         const uint32_t dlo = __shfl_up(dk, 1);
         fol[k] = ln[k] != 0 && lane > 0 && dlo == dk;
     }
-    // ---- phase 2: forward lengths of all heads together, 16 bytes per candidate and step, so the loads of a
-    // step are in flight at the same time ----
+    // ---- phase 2: the first CAND_C1 bytes of all heads together. A candidate's bytes come from ONE dword-aligned 16-byte
+    // load (the 16 bytes from c & ~3 hold s[c .. c + 12] at any byte offset) shifted into place: a byte-misaligned vector
+    // load costs the texture addresser about four times the cycles of an aligned one, and the addresser is what bounds
+    // this kernel (TA_BUSY 77 %). The loads of the four slots are in flight at the same time. ----
     {
-        bool act[4], tail[4];
+        bool tail[4], go[4];
+        const bool room = 16 <= max_total;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { act[k] = ln[k] != 0 && !fol[k]; tail[k] = false; }
-#pragma unroll 1
-        for (uint32_t off = 0; off < CAND_C1; off += 16) {
-            if (!__any(act[0] || act[1] || act[2] || act[3])) break;
-            // All five loads of a step are issued before the first use: each sits alone in its branch (idle
-            // lanes issue nothing) and the lengths are updated without branches afterwards. A load next to its
-            // use inside a branch would be waited for there, one candidate after the other.
-            const bool room = off + 16 <= max_total;
-            bool go[4];
+        for (int k = 0; k < 4; k++) { const bool act = ln[k] != 0 && !fol[k]; go[k] = act && room; tail[k] = act && !room; }
+        const uint4 zero4 = make_uint4(0, 0, 0, 0);
+        uint4 bq[4] = {zero4, zero4, zero4, zero4};
+        uint32_t a0 = 0, a1 = 0, a2 = 0;
+        if (go[0] || go[1] || go[2] || go[3]) {
+            const uint32_t wo = 32u + (uint32_t)lane, q = wo >> 2, sh = (wo & 3) * 8;
+            const uint32_t d0 = win[q], d1 = win[q + 1], d2 = win[q + 2], d3 = win[q + 3];
+            a0 = __builtin_amdgcn_alignbit(d1, d0, sh); a1 = __builtin_amdgcn_alignbit(d2, d1, sh); a2 = __builtin_amdgcn_alignbit(d3, d2, sh);
+        }
 #pragma unroll
-            for (int k = 0; k < 4; k++) go[k] = act[k] && room;
-            const uint4 zero4 = make_uint4(0, 0, 0, 0);
-            uint4 a = zero4, bq[4] = {zero4, zero4, zero4, zero4};
-            if (go[0] || go[1] || go[2] || go[3]) {
-                const uint32_t wo = 32u + (uint32_t)lane + off, q = wo >> 2, sh = (wo & 3) * 8;  // wo + 16 <= 32 + 63 + 52 + 16 < 192
-                const uint32_t d0 = win[q], d1 = win[q + 1], d2 = win[q + 2], d3 = win[q + 3], d4 = win[q + 4];
-                a = make_uint4(__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh),
-                               __builtin_amdgcn_alignbit(d3, d2, sh), __builtin_amdgcn_alignbit(d4, d3, sh));
-            }
+        for (int k = 0; k < 4; k++)
+            if (go[k]) bq[k] = *reinterpret_cast<const uint4 *>((uintptr_t)(s + cc[k]) & ~(uintptr_t)3);
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (go[k]) bq[k] = ld_u128(s + cc[k] + off);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint64_t lo = ((uint64_t)(a.y ^ bq[k].y) << 32) | (a.x ^ bq[k].x);
-                const uint64_t hi = ((uint64_t)(a.w ^ bq[k].w) << 32) | (a.z ^ bq[k].z);
-                // both halves are always consumed, so that neither load can be deferred into a branch
-                const uint32_t mlo = lo ? (uint32_t)(__builtin_ctzll(lo | (1ull << 63)) >> 3) : 16u;
-                const uint32_t mhi = hi ? 8 + (uint32_t)(__builtin_ctzll(hi | (1ull << 63)) >> 3) : 16u;
-                const uint32_t m = mlo < mhi ? mlo : mhi;
-                uint32_t nl = off + m;
-                const bool stop = m < 16 || nl >= c1;
-                nl = nl < c1 ? nl : c1;
-                if (nl < 4) nl = 0;   // the entry's 4 bytes differ: its check bits agreed by chance
-                tail[k] = tail[k] || (act[k] && !room);
-                ln[k] = go[k] ? nl : ln[k];
-                act[k] = go[k] && !stop;
-            }
+        for (int k = 0; k < 4; k++) {
+            const uint32_t sh = ((uint32_t)(uintptr_t)(s + cc[k]) & 3u) * 8;
+            const uint32_t x0 = a0 ^ __builtin_amdgcn_alignbit(bq[k].y, bq[k].x, sh);
+            const uint32_t x1 = a1 ^ __builtin_amdgcn_alignbit(bq[k].z, bq[k].y, sh);
+            const uint32_t x2 = a2 ^ __builtin_amdgcn_alignbit(bq[k].w, bq[k].z, sh);
+            const uint32_t m2 = x2 ? 8u + ((uint32_t)__builtin_ctz(x2) >> 3) : 12u;
+            const uint32_t m1 = x1 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3) : m2;
+            const uint32_t m = x0 ? 0u : m1;   // the entry's 4 bytes differ: its check bits agreed by chance
+            ln[k] = go[k] ? (m < c1 ? m : c1) : ln[k];
         }
 #pragma unroll
         for (int k = 0; k < 4; k++)
