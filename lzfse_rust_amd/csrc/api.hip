@@ -134,7 +134,7 @@ struct lzfse_mi_ctx {
     // lzfse_mi_set_option
     int opt_lanes_enc = 0, opt_lanes_dec = 0;  // sub-batches run side by side (0: chosen by size, 1: one)
     int opt_stagger = 1;
-    int diag_lz_jump = -1, diag_lz_variant = -1, diag_stats = 0;  // diagnostic build only
+    int diag_lz_jump = -1, diag_lz_variant = -1, diag_stats = 0, diag_chain = 0;  // diagnostic build only
 
     hipEvent_t get_event() {
         if (ev_used == ev_pool.size()) {
@@ -164,6 +164,7 @@ EncScratch &ctx_enc(lzfse_mi_ctx *c) { return c->enc; }
 LaneGate *ctx_gate_in(lzfse_mi_ctx *c) { return c->gate_in; }
 LaneGate *ctx_gate_out(lzfse_mi_ctx *c) { return c->gate_out; }
 int ctx_diag_stats(lzfse_mi_ctx *c) { return c->diag_stats; }
+int ctx_diag_chain(lzfse_mi_ctx *c) { return c->diag_chain; }
 }  // namespace lzmi
 
 static void timing_begin(lzfse_mi_ctx *c) {
@@ -647,7 +648,7 @@ static int split_batch(lzfse_mi_ctx *c, batch_dev_fn one, int lanes, bool stagge
         ok = hipStreamWaitEvent(c->shadow[k]->stream, c->split_ev, 0) == hipSuccess;
         c->shadow[k]->timing = c->timing;
         c->shadow[k]->diag_lz_jump = c->diag_lz_jump; c->shadow[k]->diag_lz_variant = c->diag_lz_variant;
-        c->shadow[k]->diag_stats = c->diag_stats;
+        c->shadow[k]->diag_stats = c->diag_stats; c->shadow[k]->diag_chain = c->diag_chain;
     }
     if (!ok) return unsplit();
     // staggered start (encode): lane k + 1 begins when lane k has queued its candidate kernel
@@ -724,10 +725,12 @@ int lzfse_mi_set_option(lzfse_mi_ctx *c, int option, int64_t value) {
     case LZFSE_MI_OPT_DIAG_LZ_PATH: c->diag_lz_jump = (int)value; return LZFSE_MI_OK;
     case LZFSE_MI_OPT_DIAG_LZ_TILE: c->diag_lz_variant = (int)value; return LZFSE_MI_OK;
     case LZFSE_MI_OPT_DIAG_STATS: c->diag_stats = (int)value; return LZFSE_MI_OK;
+    case LZFSE_MI_OPT_DIAG_CHAIN: c->diag_chain = (int)value; return LZFSE_MI_OK;
 #else
     case LZFSE_MI_OPT_DIAG_LZ_PATH:
     case LZFSE_MI_OPT_DIAG_LZ_TILE:
-    case LZFSE_MI_OPT_DIAG_STATS: return LZFSE_MI_UNSUPPORTED;
+    case LZFSE_MI_OPT_DIAG_STATS:
+    case LZFSE_MI_OPT_DIAG_CHAIN: return LZFSE_MI_UNSUPPORTED;
 #endif
     default: return LZFSE_MI_BAD_ARGUMENT;
     }

@@ -20,11 +20,15 @@ __device__ __forceinline__ uint32_t e_readlane(uint32_t v, int l) { return (uint
 __device__ __forceinline__ uint32_t bucket_of(uint32_t v) { return (v * 0x9E3779B1u) >> (32 - HASH_BITS); }
 
 // Link record of a position (4 bytes): distance to the previous position of its bucket (18 bits: 0 = none within the
-// match window, fse/constants.rs:42) | 14 check bits of the position's own 4 bytes (a second hash: entries of one bucket
-// whose bytes differ agree in them with probability 2^-14; the byte compare, which starts at byte 0, settles it).
-__device__ __forceinline__ uint32_t link_make(uint32_t dist, uint32_t v) { return dist | (((v * 0x85EBCA6Bu) >> 18) << 18); }
+// match window, fse/constants.rs:42) | 14 check bits of THAT position's 4 bytes (a second hash: entries of one bucket
+// whose bytes differ agree in them with probability 2^-14; the byte compare, which starts at byte 0, settles it). The
+// record that names a candidate also says whether it can match, so a chain of 4 candidates costs 3 dependent gathers.
+__device__ __forceinline__ uint32_t chk_of(uint32_t v) { return (v * 0x85EBCA6Bu) >> 18; }
+__device__ __forceinline__ uint32_t link_make(uint32_t dist, uint32_t chk_prev) { return dist | (chk_prev << 18); }
 __device__ __forceinline__ uint32_t link_dist(uint32_t r) { return r & 0x3FFFFu; }
 __device__ __forceinline__ uint32_t link_chk(uint32_t r) { return r >> 18; }
+// Entry of a chain tile's last-seen table and of its summary: (offset in tile + 1) | check bits << 16; 0 = none
+__device__ __forceinline__ uint32_t seen_make(uint32_t off1, uint32_t v) { return off1 | (chk_of(v) << 16); }
 
 struct EncStream {       // one input stream (n > VN_CUTOFF) of the batch
     uint64_t src_off;    // offset of the stream in d_src
@@ -101,7 +105,7 @@ __host__ __device__ inline uint32_t stage_need(uint32_t n_lit, uint32_t n_lmd) {
 
 // encode_match.hip
 void launch_enc_chain(const uint8_t *src, const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, uint32_t *prev, uint32_t *summary,
-                      uint32_t *flist, uint32_t *fcount, hipStream_t st);
+                      uint32_t *flist, uint32_t *fcount, uint32_t *redo, bool force_redo, hipStream_t st);
 void launch_enc_link(const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, uint32_t *prev, const uint32_t *summary,
                      const uint32_t *flist, const uint32_t *fcount, hipStream_t st);
 void launch_enc_cand(const uint8_t *src, const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, const uint32_t *prev, uint2 *rec,

@@ -22,93 +22,163 @@ namespace lzmi {
 
 // ------------------------------------------------------------------------------------ chains
 
-// One wave per tile. Positions are processed in order, 64 per step; the nearest previous
-// position with the same bucket is either a lower lane of the same step (found with 14 ballots)
-// or the LDS last-seen entry written by earlier steps.
+// One wave per tile; positions in order, 64 per step. The last-seen table of the tile lives in LDS, one 32-bit entry
+// per bucket, and a step is ONE LDS exchange per lane: the entry a lane gets back is its predecessor in the bucket --
+// an earlier step's, or a lower lane's of the same step, because gfx950 serialises the lanes of one ds_wrxchg that hit
+// the same address in ascending lane order (measured; scripts/xchg_order.hip). That order is not architectural, so
+// every lane checks what it got (a predecessor must lie before it) and a tile that ever sees anything else is redone
+// by enc_chain_ballot_kernel, which assumes nothing. LDS operations of a wave execute in issue order, so the exchanges
+// of a batch of steps are issued back to back and the wave waits once per batch, not once per step.
 __global__ __launch_bounds__(64) void enc_chain_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
                                                        const EncTile *__restrict__ tiles, uint32_t n_tiles,
                                                        uint32_t *__restrict__ prev, uint32_t *__restrict__ summary,
-                                                       uint32_t *__restrict__ flist, uint32_t *__restrict__ fcount) {
-    __shared__ uint16_t last[1u << HASH_BITS];  // offset in tile + 1, 0 = none
+                                                       uint32_t *__restrict__ flist, uint32_t *__restrict__ fcount,
+                                                       uint32_t *__restrict__ redo, uint32_t force_redo) {
+    __shared__ uint32_t last[1u << HASH_BITS];  // seen_make(): (offset in tile + 1) | check bits << 16, 0 = none
     const uint32_t t = blockIdx.x;
     if (t >= n_tiles) return;
+    const int lane = e_lane();
+    if (force_redo) {   // (diagnostic build: every tile goes through the ballot kernel)
+        if (lane == 0) redo[t] = 1;
+        return;
+    }
+    const EncTile tl = tiles[t];
+    const EncStream st = streams[tl.stream];
+    for (uint32_t k = lane; k < (1u << HASH_BITS); k += 64) last[k] = 0;
+    const uint8_t *s = src + st.src_off;
+    uint32_t *pv = prev + st.pos_base;  // link records (enc_common.h)
+    const uint32_t n_pos = st.n - 3;  // positions 0 .. n-4 are hashed (frontend_bytes.rs:166-170)
+    const uint32_t t_end = tl.start + TILE_POS < n_pos ? tl.start + TILE_POS : n_pos;
+    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    uint32_t *fl = flist + (uint64_t)t * (1u << HASH_BITS);
+    uint32_t n_first = 0;
+    bool wrong = false;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // 16 steps (1024 positions) per batch; the source values of the next batch are loaded while this one runs. All loads
+    // are unconditional (addresses clamped to the tile's last position) and their values are consumed in straight-line
+    // code at the top of a batch: one wait per batch. (A load or a first use inside a divergent branch makes the
+    // compiler wait for ALL outstanding memory operations, the link stores included, at every later use.)
+    constexpr int CH_STEPS = 16;
+    uint32_t nx[CH_STEPS];
+    const uint32_t q_last = t_end - 1;
+#pragma unroll
+    for (int j = 0; j < CH_STEPS; j++) {
+        const uint32_t q = tl.start + 64 * j + lane;
+        nx[j] = ld_u32(s + (q < q_last ? q : q_last));
+    }
+    for (uint32_t pb = tl.start; pb < t_end; pb += 64 * CH_STEPS) {
+        uint32_t key[CH_STEPS], ent[CH_STEPS], old[CH_STEPS];
+#pragma unroll
+        for (int j = 0; j < CH_STEPS; j++) {
+            key[j] = bucket_of(nx[j]);
+            ent[j] = seen_make(pb - tl.start + 64 * j + lane + 1, nx[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < CH_STEPS; j++) {
+            const uint32_t q = pb + 64 * CH_STEPS + 64 * j + lane;
+            nx[j] = ld_u32(s + (q < q_last ? q : q_last));
+        }
+#pragma unroll
+        for (int j = 0; j < CH_STEPS; j++) {
+            old[j] = 0;
+            if (pb + 64 * j + lane < t_end)
+                old[j] = __hip_atomic_exchange(&last[key[j]], ent[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+#pragma unroll
+        for (int j = 0; j < CH_STEPS; j++) {
+            const uint32_t p0 = pb + 64 * j;
+            if (p0 >= t_end) continue;  // (not break: the loop must stay fully unrolled, the arrays live in registers)
+            const uint32_t p = p0 + lane;
+            const bool valid = p < t_end;
+            const uint32_t mine = p - tl.start + 1, o = old[j] & 0xFFFFu;
+            wrong = wrong || (valid && o >= mine);
+            // first occurrence of its bucket in the tile: the link into earlier tiles is made by enc_link_kernel
+            // from this list (offset | bucket << 16); the first tile of a stream has nothing before it
+            const bool first = valid && o == 0;
+            if (tl.start != 0) {
+                const uint64_t fm = __ballot(first);
+                if (first) fl[n_first + (uint32_t)__popcll(fm & lt_mask)] = (p - tl.start) | (key[j] << 16);
+                n_first += (uint32_t)__popcll(fm);
+            }
+            if (valid) pv[p] = o ? link_make(mine - o, old[j] >> 16) : 0u;  // (inside a tile: < 65 536)
+        }
+    }
+    if (lane == 0) { fcount[t] = n_first; redo[t] = 0; }
+    if (__any(wrong)) {
+        if (lane == 0) redo[t] = 1;
+        return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t *sm = summary + (uint64_t)t * (1u << HASH_BITS);
+    for (uint32_t k = lane; k < (1u << HASH_BITS); k += 64) sm[k] = last[k];
+}
+
+// The same links without any assumption about the LDS: the nearest previous position with the same bucket is either a
+// lower lane of the same step (found with 14 ballots) or the last-seen entry written by earlier steps. Runs only for
+// tiles enc_chain_kernel flagged (never, on the hardware measured); the diagnostic build can send every tile here.
+__global__ __launch_bounds__(64) void enc_chain_ballot_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
+                                                              const EncTile *__restrict__ tiles, uint32_t n_tiles,
+                                                              uint32_t *__restrict__ prev, uint32_t *__restrict__ summary,
+                                                              uint32_t *__restrict__ flist, uint32_t *__restrict__ fcount,
+                                                              const uint32_t *__restrict__ redo) {
+    __shared__ uint16_t last[1u << HASH_BITS];  // offset in tile + 1, 0 = none
+    const uint32_t t = blockIdx.x;
+    if (t >= n_tiles || !redo[t]) return;
     const EncTile tl = tiles[t];
     const EncStream st = streams[tl.stream];
     const int lane = e_lane();
     for (uint32_t k = lane; k < (1u << HASH_BITS); k += 64) last[k] = 0;
     const uint8_t *s = src + st.src_off;
-    uint32_t *pv = prev + st.pos_base;  // link records (enc_common.h): distance to the previous position of the bucket | check bits
-    const uint32_t n_pos = st.n - 3;  // positions 0 .. n-4 are hashed (frontend_bytes.rs:166-170)
+    uint32_t *pv = prev + st.pos_base;
+    const uint32_t n_pos = st.n - 3;
     const uint32_t t_end = tl.start + TILE_POS < n_pos ? tl.start + TILE_POS : n_pos;
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
     uint32_t *fl = flist + (uint64_t)t * (1u << HASH_BITS);
     uint32_t n_first = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // 16 steps (1024 positions) per batch: the source values of a batch are loaded together, so the wave
-    // waits for memory once per batch instead of once per step (a wait also drains the link stores)
-    constexpr int CH_STEPS = 16;
-    for (uint32_t pb = tl.start; pb < t_end; pb += 64 * CH_STEPS) {
-        uint32_t vv[CH_STEPS];
+    for (uint32_t p0 = tl.start; p0 < t_end; p0 += 64) {
+        const uint32_t p = p0 + lane;
+        const bool valid = p < t_end;
+        const uint32_t v = valid ? ld_u32(s + p) : 0u;
+        const uint32_t key = bucket_of(v);
+        const uint32_t old = last[key];
+        const uint32_t mine = p - tl.start + 1;
+        uint32_t pr = old ? (tl.start + old - 1) : NONE_TILE;
+        uint64_t same = __ballot(valid);
 #pragma unroll
-        for (int j = 0; j < CH_STEPS; j++) {
-            const uint32_t q = pb + 64 * j + lane;
-            vv[j] = q < t_end ? ld_u32(s + q) : 0u;
+        for (int b = 0; b < (int)HASH_BITS; b++) {
+            uint64_t bb = __ballot((key >> b) & 1);
+            same &= ((key >> b) & 1) ? bb : ~bb;
         }
-#pragma unroll
-        for (int j = 0; j < CH_STEPS; j++) {
-            const uint32_t p0 = pb + 64 * j;
-            if (p0 >= t_end) continue;  // (not break: the loop must stay fully unrolled, vv[] lives in registers)
-            const uint32_t p = p0 + lane;
-            const bool valid = p < t_end;
-            const uint32_t v = vv[j];
-            const uint32_t key = bucket_of(v);
-            const uint32_t old = last[key];
-            const uint32_t mine = p - tl.start + 1;
-            // fast path: every lane writes its own entry and reads it back; if all read their own value no
-            // two lanes of this step share a bucket and the entry read before the write is the link
-            if (valid) last[key] = (uint16_t)mine;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t chk = last[key];
-            uint32_t pr = old ? (tl.start + old - 1) : NONE_TILE;
-            if (__ballot(valid && chk != mine)) {
-                // some lanes collide: find the nearest lower lane with the same bucket by 14 ballots
-                uint64_t same = __ballot(valid);
-#pragma unroll
-                for (int b = 0; b < (int)HASH_BITS; b++) {
-                    uint64_t bb = __ballot((key >> b) & 1);
-                    same &= ((key >> b) & 1) ? bb : ~bb;
-                }
-                const uint64_t lower = same & lt_mask;
-                if (lower) pr = p0 + (63 - __builtin_clzll(lower));
-                if (valid && (same >> lane) >> 1 == 0) last[key] = (uint16_t)mine;  // newest of its bucket wins
-            }
-            // first occurrence of its bucket in the tile: the link into earlier tiles is made by enc_link_kernel
-            // from this list (offset | bucket << 16); the first tile of a stream has nothing before it
-            const bool first = valid && pr == NONE_TILE;
-            if (tl.start == 0) { if (first) pr = NONE; }
-            else {
-                const uint64_t fm = __ballot(first);
-                if (first) fl[n_first + (uint32_t)__popcll(fm & lt_mask)] = (p - tl.start) | (key << 16);
-                n_first += (uint32_t)__popcll(fm);
-            }
-            if (valid) pv[p] = link_make((pr == NONE || pr == NONE_TILE) ? 0u : p - pr, v);  // (inside a tile: < 65 536)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+        const uint64_t lower = same & lt_mask;
+        if (lower) pr = p0 + (63 - __builtin_clzll(lower));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (same >> lane) >> 1 == 0) last[key] = (uint16_t)mine;  // newest of its bucket wins
+        const bool first = valid && pr == NONE_TILE;
+        if (tl.start != 0) {
+            const uint64_t fm = __ballot(first);
+            if (first) fl[n_first + (uint32_t)__popcll(fm & lt_mask)] = (p - tl.start) | (key << 16);
+            n_first += (uint32_t)__popcll(fm);
         }
+        if (valid) pv[p] = pr == NONE_TILE ? 0u : link_make(p - pr, chk_of(ld_u32(s + pr)));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0) fcount[t] = n_first;
     uint32_t *sm = summary + (uint64_t)t * (1u << HASH_BITS);
     for (uint32_t k = lane; k < (1u << HASH_BITS); k += 64) {
-        uint32_t o = last[k];
-        sm[k] = o ? tl.start + o - 1 : NONE;
+        const uint32_t o = last[k];
+        sm[k] = o ? seen_make(o, ld_u32(s + tl.start + o - 1)) : 0u;
     }
 }
 
-// Cross-tile links: a bucket's first occurrence in a tile (listed by enc_chain_kernel) points at the newest
-// occurrence in an earlier tile of the same stream. Anything further back than 5 tiles is outside the
-// 262 139-byte window (fse/constants.rs:42) and would end the candidate scan anyway.
+// Cross-tile links: a bucket's first occurrence in a tile (listed by the chain kernel) points at the newest
+// occurrence in an earlier tile of the same stream, whose summary entry also holds its check bits. Anything further
+// back than 5 tiles is outside the 262 139-byte window (fse/constants.rs:42) and would end the candidate scan anyway.
 __global__ void enc_link_kernel(const EncStream *__restrict__ streams, const EncTile *__restrict__ tiles, uint32_t n_tiles,
                                 uint32_t *__restrict__ prev, const uint32_t *__restrict__ summary,
                                 const uint32_t *__restrict__ flist, const uint32_t *__restrict__ fcount) {
@@ -120,13 +190,15 @@ __global__ void enc_link_kernel(const EncStream *__restrict__ streams, const Enc
     const EncStream st = streams[tl.stream];
     const uint32_t ent = flist[(uint64_t)t * (1u << HASH_BITS) + e];
     const uint32_t p = tl.start + (ent & 0xFFFF), key = ent >> 16;
-    uint32_t r = NONE;
-    const uint32_t t_idx = tl.start / TILE_POS;  // tile index inside the stream
+    const uint32_t t_idx = tl.start / TILE_POS;  // tile index inside the stream (its tiles are consecutive)
     for (uint32_t back = 1; back <= 5 && back <= t_idx; back++) {
-        uint32_t sv = summary[(uint64_t)(t - back) * (1u << HASH_BITS) + key];
-        if (sv != NONE) { r = sv; break; }
+        const uint32_t sv = summary[(uint64_t)(t - back) * (1u << HASH_BITS) + key];
+        if (sv != 0) {
+            const uint32_t r = tl.start - back * TILE_POS + (sv & 0xFFFFu) - 1;
+            if (p - r <= MAX_D_VALUE) prev[st.pos_base + p] = link_make(p - r, sv >> 16);   // (the chain kernel left 0 here)
+            break;
+        }
     }
-    if (r != NONE && p - r <= MAX_D_VALUE) prev[st.pos_base + p] |= p - r;   // (the chain kernel left distance 0 here)
 }
 
 // ------------------------------------------------------------------------------------ candidates
@@ -202,12 +274,14 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
         __builtin_amdgcn_wave_barrier();
     }
     const uint32_t *win = s_win[threadIdx.x >> 6];
-    // ---- phase 1: follow the chain (<= 4 dependent 4-byte gathers: a link record holds the distance to the next entry and
-    // 14 check bits of the entry's own 4 bytes). Equal check bits = candidate; the byte compare starts at byte 0, so the
+    // ---- phase 1: follow the chain (<= 3 dependent 4-byte gathers: a link record holds the distance to the next entry and
+    // 14 check bits of THAT entry's 4 bytes). Equal check bits = candidate; the byte compare starts at byte 0, so the
     // rare entry whose check bits agree by chance (2^-14) is dropped there: history.rs Item.val == val, exactly. ----
     uint32_t cc[4] = {NONE, NONE, NONE, NONE};
     uint32_t ln[4] = {0, 0, 0, 0};
     {
+        const uint32_t wo = 32u + (uint32_t)lane, wq = wo >> 2;
+        const uint32_t my_chk = chk_of(__builtin_amdgcn_alignbit(win[wq + 1], win[wq], (wo & 3) * 8));
         bool alive = valid;
         uint32_t c = i, rc = self;
 #pragma unroll
@@ -217,8 +291,8 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
                 if (d == 0 || i - (c - d) > MAX_D_VALUE) alive = false;  // frontend_bytes.rs:222-224: stop, not skip
                 else {
                     c -= d;
-                    rc = pv[c];
-                    if (link_chk(rc) == link_chk(self)) { cc[q] = c; ln[q] = 4; }   // (4: provisional until step 0 has looked)
+                    if (link_chk(rc) == my_chk) { cc[q] = c; ln[q] = 4; }   // (4: provisional until phase 2 has looked)
+                    if (q < 3) rc = pv[c];
                 }
             }
         }
@@ -457,9 +531,11 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
 // ------------------------------------------------------------------------------------ launchers
 
 void launch_enc_chain(const uint8_t *src, const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, uint32_t *prev, uint32_t *summary,
-                      uint32_t *flist, uint32_t *fcount, hipStream_t st) {
+                      uint32_t *flist, uint32_t *fcount, uint32_t *redo, bool force_redo, hipStream_t st) {
     if (!n_tiles) return;
-    hipLaunchKernelGGL(enc_chain_kernel, dim3(n_tiles), dim3(64), 0, st, src, streams, tiles, n_tiles, prev, summary, flist, fcount);
+    hipLaunchKernelGGL(enc_chain_kernel, dim3(n_tiles), dim3(64), 0, st, src, streams, tiles, n_tiles, prev, summary, flist, fcount, redo,
+                       force_redo ? 1u : 0u);
+    hipLaunchKernelGGL(enc_chain_ballot_kernel, dim3(n_tiles), dim3(64), 0, st, src, streams, tiles, n_tiles, prev, summary, flist, fcount, redo);
 }
 
 void launch_enc_link(const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, uint32_t *prev, const uint32_t *summary,

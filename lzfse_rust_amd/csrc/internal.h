@@ -38,6 +38,7 @@ struct LaneGate {
 LaneGate *ctx_gate_in(lzfse_mi_ctx *c);
 LaneGate *ctx_gate_out(lzfse_mi_ctx *c);
 int ctx_diag_stats(lzfse_mi_ctx *c);  // LZFSE_MI_OPT_DIAG_STATS bits: 1 block encode, 2 parse, 4 LZ decode
+int ctx_diag_chain(lzfse_mi_ctx *c);  // LZFSE_MI_OPT_DIAG_CHAIN: 1 = every chain tile through the ballot kernel
 
 // ---- decode.hip ----
 void launch_dec_walk(bool emit, const uint8_t *src, const StreamIn *streams, uint32_t n_streams,

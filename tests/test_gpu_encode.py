@@ -103,6 +103,30 @@ def test_encode_bit_exact_synthetic(ctx, oracle):
         assert o.tobytes() == oracle.encode(cases[n]), n
 
 
+def test_chain_ballot_kernel_matches(diag_ctx, oracle, snappy_raw):
+    """The chain links are made by one LDS exchange per position, which relies on the measured (not architectural)
+    lane order of that instruction and checks itself; a tile that fails the check is redone by the ballot kernel. The
+    diagnostic build sends every tile there: same streams, same stage results."""
+    from oracle_py import seq_masked
+    cases = dict(synth_cases())
+    cases["tiles"] = (snappy_raw["lcet10.txt"] + seq_masked(3, 0x03030303, 200000)) * 5
+    for k in ("html", "urls.10K", "kppkn.gtb"):
+        cases[k] = snappy_raw[k]
+    names = list(cases)
+    diag_ctx.set_option("diag_chain", 1)
+    try:
+        outs, st = diag_ctx.encode_batch([cases[n] for n in names])
+        slow = {n: gpu_candidates(diag_ctx, cases[n]) for n in ("tiles", "text", "abc")}
+    finally:
+        diag_ctx.set_option("diag_chain", 0)
+    for n, o, e in zip(names, outs, st):
+        assert e == 0, (n, e)
+        assert o.tobytes() == oracle.encode(cases[n]), n
+    for n, (prev_s, rec_s) in slow.items():
+        prev_f, rec_f = gpu_candidates(diag_ctx, cases[n])
+        assert (prev_s == prev_f).all() and (rec_s == rec_f).all(), n
+
+
 def test_encode_zero_4097_kat(ctx):
     """The reference's only bvx2 byte-exact KAT (frontend_bytes.rs:513-531) through the GPU path."""
     from test_oracle import ZERO_4097
