@@ -747,7 +747,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     const uint32_t nt = (uint32_t)ht.size(), nseg = (uint32_t)hsegs.size();
 
     if (!eb_ensure(S, EB_STREAMS, ns * sizeof(EncStream)) || !eb_ensure(S, EB_TILES, nt * sizeof(EncTile)) ||
-        !eb_ensure(S, EB_PREV, pos_total * 4) || !eb_ensure(S, EB_SUMMARY, (size_t)nt * ((2u << HASH_BITS) + 2) * 4) ||
+        !eb_ensure(S, EB_PREV, pos_total * 4) || !eb_ensure(S, EB_SUMMARY, (size_t)nt * ((2u << HASH_BITS) + 64 + 2) * 4) ||
         !eb_ensure(S, EB_REC, pos_total * 8) || !eb_ensure(S, EB_LMDS, lmd_total * 8) ||
         !eb_ensure(S, EB_BLOCKS, (size_t)blk_total * sizeof(EncBlock)) || !eb_ensure(S, EB_OUTS, ns * sizeof(EncStreamOut)) ||
         !eb_ensure(S, EB_STAGE, stage_total + 256) || !eb_ensure(S, EB_SLOTS, (size_t)blk_total * 4) ||
@@ -764,7 +764,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     EncTile *d_tiles = (EncTile *)S.bufs[EB_TILES];
     uint32_t *d_prev = (uint32_t *)S.bufs[EB_PREV];
     uint32_t *d_summary = (uint32_t *)S.bufs[EB_SUMMARY];
-    uint32_t *d_flist = d_summary + (size_t)nt * (1u << HASH_BITS), *d_fcount = d_flist + (size_t)nt * (1u << HASH_BITS), *d_redo = d_fcount + nt;
+    uint32_t *d_flist = d_summary + (size_t)nt * (1u << HASH_BITS), *d_fcount = d_flist + (size_t)nt * ((1u << HASH_BITS) + 64), *d_redo = d_fcount + nt;
     uint2 *d_rec = (uint2 *)S.bufs[EB_REC];
     uint2 *d_lmds = (uint2 *)S.bufs[EB_LMDS];
     EncBlock *d_blocks = (EncBlock *)S.bufs[EB_BLOCKS];
@@ -880,7 +880,7 @@ extern "C" LZFSE_MI_API int lzfse_mi_debug_candidates(lzfse_mi_ctx *c, const uin
     const uint32_t nt = (uint32_t)ht.size();
     size_t padn = (n + 255) & ~(size_t)255;
     if (!eb_ensure(S, EB_STREAMS, sizeof(EncStream)) || !eb_ensure(S, EB_TILES, nt * sizeof(EncTile)) ||
-        !eb_ensure(S, EB_PREV, padn * 4) || !eb_ensure(S, EB_SUMMARY, (size_t)nt * ((2u << HASH_BITS) + 2) * 4) ||
+        !eb_ensure(S, EB_PREV, padn * 4) || !eb_ensure(S, EB_SUMMARY, (size_t)nt * ((2u << HASH_BITS) + 64 + 2) * 4) ||
         !eb_ensure(S, EB_REC, padn * 8) || !eb_ensure(S, EB_STAGE, padn + 256) || !eb_ensure(S, EB_BITMAP, padn / 8 + 64))
         return LZFSE_MI_IO;
     uint8_t *d_src = (uint8_t *)S.bufs[EB_STAGE];
@@ -888,7 +888,7 @@ extern "C" LZFSE_MI_API int lzfse_mi_debug_candidates(lzfse_mi_ctx *c, const uin
     E_TRY(hipMemcpyAsync(S.bufs[EB_STREAMS], &e, sizeof e, hipMemcpyHostToDevice, stq));
     E_TRY(hipMemcpyAsync(S.bufs[EB_TILES], ht.data(), nt * sizeof(EncTile), hipMemcpyHostToDevice, stq));
     uint32_t *sm = (uint32_t *)S.bufs[EB_SUMMARY];
-    uint32_t *fl = sm + (size_t)nt * (1u << HASH_BITS), *fc = fl + (size_t)nt * (1u << HASH_BITS), *redo = fc + nt;
+    uint32_t *fl = sm + (size_t)nt * (1u << HASH_BITS), *fc = fl + (size_t)nt * ((1u << HASH_BITS) + 64), *redo = fc + nt;
     launch_enc_chain(d_src, (EncStream *)S.bufs[EB_STREAMS], (EncTile *)S.bufs[EB_TILES], nt, (uint32_t *)S.bufs[EB_PREV], sm, fl, fc, redo,
                      ctx_diag_chain(c) == 1, stq);
     launch_enc_link((EncStream *)S.bufs[EB_STREAMS], (EncTile *)S.bufs[EB_TILES], nt, (uint32_t *)S.bufs[EB_PREV], sm, fl, fc, stq);

@@ -16,11 +16,16 @@
 // (A replay of the 4-entry table itself -- bucket-partitioned tables in LDS fed by a stable multi-split of the positions,
 // writing every position's four candidates -- was built and measured in round 2: it removes the dependent hops from
 // enc_cand_kernel but costs more than the chains it replaces)
+#include <type_traits>
+
 #include "enc_common.h"
 
 namespace lzmi {
 
 // ------------------------------------------------------------------------------------ chains
+
+// first-occurrence list of a tile: one slot per bucket + 64 slots where lanes that have nothing to list store
+constexpr uint32_t FL_STRIDE = (1u << HASH_BITS) + 64;
 
 // One wave per tile; positions in order, 64 per step. The last-seen table of the tile lives in LDS, one 32-bit entry
 // per bucket, and a step is ONE LDS exchange per lane: the entry a lane gets back is its predecessor in the bucket --
@@ -49,8 +54,7 @@ __global__ __launch_bounds__(64) void enc_chain_kernel(const uint8_t *__restrict
     uint32_t *pv = prev + st.pos_base;  // link records (enc_common.h)
     const uint32_t n_pos = st.n - 3;  // positions 0 .. n-4 are hashed (frontend_bytes.rs:166-170)
     const uint32_t t_end = tl.start + TILE_POS < n_pos ? tl.start + TILE_POS : n_pos;
-    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
-    uint32_t *fl = flist + (uint64_t)t * (1u << HASH_BITS);
+    uint32_t *fl = flist + (uint64_t)t * FL_STRIDE;
     uint32_t n_first = 0;
     bool wrong = false;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(64) void enc_chain_kernel(const uint8_t *__restrict
     // are unconditional (addresses clamped to the tile's last position) and their values are consumed in straight-line
     // code at the top of a batch: one wait per batch. (A load or a first use inside a divergent branch makes the
     // compiler wait for ALL outstanding memory operations, the link stores included, at every later use.)
-    constexpr int CH_STEPS = 16;
+    constexpr int CH_STEPS = 32;
     uint32_t nx[CH_STEPS];
     const uint32_t q_last = t_end - 1;
 #pragma unroll
@@ -67,12 +71,19 @@ __global__ __launch_bounds__(64) void enc_chain_kernel(const uint8_t *__restrict
         const uint32_t q = tl.start + 64 * j + lane;
         nx[j] = ld_u32(s + (q < q_last ? q : q_last));
     }
-    for (uint32_t pb = tl.start; pb < t_end; pb += 64 * CH_STEPS) {
+    uint32_t *pvt = pv + tl.start;   // records of the tile: offsets below 2^16
+    // One batch. FULL: all its positions lie inside the tile (no lane masks); LATER: not the first tile of its stream
+    // (first occurrences are listed). A full batch is straight-line code -- every store is unconditional -- so that the
+    // independent dependency chains of its steps can be interleaved; a lone wave per SIMD has nothing else to hide
+    // instruction latency with.
+    auto batch = [&](uint32_t pb, auto full_tag, auto later_tag) {
+        constexpr bool FULL = decltype(full_tag)::value, LATER = decltype(later_tag)::value;
         uint32_t key[CH_STEPS], ent[CH_STEPS], old[CH_STEPS];
+        const uint32_t off0 = pb - tl.start + (uint32_t)lane;   // offset in tile of this lane's position in step 0
 #pragma unroll
         for (int j = 0; j < CH_STEPS; j++) {
             key[j] = bucket_of(nx[j]);
-            ent[j] = seen_make(pb - tl.start + 64 * j + lane + 1, nx[j]);
+            ent[j] = seen_make(off0 + 64 * j + 1, nx[j]);
         }
 #pragma unroll
         for (int j = 0; j < CH_STEPS; j++) {
@@ -82,27 +93,38 @@ __global__ __launch_bounds__(64) void enc_chain_kernel(const uint8_t *__restrict
 #pragma unroll
         for (int j = 0; j < CH_STEPS; j++) {
             old[j] = 0;
-            if (pb + 64 * j + lane < t_end)
+            if (FULL || pb + 64 * j + lane < t_end)
                 old[j] = __hip_atomic_exchange(&last[key[j]], ent[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
 #pragma unroll
         for (int j = 0; j < CH_STEPS; j++) {
-            const uint32_t p0 = pb + 64 * j;
-            if (p0 >= t_end) continue;  // (not break: the loop must stay fully unrolled, the arrays live in registers)
-            const uint32_t p = p0 + lane;
-            const bool valid = p < t_end;
-            const uint32_t mine = p - tl.start + 1, o = old[j] & 0xFFFFu;
-            wrong = wrong || (valid && o >= mine);
+            if (!FULL && pb + 64 * j >= t_end) continue;  // (not break: the loop must stay fully unrolled, the arrays live in registers)
+            const uint32_t off = off0 + 64 * j;
+            __builtin_assume(off < 65536u);
+            const bool valid = FULL || pb + 64 * j + lane < t_end;
+            const uint32_t o = old[j] & 0xFFFFu;
+            wrong = wrong || (valid && o > off);   // a predecessor lies before its position (o is offset + 1)
             // first occurrence of its bucket in the tile: the link into earlier tiles is made by enc_link_kernel
             // from this list (offset | bucket << 16); the first tile of a stream has nothing before it
-            const bool first = valid && o == 0;
-            if (tl.start != 0) {
+            if (LATER) {
+                const bool first = valid && o == 0;
                 const uint64_t fm = __ballot(first);
-                if (first) fl[n_first + (uint32_t)__popcll(fm & lt_mask)] = (p - tl.start) | (key[j] << 16);
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+                fl[first ? n_first + below : (1u << HASH_BITS) + (uint32_t)lane] = off | (key[j] << 16);
                 n_first += (uint32_t)__popcll(fm);
             }
-            if (valid) pv[p] = o ? link_make(mine - o, old[j] >> 16) : 0u;  // (inside a tile: < 65 536)
+            const uint32_t rec = o ? link_make(off + 1 - o, old[j] >> 16) : 0u;  // (inside a tile: < 65 536)
+            if (FULL) pvt[off] = rec;
+            else if (valid) pvt[off] = rec;
         }
+    };
+    uint32_t pb = tl.start;
+    if (tl.start != 0) {
+        for (; pb + 64 * CH_STEPS <= t_end; pb += 64 * CH_STEPS) batch(pb, std::true_type{}, std::true_type{});
+        if (pb < t_end) batch(pb, std::false_type{}, std::true_type{});
+    } else {
+        for (; pb + 64 * CH_STEPS <= t_end; pb += 64 * CH_STEPS) batch(pb, std::true_type{}, std::false_type{});
+        if (pb < t_end) batch(pb, std::false_type{}, std::false_type{});
     }
     if (lane == 0) { fcount[t] = n_first; redo[t] = 0; }
     if (__any(wrong)) {
@@ -135,7 +157,7 @@ __global__ __launch_bounds__(64) void enc_chain_ballot_kernel(const uint8_t *__r
     const uint32_t n_pos = st.n - 3;
     const uint32_t t_end = tl.start + TILE_POS < n_pos ? tl.start + TILE_POS : n_pos;
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
-    uint32_t *fl = flist + (uint64_t)t * (1u << HASH_BITS);
+    uint32_t *fl = flist + (uint64_t)t * FL_STRIDE;
     uint32_t n_first = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -188,7 +210,7 @@ __global__ void enc_link_kernel(const EncStream *__restrict__ streams, const Enc
     if (t >= n_tiles || e >= fcount[t]) return;
     const EncTile tl = tiles[t];
     const EncStream st = streams[tl.stream];
-    const uint32_t ent = flist[(uint64_t)t * (1u << HASH_BITS) + e];
+    const uint32_t ent = flist[(uint64_t)t * FL_STRIDE + e];
     const uint32_t p = tl.start + (ent & 0xFFFF), key = ent >> 16;
     const uint32_t t_idx = tl.start / TILE_POS;  // tile index inside the stream (its tiles are consecutive)
     for (uint32_t back = 1; back <= 5 && back <= t_idx; back++) {
