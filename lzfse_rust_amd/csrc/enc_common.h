@@ -67,11 +67,13 @@ struct RangeRec {    // a run of events adopted into the match list
     uint32_t kind, pad;
 };
 
-struct EncTile {
+struct EncTile {         // one chain tile; carries what its kernels need of the stream, so that a workgroup starts with ONE descriptor load
     uint32_t stream;
-    uint32_t first;      // 1 if this is the first tile of its stream
+    uint32_t n;          // stream length
     uint32_t start;      // first position of the tile (stream relative)
     uint32_t pad;
+    uint64_t src_off;    // offset of the stream in d_src
+    uint64_t pos_base;   // offset of the stream in the per-position arrays (prev, rec)
 };
 
 struct EncBlock {        // one bvx2 block (written by the walk kernel)

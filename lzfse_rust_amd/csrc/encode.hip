@@ -719,7 +719,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         e.pos_base = pos_total;
         e.tile_base = (uint32_t)ht.size();
         const uint32_t n_pos = e.n - 3;
-        for (uint32_t p = 0; p < n_pos; p += TILE_POS) ht.push_back({si, p == 0 ? 1u : 0u, p, 0u});
+        for (uint32_t p = 0; p < n_pos; p += TILE_POS) ht.push_back({si, e.n, p, 0u, e.src_off, e.pos_base});
         e.blk_base = blk_total;
         e.blk_cap = e.n / 39000 + 2;
         e.lmd_base = lmd_total;
@@ -876,7 +876,7 @@ extern "C" LZFSE_MI_API int lzfse_mi_debug_candidates(lzfse_mi_ctx *c, const uin
     EncStream e{};
     e.src_off = 0; e.pos_base = 0; e.n = (uint32_t)n;
     std::vector<EncTile> ht;
-    for (uint32_t p = 0; p < e.n - 3; p += TILE_POS) ht.push_back({0u, p == 0 ? 1u : 0u, p, 0u});
+    for (uint32_t p = 0; p < e.n - 3; p += TILE_POS) ht.push_back({0u, e.n, p, 0u, 0ull, 0ull});
     const uint32_t nt = (uint32_t)ht.size();
     size_t padn = (n + 255) & ~(size_t)255;
     if (!eb_ensure(S, EB_STREAMS, sizeof(EncStream)) || !eb_ensure(S, EB_TILES, nt * sizeof(EncTile)) ||

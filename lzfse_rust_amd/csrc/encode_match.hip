@@ -48,11 +48,10 @@ __global__ __launch_bounds__(64) void enc_chain_kernel(const uint8_t *__restrict
         return;
     }
     const EncTile tl = tiles[t];
-    const EncStream st = streams[tl.stream];
     for (uint32_t k = lane; k < (1u << HASH_BITS); k += 64) last[k] = 0;
-    const uint8_t *s = src + st.src_off;
-    uint32_t *pv = prev + st.pos_base;  // link records (enc_common.h)
-    const uint32_t n_pos = st.n - 3;  // positions 0 .. n-4 are hashed (frontend_bytes.rs:166-170)
+    const uint8_t *s = src + tl.src_off;
+    uint32_t *pv = prev + tl.pos_base;  // link records (enc_common.h)
+    const uint32_t n_pos = tl.n - 3;  // positions 0 .. n-4 are hashed (frontend_bytes.rs:166-170)
     const uint32_t t_end = tl.start + TILE_POS < n_pos ? tl.start + TILE_POS : n_pos;
     uint32_t *fl = flist + (uint64_t)t * FL_STRIDE;
     uint32_t n_first = 0;
@@ -149,12 +148,11 @@ __global__ __launch_bounds__(64) void enc_chain_ballot_kernel(const uint8_t *__r
     const uint32_t t = blockIdx.x;
     if (t >= n_tiles || !redo[t]) return;
     const EncTile tl = tiles[t];
-    const EncStream st = streams[tl.stream];
     const int lane = e_lane();
     for (uint32_t k = lane; k < (1u << HASH_BITS); k += 64) last[k] = 0;
-    const uint8_t *s = src + st.src_off;
-    uint32_t *pv = prev + st.pos_base;
-    const uint32_t n_pos = st.n - 3;
+    const uint8_t *s = src + tl.src_off;
+    uint32_t *pv = prev + tl.pos_base;
+    const uint32_t n_pos = tl.n - 3;
     const uint32_t t_end = tl.start + TILE_POS < n_pos ? tl.start + TILE_POS : n_pos;
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
     uint32_t *fl = flist + (uint64_t)t * FL_STRIDE;
@@ -209,7 +207,6 @@ __global__ void enc_link_kernel(const EncStream *__restrict__ streams, const Enc
     const uint32_t e = (blockIdx.x % BPT) * blockDim.x + threadIdx.x;
     if (t >= n_tiles || e >= fcount[t]) return;
     const EncTile tl = tiles[t];
-    const EncStream st = streams[tl.stream];
     const uint32_t ent = flist[(uint64_t)t * FL_STRIDE + e];
     const uint32_t p = tl.start + (ent & 0xFFFF), key = ent >> 16;
     const uint32_t t_idx = tl.start / TILE_POS;  // tile index inside the stream (its tiles are consecutive)
@@ -217,7 +214,7 @@ __global__ void enc_link_kernel(const EncStream *__restrict__ streams, const Enc
         const uint32_t sv = summary[(uint64_t)(t - back) * (1u << HASH_BITS) + key];
         if (sv != 0) {
             const uint32_t r = tl.start - back * TILE_POS + (sv & 0xFFFFu) - 1;
-            if (p - r <= MAX_D_VALUE) prev[st.pos_base + p] = link_make(p - r, sv >> 16);   // (the chain kernel left 0 here)
+            if (p - r <= MAX_D_VALUE) prev[tl.pos_base + p] = link_make(p - r, sv >> 16);   // (the chain kernel left 0 here)
             break;
         }
     }
@@ -266,13 +263,12 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
     const uint32_t t = (slot / CAND_BPT) * 8 + xcd, bx = slot % CAND_BPT;
     if (t >= n_tiles) return;
     const EncTile tl = tiles[t];
-    const EncStream st = streams[tl.stream];
     const uint32_t i = tl.start + bx * blockDim.x + threadIdx.x;
-    const uint32_t n = st.n, n_pos = n - 3;
+    const uint32_t n = tl.n, n_pos = n - 3;
     if (tl.start + bx * blockDim.x >= n_pos) return;  // block-uniform
     const bool valid = i < n_pos && i < tl.start + TILE_POS;
-    const uint8_t *s = src + st.src_off;
-    const uint32_t *pv = prev + st.pos_base;
+    const uint8_t *s = src + tl.src_off;
+    const uint32_t *pv = prev + tl.pos_base;
     const int lane = e_lane();
     const uint32_t self = valid ? pv[i] : 0u;
     const uint32_t max_total = valid ? n - i : 0;
@@ -541,13 +537,13 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
                 r.x = (i - best_idx) | (bw << 18) | (capped ? REC_CAPPED : 0u);
                 r.y = best_len;
             }
-            rec[st.pos_base + i] = r;
+            rec[tl.pos_base + i] = r;
         }
     }
     // has-match bitmap: tile starts are multiples of 64, so a wave covers exactly one word
     const uint64_t bits = __ballot(valid && r.y != 0);
     // (words past the stream's last position belong to the next stream: never touch them)
-    if (lane == 0 && i < tl.start + TILE_POS && i < n_pos) bitmap[(st.pos_base + i) >> 6] = bits;
+    if (lane == 0 && i < tl.start + TILE_POS && i < n_pos) bitmap[(tl.pos_base + i) >> 6] = bits;
 }
 
 // ------------------------------------------------------------------------------------ launchers
