@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the exclusive pass, PCIe-inclusive and copy-peak measurements")
     ap.add_argument("--lanes", type=int, default=0, help="sub-batches run side by side per call (0: library default, 1: unsplit)")
+    ap.add_argument("--stagger", action="store_true", help="encode lanes start one after the other instead of together")
     ap.add_argument("--skip-verify", action="store_true", help=argparse.SUPPRESS)  # timing of deliberately broken ablation builds
     ap.add_argument("--per-file", type=int, default=0, metavar="R",
                     help="instead of the headline run: Criterion-style table, each Snappy file alone as a batch of R copies")
@@ -168,6 +169,8 @@ def main():
     if args.lanes:
         ctx.set_option("encode_lanes", args.lanes)
         ctx.set_option("decode_lanes", args.lanes)
+    if args.stagger:
+        ctx.set_option("stagger", 1)
 
     names, fixture_streams, hashes = load_corpus_streams()
     if args.per_file:

@@ -86,7 +86,7 @@ LZFSE_MI_API int lzfse_mi_set_stream(lzfse_mi_ctx *ctx, void *hip_stream);
 enum {
     LZFSE_MI_OPT_ENCODE_LANES = 1,  /* 0: chosen by batch size (default), 1: one pass ("exclusive" kernel timing), 2..4 */
     LZFSE_MI_OPT_DECODE_LANES = 2,
-    LZFSE_MI_OPT_STAGGER = 3,       /* encode lanes start one after the other (default 1) */
+    LZFSE_MI_OPT_STAGGER = 3,       /* 1: encode lanes start one after the other (default 0: together) */
     LZFSE_MI_OPT_DIAG_LZ_PATH = 100, /* -1: by cost, 0: tile kernel only, 1: pointer jumping for every stream */
     LZFSE_MI_OPT_DIAG_LZ_TILE = 101, /* -1: by stream count, 0: 256-thread / 8 KiB tile, 1: 1024-thread / 32 KiB tile */
     LZFSE_MI_OPT_DIAG_STATS = 102,   /* bit mask: per-stage statistics on stderr */

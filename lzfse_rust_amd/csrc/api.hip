@@ -133,7 +133,7 @@ struct lzfse_mi_ctx {
     std::vector<uint32_t> detail, detail_out;
     // lzfse_mi_set_option
     int opt_lanes_enc = 0, opt_lanes_dec = 0;  // sub-batches run side by side (0: chosen by size, 1: one)
-    int opt_stagger = 1;
+    int opt_stagger = 0;
     int diag_lz_jump = -1, diag_lz_variant = -1, diag_stats = 0, diag_chain = 0;  // diagnostic build only
 
     hipEvent_t get_event() {

@@ -226,12 +226,11 @@ __device__ __forceinline__ uint32_t bo_finalize(BitOut &o) {
     return nbytes * 8 - o.fill;
 }
 
-__global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
+__global__ __launch_bounds__(BLK_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void enc_block_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
                                                                 uint32_t n_streams, const EncStreamOut *__restrict__ outs,
                                                                 const uint2 *__restrict__ lmds, EncBlock *__restrict__ blocks,
                                                                 const uint32_t *__restrict__ slot_stream, uint8_t *__restrict__ stage,
-                                                                unsigned long long *__restrict__ cyc) {
-    __shared__ __attribute__((aligned(16))) uint8_t lit[LITERALS_PER_BLOCK + 16];
+                                                                uint8_t *__restrict__ lit_scratch, unsigned long long *__restrict__ cyc) {
     __shared__ uint32_t hist[N_WEIGHTS];
     __shared__ uint16_t wts[N_WEIGHTS];
     __shared__ uint32_t etab[N_WEIGHTS];      // t_k (low 16) | t_w (high 16), encoder.rs:184-188
@@ -255,6 +254,11 @@ __global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *_
     const uint8_t *s = src + st.src_off;
     const uint2 *bl = lmds + blk.lmd_start;
     uint8_t *sg = stage + blk.stage_off;
+    // The block's literal bytes (<= 40 000 + pad) live in global scratch, not in LDS: they are written once, read twice
+    // in order, and 40 KB of LDS per block would leave room for two blocks per CU. The scratch is the stream's part of
+    // the candidate-record array, which no stage reads any more (8 bytes per position; a block needs at most its own
+    // raw bytes + 4 of padding here, blocks are kept 32 bytes apart).
+    uint8_t *lit = lit_scratch + st.pos_base * 8 + blk.src_start + 32 * bi;
 
     // diagnostics (LZFSE_MI_BLOCK_STATS): cycles per phase, summed over blocks
     uint64_t tq = cyc ? __builtin_amdgcn_s_memtime() : 0;
@@ -300,10 +304,18 @@ __global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *_
                     // literal bytes of the same stream, except at its very end)
                     const bool wide = run_src + ex_s + 24 <= st.n;
                     if (wide) {
-                        uint64_t w0 = ld_u64(ls), w1 = l > 8 ? ld_u64(ls + 8) : 0, w2 = l > 16 ? ld_u64(ls + 16) : 0;
-                        for (uint32_t k = 0; k < l; k++) {
-                            uint64_t w = k < 8 ? w0 : (k < 16 ? w1 : w2);
-                            ld[k] = (uint8_t)(w >> (8 * (k & 7)));
+                        // exactly l bytes in at most five LDS stores of 8 / 8 / 4 / 2 / 1 bytes at byte alignment (gfx950 runs
+                        // LDS in unaligned access mode; a byte loop costs the wave its longest run in iterations)
+                        const uint64_t w0 = ld_u64(ls), w1 = l > 8 ? ld_u64(ls + 8) : 0, w2 = l > 16 ? ld_u64(ls + 16) : 0;
+                        uint64_t cur = w0;
+                        uint8_t *q = ld;
+                        if (l >= 8) { __builtin_memcpy(q, &w0, 8); q += 8; cur = w1; }
+                        if (l >= 16) { __builtin_memcpy(q, &w1, 8); q += 8; cur = w2; }
+                        if (l == 24) { __builtin_memcpy(q, &w2, 8); }
+                        else {
+                            if (l & 4) { const uint32_t c4 = (uint32_t)cur; __builtin_memcpy(q, &c4, 4); q += 4; cur >>= 32; }
+                            if (l & 2) { const uint16_t c2 = (uint16_t)cur; __builtin_memcpy(q, &c2, 2); q += 2; cur >>= 16; }
+                            if (l & 1) *q = (uint8_t)cur;
                         }
                     } else {
                         for (uint32_t k = 0; k < l; k++) ld[k] = ls[k];
@@ -325,12 +337,20 @@ __global__ __launch_bounds__(BLK_THREADS) void enc_block_kernel(const uint8_t *_
             lds_barrier();
         }
     }
-    lds_barrier();
+    __syncthreads();   // (the literal bytes are global stores: drained and visible to the workgroup)
     lap(0);
     // literals.rs:136-145 pad with literals[0]; weights.rs:56-64 literal histogram (unpadded)
     const uint32_t n_lit = blk.n_lit, n4 = (n_lit + 3) / 4 * 4;
     if (tid < 4) lit[n_lit + tid] = n_lit ? lit[0] : 0;
-    for (uint32_t i = tid; i < n_lit; i += BLK_THREADS) atomicAdd(&hist[104 + lit[i]], 1u);
+    {
+        // 8 bytes per thread and step (the scratch has slack after the pad; bytes beyond n_lit are not counted)
+        for (uint32_t i = tid * 8; i < n_lit; i += BLK_THREADS * 8) {
+            const uint64_t w = ld_u64(lit + i);
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (i + k < n_lit) atomicAdd(&hist[104 + (uint32_t)((w >> (8 * k)) & 0xFF)], 1u);
+        }
+    }
     __syncthreads();
     for (uint32_t i = tid; i < N_WEIGHTS; i += BLK_THREADS) wts[i] = (uint16_t)hist[i];
     __syncthreads();
@@ -835,7 +855,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
             E_TRY(hipMemsetAsync(d_cyc, 0, 64, stq));
         }
         hipLaunchKernelGGL(enc_block_kernel, dim3(blk_total), dim3(BLK_THREADS), 0, stq, d_src, d_streams, ns, d_outs, d_lmds,
-                           d_blocks, d_slots, d_stage, d_cyc);
+                           d_blocks, d_slots, d_stage, (uint8_t *)d_rec, d_cyc);
     }
     {
         StageTimer t(c, "enc_pack");

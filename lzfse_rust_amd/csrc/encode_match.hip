@@ -255,9 +255,9 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
     // Workgroups are handed to the 8 XCDs round-robin. All workgroups of one tile go to the same XCD, so the
     // link records and source bytes a tile gathers from (its own 0.5 MB + the 2 MB window before it) stay in
     // that XCD's 4 MB L2 instead of being spread over all eight.
-    __shared__ uint32_t q_i[4][256], q_c[4][256];  // per-wave work list of phase 3: position, candidate
-    __shared__ uint16_t q_id[4][256], q_res[4][256];
-    __shared__ uint32_t q_dist[4][256], q_tab[4][64];  // distance of a listed head; first head per distance hash
+    // (LDS is kept small on purpose: this kernel runs next to another lane's chain kernel, whose tiles need 64 KiB each)
+    __shared__ uint16_t q_id[4][256], q_res[4][256];   // per-wave work list of phase 3: slot * 64 + lane of a head; its length
+    __shared__ uint32_t q_dist[4][256], q_tab[4][64];  // distance of a head (by slot * 64 + lane); first head per distance hash
     __shared__ uint32_t s_win[4][52];                  // per wave: 192 source bytes around its 64 positions (+ read slack)
     const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const uint32_t t = (slot / CAND_BPT) * 8 + xcd, bx = slot % CAND_BPT;
@@ -408,10 +408,7 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
             for (int k = 0; k < 4; k++) {
                 const bool ind = more[k] && !dep[k];
                 const uint64_t mk = __ballot(ind);
-                if (ind) {
-                    const uint32_t q = total + (uint32_t)__popcll(mk & lt_mask);
-                    q_i[wv][q] = i; q_c[wv][q] = cc[k]; q_id[wv][q] = (uint16_t)(k * 64 + lane);
-                }
+                if (ind) q_id[wv][total + (uint32_t)__popcll(mk & lt_mask)] = (uint16_t)(k * 64 + lane);
                 total += (uint32_t)__popcll(mk);
             }
         }
@@ -429,7 +426,9 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
                     const uint32_t q = next + (uint32_t)__popcll(idle & before);
                     if (!busy && q < total) {
                         busy = true;
-                        it_i = q_i[wv][q]; it_c = q_c[wv][q]; it_id = q_id[wv][q];
+                        it_id = q_id[wv][q];
+                        it_i = i - (uint32_t)lane + (it_id & 63);
+                        it_c = it_i - q_dist[wv][it_id];
                         it_off = CAND_C1;
                         const uint32_t maxh = n - it_i;
                         it_lim = maxh < FCAP + 64 ? maxh : FCAP + 64;

@@ -76,9 +76,10 @@ def test_split_lane_count_option(snappy_raw, oracle):
         assert all(o.tobytes() == want for o in many)
         back, st = c.decode_batch([want] * 96)
         assert all(e == 0 for e in st) and all(o.tobytes() == r for o in back)
-    c.set_option("stagger", 0)
-    many, st = c.encode_batch([r] * 96)
-    assert all(e == 0 for e in st) and all(o.tobytes() == want for o in many)
+    for stagger in (1, 0):   # lanes one after the other (LaneGate) / together (the default)
+        c.set_option("stagger", stagger)
+        many, st = c.encode_batch([r] * 96)
+        assert all(e == 0 for e in st) and all(o.tobytes() == want for o in many)
     with pytest.raises(m.LzfseError):
         c.set_option("diag_lz_path", 1)   # the product library has no diagnostic options
 
