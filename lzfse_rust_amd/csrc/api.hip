@@ -436,7 +436,7 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
     for (uint32_t i = 0; i < ns; i++) {
         StreamPlan &p = h_plan[i];
         p.blk_base = nb; p.lmd_base = nl; p.lit_base = nu; p.n_blocks = h_walk[i].n_blocks; p.skip = 0;
-        p.jbase = 0; p.jump = 0; p.pad = 0;
+        p.jbase = 0; p.jump = 0; p.turn = i;
         statuses[i] = LZFSE_MI_OK;
         out_lens[i] = 0;
         // A stream whose walk failed at block k still has its first k blocks decoded: the reference decodes in order, so
@@ -454,6 +454,13 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
         }
     }
     if (nb > 0x7FFFFFFFull) return LZFSE_MI_UNSUPPORTED;
+    {
+        // order of the tile kernel's workgroups: streams by decreasing size (plan[b].turn)
+        std::vector<uint32_t> turn(ns);
+        for (uint32_t i = 0; i < ns; i++) turn[i] = i;
+        std::stable_sort(turn.begin(), turn.end(), [&](uint32_t a, uint32_t b) { return h_walk[a].raw_total > h_walk[b].raw_total; });
+        for (uint32_t b = 0; b < ns; b++) h_plan[b].turn = turn[b];
+    }
     if (!c->d_blocks.ensure((nb + 1) * sizeof(BlockDesc)) || !c->d_bres.ensure((nb + 1) * sizeof(BlockResult)) ||
         !c->d_lmds.ensure((nl + 64) * sizeof(LmdRec)) || !c->d_lits.ensure(nu + 256) || !c->d_origin.ensure((nj + 16) * 4) ||
         !c->d_jerr.ensure((size_t)ns * 4 + 64 * 4))

@@ -52,7 +52,7 @@ struct StreamPlan {
     int32_t skip;  // != 0: stream not decoded (status already final)
     uint64_t jbase;  // pointer-jumping LZ path: first entry of the stream in the origin array
     int32_t jump;    // != 0: LZ stage by pointer jumping (large streams), else by the tile kernel
-    int32_t pad;
+    uint32_t turn;   // plan[b].turn = the stream workgroup b of the tile kernel decodes: longest streams first
 };
 
 struct BlockDesc {

@@ -689,7 +689,9 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
     __shared__ uint32_t s_cnt[4];
     __shared__ int s_status;
 
-    const uint32_t s = blockIdx.x;
+    // one workgroup per stream, and a stream's time goes with its size (14 KB .. 700 KB in one Snappy batch): the
+    // workgroups take the streams longest first, so that no long stream starts when the others are nearly done
+    const uint32_t s = plan[blockIdx.x].turn;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const StreamPlan pl = plan[s];
     if (pl.skip || pl.jump) return;
