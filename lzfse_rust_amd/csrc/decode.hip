@@ -268,12 +268,17 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
     BlockResult *__restrict__ results) {
     __shared__ uint32_t u_tab[U_STATES];
     __shared__ uint2 v_tab[L_STATES + M_STATES + D_STATES];
-    __shared__ uint32_t stage[168];   // up to 662 header+weight bytes (v2), dword aligned
-    __shared__ uint16_t wts[N_WEIGHTS];
-    __shared__ uint16_t cum[N_WEIGHTS];
-    __shared__ uint32_t ring[2][128];
-    __shared__ uint32_t stg_lmd[64 * 3 + 1];  // 64 steps of (L, M, D) values, + one dump slot for the idle lanes
-    __shared__ __attribute__((aligned(4))) uint8_t stg_lit[64 * 4 + 4];   // 64 groups of four literals, + dump slot
+    // The buffers of the table set-up (weight payload, weights, cumulative weights) and those of the two bit streams share
+    // one pool: the set-up is over (a workgroup barrier) before the first payload word is staged. 9.3 KB of LDS per block
+    // instead of 11.4: the 32 wave slots of a CU, not its LDS, bound the number of resident blocks (16 instead of 14).
+    __shared__ uint32_t pool[168 + N_WEIGHTS];
+    uint32_t *const stage = pool;                                               // up to 662 header+weight bytes (v2), dword aligned
+    uint16_t *const wts = reinterpret_cast<uint16_t *>(pool + 168);            // N_WEIGHTS
+    uint16_t *const cum = reinterpret_cast<uint16_t *>(pool + 168 + N_WEIGHTS / 2);
+    uint32_t (*const ring)[128] = reinterpret_cast<uint32_t (*)[128]>(pool);   // [2][128] payload windows
+    uint32_t *const stg_lmd = pool + 256;          // 64 steps of (L, M, D) values, + one dump slot for the idle lanes (193)
+    uint8_t *const stg_lit = reinterpret_cast<uint8_t *>(pool + 256 + 194);    // 64 groups of four literals, + dump slot (260 B)
+    static_assert(256 + 194 + 65 <= 168 + N_WEIGHTS, "dec_fse LDS pool");
     __shared__ int sh_status[2];
     __shared__ uint32_t sh_sums[3];
 
