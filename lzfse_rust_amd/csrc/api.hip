@@ -463,11 +463,12 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
     }
     if (!c->d_blocks.ensure((nb + 1) * sizeof(BlockDesc)) || !c->d_bres.ensure((nb + 1) * sizeof(BlockResult)) ||
         !c->d_lmds.ensure((nl + 64) * sizeof(LmdRec)) || !c->d_lits.ensure(nu + 256) || !c->d_origin.ensure((nj + 16) * 4) ||
-        !c->d_jerr.ensure((size_t)ns * 4 + 64 * 4))
+        !c->d_jerr.ensure((size_t)ns * 4 + 128 * 4 + (nb + 1) * 4))
         return LZFSE_MI_IO;
     uint32_t *d_jerr = (uint32_t *)c->d_jerr.p, *d_jflags = d_jerr + ns;
     HIP_TRY(hipMemsetAsync(d_jerr, 0xFF, (size_t)ns * 4, st));
-    HIP_TRY(hipMemsetAsync(d_jflags, 0, 64 * 4, st));
+    uint32_t *d_ohist = d_jflags + 64, *d_order = d_ohist + 64;   // FSE workgroup order (launch_dec_fse)
+    HIP_TRY(hipMemsetAsync(d_jflags, 0, 128 * 4, st));
     HIP_TRY(hipMemcpyAsync(c->d_plan.p, h_plan.data(), ns * sizeof(StreamPlan), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(c->d_bres.p, 0, (nb + 1) * sizeof(BlockResult), st));
     HIP_TRY(hipMemsetAsync(c->d_sres.p, 0, ns * sizeof(StreamResult), st));
@@ -484,7 +485,7 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
     {
         StageTimer t(c, "dec_fse");
         launch_dec_fse((const uint8_t *)d_src, src_total, (const BlockDesc *)c->d_blocks.p, (uint32_t)nb,
-                       (uint8_t *)c->d_lits.p, (LmdRec *)c->d_lmds.p, (BlockResult *)c->d_bres.p, st);
+                       (uint8_t *)c->d_lits.p, (LmdRec *)c->d_lmds.p, (BlockResult *)c->d_bres.p, d_ohist, d_order, st);
     }
     {
         StageTimer t(c, "dec_lz");

@@ -259,13 +259,36 @@ __device__ __forceinline__ int bw_finalize(const BitWindow &w) {
 
 constexpr int FSE_THREADS = 128;
 
+// ---- order of the FSE workgroups: a block's time is the length of its longer bit stream (its LMD count, or a quarter of
+// its literal count), and a stream ends with a short block. Blocks are handed out longest first (a counting sort into
+// 64 classes), so that the last round of workgroups is made of short blocks instead of whatever comes last. ----
+__device__ __forceinline__ uint32_t fse_order_key(const BlockDesc &d) {
+    if (d.kind != KIND_VX2 && d.kind != KIND_VX1) return 63u;
+    const uint32_t work = d.n_lmd > d.n_lit / 4 ? d.n_lmd : d.n_lit / 4;
+    const uint32_t c = work / 160u;
+    return 63u - (c < 63u ? c : 63u);
+}
+__global__ void dec_order_count_kernel(const BlockDesc *__restrict__ blocks, uint32_t n_blocks, uint32_t *__restrict__ hist) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n_blocks) atomicAdd(&hist[fse_order_key(blocks[b])], 1u);
+}
+__global__ __launch_bounds__(64) void dec_order_scan_kernel(uint32_t *__restrict__ hist) {
+    const uint32_t v = hist[threadIdx.x];
+    hist[threadIdx.x] = wave_incl_scan(v) - v;
+}
+__global__ void dec_order_place_kernel(const BlockDesc *__restrict__ blocks, uint32_t n_blocks, uint32_t *__restrict__ hist,
+                                       uint32_t *__restrict__ order) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n_blocks) order[atomicAdd(&hist[fse_order_key(blocks[b])], 1u)] = b;
+}
+
 // LDS table entry formats
 //   U: k | symbol << 8 | (delta & 0xFFFF) << 16                       (decoder.rs:222-238)
 //   V: .x = k | v_bits << 8 | (delta & 0xFFFF) << 16, .y = v_base     (decoder.rs:205-220)
 __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
     const uint8_t *__restrict__ src, uint64_t src_total, const BlockDesc *__restrict__ blocks,
     uint32_t n_blocks, uint8_t *__restrict__ lit_out, LmdRec *__restrict__ lmd_out,
-    BlockResult *__restrict__ results) {
+    BlockResult *__restrict__ results, const uint32_t *__restrict__ order) {
     __shared__ uint32_t u_tab[U_STATES];
     __shared__ uint2 v_tab[L_STATES + M_STATES + D_STATES];
     // The buffers of the table set-up (weight payload, weights, cumulative weights) and those of the two bit streams share
@@ -282,8 +305,8 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
     __shared__ int sh_status[2];
     __shared__ uint32_t sh_sums[3];
 
-    const uint32_t b = blockIdx.x;
-    if (b >= n_blocks) return;
+    if (blockIdx.x >= n_blocks) return;
+    const uint32_t b = order[blockIdx.x];   // longest blocks first (dec_order_*)
     const BlockDesc d = blocks[b];
     if (d.kind != KIND_VX2 && d.kind != KIND_VX1) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1099,10 +1122,14 @@ void launch_dec_emit(const StreamIn *streams, uint32_t n_streams, const StreamPl
 }
 
 void launch_dec_fse(const uint8_t *src, uint64_t src_total, const BlockDesc *blocks, uint32_t n_blocks,
-                    uint8_t *lit_out, LmdRec *lmd_out, BlockResult *results, hipStream_t st) {
+                    uint8_t *lit_out, LmdRec *lmd_out, BlockResult *results, uint32_t *order_hist, uint32_t *order, hipStream_t st) {
     if (!n_blocks) return;
+    // order_hist: 64 zeroed words; order: n_blocks words
+    hipLaunchKernelGGL(dec_order_count_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, st, blocks, n_blocks, order_hist);
+    hipLaunchKernelGGL(dec_order_scan_kernel, dim3(1), dim3(64), 0, st, order_hist);
+    hipLaunchKernelGGL(dec_order_place_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, st, blocks, n_blocks, order_hist, order);
     hipLaunchKernelGGL(dec_fse_kernel, dim3(n_blocks), dim3(FSE_THREADS), 0, st, src, src_total, blocks,
-                       n_blocks, lit_out, lmd_out, results);
+                       n_blocks, lit_out, lmd_out, results, order);
 }
 
 void launch_dec_lz(int variant, const uint8_t *src, const StreamIn *streams, const StreamPlan *plan,
