@@ -193,7 +193,10 @@ struct BitWindow {
 
 __device__ __forceinline__ uint32_t bw_gload(const BitWindow &w, int32_t dw) {
     const uint8_t *a = w.ga + (int64_t)dw * 4;
-    return (a >= w.glo && a + 4 <= w.ghi) ? *(const uint32_t *)a : 0u;
+    // (the payload is global memory: said explicitly, or the pointer kept in a struct beside an LDS pointer is treated as
+    // generic and every refill becomes a flat load, which also waits on the LDS counter)
+    typedef const __attribute__((address_space(1))) uint32_t *gptr;
+    return (a >= w.glo && a + 4 <= w.ghi) ? *(gptr)(uintptr_t)a : 0u;
 }
 
 // the 64 bits below `rem`: bits [rem - 64, rem)
