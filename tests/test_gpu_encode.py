@@ -223,6 +223,33 @@ def test_encode_random_structures_bit_exact(ctx, oracle):
         assert o.tobytes() == r
 
 
+def test_encode_tile_and_batch_edges_bit_exact(ctx, diag_ctx, oracle, snappy_raw):
+    """Stream lengths around the edges of the match-finding kernels: the 65 472-position chain tile (last tile of 1, 2,
+    63 positions; exactly full), the 2 048-position batch of the chain kernel (tail batch of 1 / 2 047 positions), the
+    256-position candidate workgroup and the 64-position wave; text, a highly repetitive input and low-entropy noise,
+    through the LDS-exchange chain kernel and through its ballot fallback."""
+    from oracle_py import seq_masked
+    tile = 65472
+    text = (snappy_raw["alice29.txt"] + snappy_raw["lcet10.txt"]) * 2
+    rep = (snappy_raw["html"][:7000] * 40)
+    noise = seq_masked(5, 0x07070707, 300000)
+    lens = [tile + 3, tile + 4, tile + 5, tile + 3 + 63, tile + 3 + 64, tile + 3 + 65, 2 * tile + 2, 2 * tile + 3, 2 * tile + 4,
+            tile + 3 + 2047, tile + 3 + 2048, tile + 3 + 2049, tile + 3 + 255, tile + 3 + 256, tile + 3 + 257, 3 * tile + 3 + 1]
+    raws = [src[:n] for src in (text, rep, noise) for n in lens]
+    want = [oracle.encode(r) for r in raws]
+    for c, force in ((ctx, None), (diag_ctx, 1)):
+        if force is not None:
+            c.set_option("diag_chain", force)
+        try:
+            outs, st = c.encode_batch(raws)
+        finally:
+            if force is not None:
+                c.set_option("diag_chain", 0)
+        assert all(e == 0 for e in st)
+        for r, o, w in zip(raws, outs, want):
+            assert o.tobytes() == w, (len(r), force)
+
+
 def test_encode_block_boundaries_bit_exact(ctx, oracle):
     """Multi-block streams whose blocks close on the literal limit (noise), on the LMD limit (dense short matches),
     inside over-long literal runs (L > 315) and inside over-long matches (M > 2 359): fse/buffer.rs:45-97."""
