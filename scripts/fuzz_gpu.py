@@ -1,0 +1,90 @@
+"""One-off randomised parity campaign on a GPU box (not part of the test-suite: the suite's cases are fixed):
+    python scripts/fuzz_gpu.py [ROUNDS] [SEED]
+Every round: ~120 streams of random structure and length (4 097 B .. 3 MiB, some at tile edges) are encoded by the device
+and compared with the CPU restatement's bytes, decoded back, and a damaged copy of every stream (one byte changed, or cut
+short) is decoded by both with the status codes and lengths compared."""
+import os, sys, time
+import numpy as np
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import lzfse_rust_amd as lz
+import oracle_py
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+O = oracle_py.Oracle()
+ctx = lz.Context(0)
+rng = np.random.default_rng(seed)
+words = [bytes(rng.integers(97, 123, size=int(rng.integers(1, 12)), dtype=np.uint8)) for _ in range(800)]
+TILE = 65472
+
+def gen(kind, n):
+    if kind == 0:
+        return rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+    if kind == 1:
+        return (rng.integers(0, int(rng.integers(2, 9)), size=n, dtype=np.uint8) * 31).astype(np.uint8).tobytes()
+    if kind == 2:
+        chunk = rng.integers(0, 256, size=int(rng.integers(5, 9000)), dtype=np.uint8)
+        a = np.tile(chunk, n // chunk.size + 1)[:n].copy()
+        idx = rng.integers(0, n, size=max(1, n // int(rng.integers(30, 8000))))
+        a[idx] ^= rng.integers(1, 256, size=idx.size, dtype=np.uint8)
+        return a.tobytes()
+    if kind == 3:
+        per = int(rng.integers(1, 300000))
+        return (bytes(rng.integers(0, 256, size=per, dtype=np.uint8)) * (n // per + 1))[:n]
+    if kind == 4:
+        out = bytearray()
+        while len(out) < n:
+            out += words[int(rng.integers(0, 800))] + b" "
+        return bytes(out[:n])
+    if kind == 5:
+        runs = bytearray()
+        while len(runs) < n:
+            runs += bytes([int(rng.integers(0, 256))]) * int(rng.integers(1, 6000))
+        return bytes(runs[:n])
+    parts = bytearray()
+    while len(parts) < n:
+        parts += gen(int(rng.integers(0, 6)), int(rng.integers(100, 60000)))
+    return bytes(parts[:n])
+
+def length():
+    r = rng.random()
+    if r < 0.15:
+        return int(TILE * rng.integers(1, 6) + 3 + rng.integers(-3, 70))
+    if r < 0.3:
+        return int(rng.integers(4097, 20000))
+    if r < 0.9:
+        return int(rng.integers(20000, 600000))
+    return int(rng.integers(600000, 3 << 20))
+
+t0 = time.time(); total = 0
+for rd in range(rounds):
+    raws = [gen(int(rng.integers(0, 7)), max(4097, length())) for _ in range(120)]
+    total += sum(map(len, raws))
+    want = [O.encode(r) for r in raws]
+    outs, st = ctx.encode_batch(raws)
+    assert all(e == 0 for e in st), st
+    for i, (r, o, w) in enumerate(zip(raws, outs, want)):
+        assert o.tobytes() == w, f"round {rd}: encode differs, stream {i} of {len(r)} bytes"
+    dec, st2 = ctx.decode_batch(want)
+    assert all(e == 0 for e in st2)
+    for r, o in zip(raws, dec):
+        assert o.tobytes() == r
+    bad = []
+    for w in want:
+        b = bytearray(w)
+        if rng.random() < 0.3:
+            b = b[: int(rng.integers(4, len(b)))]
+        else:
+            k = int(rng.integers(0, len(b)))
+            b[k] ^= int(rng.integers(1, 256))
+        bad.append(bytes(b))
+    caps = [len(r) + 64 for r in raws]
+    got, gst = ctx.decode_batch(bad, caps=caps)
+    for i, (b, cap, g, s) in enumerate(zip(bad, caps, got, gst)):
+        ws = O.decode_status(b, cap)
+        assert s == ws, f"round {rd}: status {s} vs {ws}, stream {i} of {len(b)} bytes"
+        if s == 0:
+            assert g.tobytes() == O.decode(b, cap=cap)
+    print(f"round {rd}: {len(raws)} streams ok ({sum(map(len, raws)) / 1e6:.0f} MB), {time.time() - t0:.0f} s", flush=True)
+print(f"fuzz ok: {rounds} rounds, {total / 1e6:.0f} MB")
