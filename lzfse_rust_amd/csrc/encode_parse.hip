@@ -699,6 +699,11 @@ __global__ __launch_bounds__(SEGM_THREADS) void enc_segment_kernel(const EncStre
     uint32_t rem_l = 0, rem_m = 0, rem_d = 0;
     uint32_t raw_pos = 0;       // first raw byte of the current block
     bool more = true;
+    // A block normally costs ONE memory round trip: the 64 lanes that probe the prefix sums just below the expected end
+    // of the block also fetch the events there; the last complete event, the boundary event, the first event of the next
+    // block and the prefix sums in front of it are then picked out of registers (carried into the next iteration).
+    bool c_base = false, c_start = false;          // carried: PC / PL at j - 1, lit_pos of event j
+    uint32_t c_base_c = 0, c_base_l = 0, c_start_pos = 0;
     while (more && !w.status) {
         const uint32_t blk_lmd_start = w.lmd_count;
         w.n_lmd = 0; w.n_lit = 0; w.n_match = 0; w.prev_d = 0;
@@ -709,7 +714,16 @@ __global__ __launch_bounds__(SEGM_THREADS) void enc_segment_kernel(const EncStre
         uint32_t ev_begin = j, ev_end = j, head_lmds = w.n_lmd, head_prev_d = w.prev_d;
         if (!full) {
             // events [j, j2) fit completely: n_lmd + sum c <= 10 000 and n_lit + sum l <= 40 000
-            const uint32_t base_c = j ? PC[j - 1] : 0, base_l = j ? PL[j - 1] : 0;
+            const uint32_t base_c = j ? (c_base ? c_base_c : PC[j - 1]) : 0, base_l = j ? (c_base ? c_base_l : PL[j - 1]) : 0;
+            const uint32_t j_first = j;
+            const bool had_start = c_start;
+            const uint32_t start_carried = c_start_pos;
+            c_base = false; c_start = false;
+            uint32_t w0 = 0;                // first event of the probed window
+            bool probed = false;
+            uint32_t pr_c = 0, pr_l = 0;    // PC / PL of this lane's probe
+            MatchRec pr_m;                  // ... and its event
+            pr_m.lit_pos = 0; pr_m.l = 0; pr_m.m = 0; pr_m.d = 0;
             const uint32_t room_c = LMDS_PER_BLOCK - w.n_lmd, room_l = LITERALS_PER_BLOCK - w.n_lit;
             // first event that does NOT fit: in [j, hi] with hi <= j + 10 001 (every event has at least one LMD);
             // fits(e) is monotone, 64 probes per step narrow [lo, hi] by a factor of 65
@@ -720,7 +734,9 @@ __global__ __launch_bounds__(SEGM_THREADS) void enc_segment_kernel(const EncStre
                 const uint32_t top = (j + room_c + 1 < hi) ? j + room_c + 1 : hi;  // events >= top cannot fit (top <= hi)
                 if (top - lo > 64) {
                     const uint32_t e = top - 64 + (uint32_t)lane;
-                    const bool fits = PC[e] - base_c <= room_c && PL[e] - base_l <= room_l;
+                    w0 = top - 64; probed = true;
+                    pr_c = PC[e]; pr_l = PL[e]; pr_m = mt[e];
+                    const bool fits = pr_c - base_c <= room_c && pr_l - base_l <= room_l;
                     const uint32_t nfit = (uint32_t)__popcll(__ballot(fits));  // monotone: the first nfit probes fit
                     if (nfit == 0) hi = top - 64;                               // answer below the probed range
                     else { lo = top - 64 + nfit; hi = nfit < 64 ? lo : top; }   // exact when a probe failed
@@ -740,12 +756,21 @@ __global__ __launch_bounds__(SEGM_THREADS) void enc_segment_kernel(const EncStre
             }
             const uint32_t j2 = lo;
             ev_end = j2;
+            // events j2 - 1, j2 (and j2 + 1) in the probed window: taken from the lanes that fetched them
+            const bool in_win = probed && j2 > w0 && j2 < w0 + 64;
+            const int la = in_win ? (int)(j2 - 1 - w0) : 0;
             if (j2 > j) {
-                const uint32_t dc = PC[j2 - 1] - base_c, dl = PL[j2 - 1] - base_l;
-                const MatchRec last = mt[j2 - 1];
+                MatchRec last;
+                uint32_t pc_last, pl_last;
+                if (in_win) {
+                    pc_last = e_readlane(pr_c, la); pl_last = e_readlane(pr_l, la);
+                    last.lit_pos = e_readlane(pr_m.lit_pos, la); last.l = e_readlane(pr_m.l, la);
+                    last.m = e_readlane(pr_m.m, la); last.d = e_readlane(pr_m.d, la);
+                } else { pc_last = PC[j2 - 1]; pl_last = PL[j2 - 1]; last = mt[j2 - 1]; }
+                const uint32_t dc = pc_last - base_c, dl = pl_last - base_l;
                 const uint32_t end_pos = last.lit_pos + last.l + last.m;
                 // raw bytes of the full events = end_pos - (start of event j's literals)
-                const uint32_t start_pos = mt[j].lit_pos;
+                const uint32_t start_pos = had_start ? start_carried : mt[j_first].lit_pos;
                 w.n_lmd += dc; w.n_lit += dl; w.n_match += (end_pos - start_pos) - dl;
                 w.lmd_count += dc;  // written by enc_lmd_kernel
                 w.prev_d = last.d;  // every event ends with push_lmd(.., d)
@@ -754,7 +779,13 @@ __global__ __launch_bounds__(SEGM_THREADS) void enc_segment_kernel(const EncStre
             j = j2;
             if (j < E) {
                 // boundary event: fills the block (by construction it cannot complete)
-                MatchRec m = mt[j];
+                MatchRec m;
+                if (in_win) {
+                    m.lit_pos = 0; m.l = e_readlane(pr_m.l, la + 1); m.m = e_readlane(pr_m.m, la + 1); m.d = e_readlane(pr_m.d, la + 1);
+                    // the next block starts behind it: prefix sums at the boundary event, position of the event after it
+                    c_base = true; c_base_c = e_readlane(pr_c, la + 1); c_base_l = e_readlane(pr_l, la + 1);
+                    if (la + 2 < 64) { c_start = true; c_start_pos = e_readlane(pr_m.lit_pos, la + 2); }
+                } else m = mt[j];
                 rem_l = m.l; rem_m = m.m; rem_d = m.d;
                 j++;
                 if (em_buffer_push(w, rem_l, rem_m, rem_d)) rem = false; else { rem = true; full = true; }
