@@ -10,10 +10,18 @@ constexpr uint32_t OVER = 512;              // overrun of a segment walker into 
 constexpr uint32_t SEG_EV_CAP = (SEG + OVER) / 4 + 4;  // every emit advances literal_index by >= 4
 constexpr uint32_t NONE = 0xFFFFFFFFu;      // no previous position
 constexpr uint32_t NONE_TILE = 0xFFFFFFFEu; // no previous position inside the tile (link pending)
-constexpr uint32_t FCAP = 1024;             // cap of the forward length computed per position (>= GOOD_MATCH_LEN)
+constexpr uint32_t FCAP = 1023;             // cap of the forward length computed per position (>= GOOD_MATCH_LEN); 10 bits of a record
 constexpr uint32_t XCAP = 4096;             // cap of the exact per-lane extension in the segment walkers
-constexpr uint32_t BCAP = 32;               // cap of the backward length computed per position
-constexpr uint32_t REC_CAPPED = 0x80000000u;
+constexpr uint32_t BCAP = 15;               // cap of the backward length kept per position; 4 bits of a record
+
+// Candidate record of a position (4 bytes): the best match as if the position were visited. distance (18 bits) |
+// forward length << 18 (10 bits; FCAP = "at least FCAP": the walkers ask for the exact length) | backward length << 28
+// (4 bits; BCAP = "at least BCAP"). 0 = no match. Half the bytes of round 1's {word, length} pair: the segment walkers
+// are bound by the rate of L2 misses on this array, and twice as many positions share a sector.
+__device__ __forceinline__ uint32_t rec_make(uint32_t dist, uint32_t fwd, uint32_t bwd) { return dist | (fwd << 18) | (bwd << 28); }
+__device__ __forceinline__ uint32_t rec_dist(uint32_t r) { return r & 0x3FFFFu; }
+__device__ __forceinline__ uint32_t rec_fwd(uint32_t r) { return (r >> 18) & 0x3FFu; }
+__device__ __forceinline__ uint32_t rec_bwd(uint32_t r) { return r >> 28; }
 
 __device__ __forceinline__ int e_lane() { return threadIdx.x & 63; }
 __device__ __forceinline__ uint32_t e_readlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
@@ -110,14 +118,14 @@ void launch_enc_chain(const uint8_t *src, const EncStream *streams, const EncTil
                       uint32_t *flist, uint32_t *fcount, uint32_t *redo, bool force_redo, hipStream_t st);
 void launch_enc_link(const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, uint32_t *prev, const uint32_t *summary,
                      const uint32_t *flist, const uint32_t *fcount, hipStream_t st);
-void launch_enc_cand(const uint8_t *src, const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, const uint32_t *prev, uint2 *rec,
+void launch_enc_cand(const uint8_t *src, const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, const uint32_t *prev, uint32_t *rec,
                      uint64_t *bitmap, hipStream_t st);
 
 // encode_parse.hip
 void launch_enc_spec(const uint8_t *src, const EncStream *streams, const uint2 *segs, uint32_t n_segs, const uint32_t *prev,
-                     const uint2 *rec, const uint64_t *bitmap, SpecEvent *logs, SpecHeader *hdrs, hipStream_t st);
+                     const uint32_t *rec, const uint64_t *bitmap, SpecEvent *logs, SpecHeader *hdrs, hipStream_t st);
 void launch_enc_stitch(const uint8_t *src, const EncStream *streams, uint32_t ns, const uint2 *segs, uint32_t n_segs, const uint32_t *prev,
-                       const uint2 *rec, const uint64_t *bitmap, const SpecEvent *logs, const SpecHeader *hdrs, uint4 *sync,
+                       const uint32_t *rec, const uint64_t *bitmap, const SpecEvent *logs, const SpecHeader *hdrs, uint4 *sync,
                        RangeRec *ranges, MatchRec *gaps, EncStreamOut *outs, hipStream_t st);
 void launch_enc_compact(const EncStream *streams, const uint32_t *slot_stream, uint32_t n_slots, uint32_t ns, const EncStreamOut *outs,
                         const RangeRec *ranges, const SpecEvent *logs, const MatchRec *gaps, MatchRec *matches, uint32_t *pc,

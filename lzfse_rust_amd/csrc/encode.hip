@@ -256,9 +256,9 @@ __global__ __launch_bounds__(BLK_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     uint8_t *sg = stage + blk.stage_off;
     // The block's literal bytes (<= 40 000 + pad) live in global scratch, not in LDS: they are written once, read twice
     // in order, and 40 KB of LDS per block would leave room for two blocks per CU. The scratch is the stream's part of
-    // the candidate-record array, which no stage reads any more (8 bytes per position; a block needs at most its own
+    // the candidate-record array, which no stage reads any more (4 bytes per position; a block needs at most its own
     // raw bytes + 4 of padding here, blocks are kept 32 bytes apart).
-    uint8_t *lit = lit_scratch + st.pos_base * 8 + blk.src_start + 32 * bi;
+    uint8_t *lit = lit_scratch + st.pos_base * 4 + blk.src_start + 32 * bi;
 
     // diagnostics (LZFSE_MI_BLOCK_STATS): cycles per phase, summed over blocks
     uint64_t tq = cyc ? __builtin_amdgcn_s_memtime() : 0;
@@ -768,7 +768,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
 
     if (!eb_ensure(S, EB_STREAMS, ns * sizeof(EncStream)) || !eb_ensure(S, EB_TILES, nt * sizeof(EncTile)) ||
         !eb_ensure(S, EB_PREV, pos_total * 4) || !eb_ensure(S, EB_SUMMARY, (size_t)nt * ((2u << HASH_BITS) + 64 + 2) * 4) ||
-        !eb_ensure(S, EB_REC, pos_total * 8) || !eb_ensure(S, EB_LMDS, lmd_total * 8) ||
+        !eb_ensure(S, EB_REC, pos_total * 4) || !eb_ensure(S, EB_LMDS, lmd_total * 8) ||
         !eb_ensure(S, EB_BLOCKS, (size_t)blk_total * sizeof(EncBlock)) || !eb_ensure(S, EB_OUTS, ns * sizeof(EncStreamOut)) ||
         !eb_ensure(S, EB_STAGE, stage_total + 256) || !eb_ensure(S, EB_SLOTS, (size_t)blk_total * 4) ||
         !eb_ensure(S, EB_BITMAP, pos_total / 8 + 64))
@@ -785,7 +785,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     uint32_t *d_prev = (uint32_t *)S.bufs[EB_PREV];
     uint32_t *d_summary = (uint32_t *)S.bufs[EB_SUMMARY];
     uint32_t *d_flist = d_summary + (size_t)nt * (1u << HASH_BITS), *d_fcount = d_flist + (size_t)nt * ((1u << HASH_BITS) + 64), *d_redo = d_fcount + nt;
-    uint2 *d_rec = (uint2 *)S.bufs[EB_REC];
+    uint32_t *d_rec = (uint32_t *)S.bufs[EB_REC];
     uint2 *d_lmds = (uint2 *)S.bufs[EB_LMDS];
     EncBlock *d_blocks = (EncBlock *)S.bufs[EB_BLOCKS];
     EncStreamOut *d_outs = (EncStreamOut *)S.bufs[EB_OUTS];
@@ -901,7 +901,7 @@ extern "C" LZFSE_MI_API int lzfse_mi_debug_candidates(lzfse_mi_ctx *c, const uin
     size_t padn = (n + 255) & ~(size_t)255;
     if (!eb_ensure(S, EB_STREAMS, sizeof(EncStream)) || !eb_ensure(S, EB_TILES, nt * sizeof(EncTile)) ||
         !eb_ensure(S, EB_PREV, padn * 4) || !eb_ensure(S, EB_SUMMARY, (size_t)nt * ((2u << HASH_BITS) + 64 + 2) * 4) ||
-        !eb_ensure(S, EB_REC, padn * 8) || !eb_ensure(S, EB_STAGE, padn + 256) || !eb_ensure(S, EB_BITMAP, padn / 8 + 64))
+        !eb_ensure(S, EB_REC, padn * 4) || !eb_ensure(S, EB_STAGE, padn + 256) || !eb_ensure(S, EB_BITMAP, padn / 8 + 64))
         return LZFSE_MI_IO;
     uint8_t *d_src = (uint8_t *)S.bufs[EB_STAGE];
     E_TRY(hipMemcpyAsync(d_src, h_src, n, hipMemcpyHostToDevice, stq));
@@ -912,11 +912,18 @@ extern "C" LZFSE_MI_API int lzfse_mi_debug_candidates(lzfse_mi_ctx *c, const uin
     launch_enc_chain(d_src, (EncStream *)S.bufs[EB_STREAMS], (EncTile *)S.bufs[EB_TILES], nt, (uint32_t *)S.bufs[EB_PREV], sm, fl, fc, redo,
                      ctx_diag_chain(c) == 1, stq);
     launch_enc_link((EncStream *)S.bufs[EB_STREAMS], (EncTile *)S.bufs[EB_TILES], nt, (uint32_t *)S.bufs[EB_PREV], sm, fl, fc, stq);
-    launch_enc_cand(d_src, (EncStream *)S.bufs[EB_STREAMS], (EncTile *)S.bufs[EB_TILES], nt, (uint32_t *)S.bufs[EB_PREV], (uint2 *)S.bufs[EB_REC],
+    launch_enc_cand(d_src, (EncStream *)S.bufs[EB_STREAMS], (EncTile *)S.bufs[EB_TILES], nt, (uint32_t *)S.bufs[EB_PREV], (uint32_t *)S.bufs[EB_REC],
                     (uint64_t *)S.bufs[EB_BITMAP], stq);
     E_TRY(hipMemcpyAsync(h_prev, S.bufs[EB_PREV], (n - 3) * 4, hipMemcpyDeviceToHost, stq));  // link records
-    E_TRY(hipMemcpyAsync(h_rec_xy, S.bufs[EB_REC], (n - 3) * 8, hipMemcpyDeviceToHost, stq));
+    std::vector<uint32_t> packed(n - 3);
+    E_TRY(hipMemcpyAsync(packed.data(), S.bufs[EB_REC], (n - 3) * 4, hipMemcpyDeviceToHost, stq));
     E_TRY(hipStreamSynchronize(stq));
+    // (the tests read a record as the pair {distance | backward << 18 | capped << 31, forward length})
+    for (size_t k = 0; k + 3 < n; k++) {
+        const uint32_t r = packed[k], fwd = (r >> 18) & 0x3FFu;
+        h_rec_xy[2 * k] = (r & 0x3FFFFu) | ((r >> 28) << 18) | (fwd == FCAP ? 0x80000000u : 0u);
+        h_rec_xy[2 * k + 1] = fwd;
+    }
     return hipGetLastError() == hipSuccess ? LZFSE_MI_OK : LZFSE_MI_IO;
 }
 #endif

@@ -239,7 +239,7 @@ __device__ __forceinline__ uint32_t lcp_fwd(const uint8_t *s, uint32_t a, uint32
     return len;
 }
 
-// rec[i] = { dist | bwd << 18 | capped << 31 , fwd_len }  ; fwd_len == 0: no match at i
+// rec[i] = rec_make(dist, fwd_len, bwd) (enc_common.h); 0: no match at i
 //
 // One lane per position, hops in lock-step. A lane compares at most CAND_C1 bytes on its own. Lanes
 // that are still equal there are grouped into runs of consecutive positions with the same distance
@@ -251,7 +251,7 @@ constexpr uint32_t CAND_BPT = (TILE_POS + 255) / 256;  // workgroups per tile
 
 __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
                                                        const EncTile *__restrict__ tiles, uint32_t n_tiles, const uint32_t *__restrict__ prev,
-                                                       uint2 *__restrict__ rec, uint64_t *__restrict__ bitmap) {
+                                                       uint32_t *__restrict__ rec, uint64_t *__restrict__ bitmap) {
     // Workgroups are handed to the 8 XCDs round-robin. All workgroups of one tile go to the same XCD, so the
     // link records and source bytes a tile gathers from (its own 0.5 MB + the 2 MB window before it) stay in
     // that XCD's 4 MB L2 instead of being spread over all eight.
@@ -502,15 +502,16 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
         }
     }
     // backward extension: the same run structure, LCS(i + t, c + t) = LCS(i, c) + t (up to the cap)
-    uint2 r = make_uint2(0, 0);
+    uint32_t r = 0;
     {
+        constexpr uint32_t BW_CALC = 16;   // two 8-byte steps; stored as min(.., BCAP)
         const uint32_t bd = best_len ? i - best_idx : NONE;
         const uint32_t bd_lo = __shfl_up(bd, 1);
         const bool bfol = best_len != 0 && lane > 0 && bd_lo == bd;
-        const uint32_t bmax = best_idx < BCAP ? best_idx : BCAP;
+        const uint32_t bmax = best_idx < BW_CALC ? best_idx : BW_CALC;
         uint32_t bw = 0;
         if (best_len && !bfol) {
-            // lcs_bwd with this position's side read from the window (8 bytes per step, at most BCAP = 32 back)
+            // lcs_bwd with this position's side read from the window (8 bytes per step, at most 16 back)
             uint32_t len = 0;
             bool open = true;
             while (open && len + 8 <= bmax) {
@@ -532,15 +533,13 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
             if (bfol) { bw = hb + (uint32_t)(lane - h); if (bw > bmax) bw = bmax; }
         }
         if (valid) {
-            if (best_len) {
-                r.x = (i - best_idx) | (bw << 18) | (capped ? REC_CAPPED : 0u);
-                r.y = best_len;
-            }
+            // (a length that stopped at the cap is stored as FCAP; one that ends at FCAP exactly is asked for again: harmless)
+            if (best_len) r = rec_make(i - best_idx, capped ? FCAP : best_len, bw < BCAP ? bw : BCAP);
             rec[tl.pos_base + i] = r;
         }
     }
     // has-match bitmap: tile starts are multiples of 64, so a wave covers exactly one word
-    const uint64_t bits = __ballot(valid && r.y != 0);
+    const uint64_t bits = __ballot(valid && r != 0);
     // (words past the stream's last position belong to the next stream: never touch them)
     if (lane == 0 && i < tl.start + TILE_POS && i < n_pos) bitmap[(tl.pos_base + i) >> 6] = bits;
 }
@@ -562,7 +561,7 @@ void launch_enc_link(const EncStream *streams, const EncTile *tiles, uint32_t n_
                        fcount);
 }
 
-void launch_enc_cand(const uint8_t *src, const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, const uint32_t *prev, uint2 *rec,
+void launch_enc_cand(const uint8_t *src, const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, const uint32_t *prev, uint32_t *rec,
                      uint64_t *bitmap, hipStream_t st) {
     if (!n_tiles) return;
     hipLaunchKernelGGL(enc_cand_kernel, dim3(((n_tiles + 7) / 8) * 8 * CAND_BPT), dim3(256), 0, st, src, streams, tiles, n_tiles, prev, rec, bitmap);

@@ -141,7 +141,7 @@ __device__ uint32_t st_wave_lcs_bwd(const uint8_t *s, uint32_t a, uint32_t b, ui
 // record is capped can have its exact lengths computed by the whole wave (one request at a time).
 __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
                                                       const uint2 *__restrict__ segs, uint32_t n_segs,
-                                                      const uint32_t *__restrict__ prev, const uint2 *__restrict__ rec,
+                                                      const uint32_t *__restrict__ prev, const uint32_t *__restrict__ rec,
                                                       const uint64_t *__restrict__ bitmap, SpecEvent *__restrict__ logs,
                                                       SpecHeader *__restrict__ hdrs) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict_
     const uint32_t end = es.n - 3;
     const uint32_t S = sg.y * SEG;
     const uint32_t stop = exists ? ((S + SEG + OVER < end) ? S + SEG + OVER : end) : 0;
-    const uint2 *r = rec + es.pos_base;
+    const uint32_t *r = rec + es.pos_base;
     const uint64_t *bm = bitmap + (es.pos_base >> 6);
     SpecEvent *ev = logs + (uint64_t)g * SEG_EV_CAP;
     const int lane = e_lane();
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict_
     bool running = exists && st.index < stop;
     while (__any(running)) {
         uint32_t p = 0;
-        uint2 rr = make_uint2(0, 0);
+        uint32_t rr = 0;
         bool have = false;
         if (running) {
             // the two bitmap words at the walker's position are kept in registers and refreshed together with
@@ -187,10 +187,10 @@ __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict_
                 if ((p >> 6) != cw) { cw = p >> 6; w0 = bm[cw]; w1 = bm[cw + 1]; }
             }
         }
-        uint32_t dist = rr.x & 0x3FFFF, bw = (rr.x >> 18) & 0xFF, fwd = rr.y;
+        uint32_t dist = rec_dist(rr), bw = rec_bwd(rr), fwd = rec_fwd(rr);
         uint32_t midx = p - dist;
         // ---- exact re-evaluation of capped records, one requesting lane at a time, by the whole wave ----
-        uint64_t req = __ballot(have && (rr.x & REC_CAPPED));
+        uint64_t req = __ballot(have && fwd == FCAP);
         while (req) {
             const int L = __builtin_ctzll(req);
             req &= req - 1;
@@ -344,7 +344,7 @@ __device__ __forceinline__ void sx_gap_event(Stitch &x, uint32_t lit_before, uin
 // One wave per stream; control flow and values are wave-uniform.
 __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
                                                         uint32_t n_streams, const uint32_t *__restrict__ prev,
-                                                        const uint2 *__restrict__ rec, const uint64_t *__restrict__ bitmap,
+                                                        const uint32_t *__restrict__ rec, const uint64_t *__restrict__ bitmap,
                                                         const SpecEvent *__restrict__ logs, const SpecHeader *__restrict__ hdrs,
                                                         const uint4 *__restrict__ sync, RangeRec *__restrict__ ranges,
                                                         MatchRec *__restrict__ gaps, EncStreamOut *__restrict__ outs) {
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
     const EncStream &es = streams[si];
     const uint8_t *s = src + es.src_off;
     const uint32_t *pv = prev + es.pos_base;
-    const uint2 *r = rec + es.pos_base;
+    const uint32_t *r = rec + es.pos_base;
     const uint64_t *bm = bitmap + (es.pos_base >> 6);
     const uint32_t n = es.n, end = n - 3, K = es.n_seg;
     const SpecEvent *L0 = logs + (uint64_t)es.seg_base * SEG_EV_CAP;
@@ -434,10 +434,10 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
         if (p >= end) { T.index = end; done = true; break; }
         st_iters++;
         T.index = p;
-        const uint2 rr = r[p];
-        uint32_t dist = rr.x & 0x3FFFF, bw = (rr.x >> 18) & 0xFF, fwd = rr.y;
+        const uint32_t rr = r[p];
+        uint32_t dist = rec_dist(rr), bw = rec_bwd(rr), fwd = rec_fwd(rr);
         uint32_t midx = p - dist;
-        if (rr.x & REC_CAPPED) {
+        if (fwd == FCAP) {
             // exact forward part of find_match (frontend_bytes.rs:214-231) by the whole wave
             uint32_t v = ld_u32(s + p), best_len = 0, best_idx = 0, c = p, d = link_dist(pv[p]);
             for (int q = 0; q < 4 && d != 0; q++) {
@@ -856,13 +856,13 @@ __global__ __launch_bounds__(256) void enc_lmd_kernel(const EncStream *__restric
 // ------------------------------------------------------------------------------------ launchers
 
 void launch_enc_spec(const uint8_t *src, const EncStream *streams, const uint2 *segs, uint32_t n_segs, const uint32_t *prev,
-                     const uint2 *rec, const uint64_t *bitmap, SpecEvent *logs, SpecHeader *hdrs, hipStream_t st) {
+                     const uint32_t *rec, const uint64_t *bitmap, SpecEvent *logs, SpecHeader *hdrs, hipStream_t st) {
     if (!n_segs) return;
     hipLaunchKernelGGL(enc_spec_kernel, dim3((n_segs + 63) / 64), dim3(64), 0, st, src, streams, segs, n_segs, prev, rec, bitmap, logs,
                        hdrs);
 }
 void launch_enc_stitch(const uint8_t *src, const EncStream *streams, uint32_t ns, const uint2 *segs, uint32_t n_segs, const uint32_t *prev,
-                       const uint2 *rec, const uint64_t *bitmap, const SpecEvent *logs, const SpecHeader *hdrs, uint4 *sync,
+                       const uint32_t *rec, const uint64_t *bitmap, const SpecEvent *logs, const SpecHeader *hdrs, uint4 *sync,
                        RangeRec *ranges, MatchRec *gaps, EncStreamOut *outs, hipStream_t st) {
     hipLaunchKernelGGL(enc_sync_kernel, dim3((n_segs + 63) / 64), dim3(64), 0, st, streams, segs, n_segs, logs, hdrs, sync);
     hipLaunchKernelGGL(enc_stitch_kernel, dim3(ns), dim3(64), 0, st, src, streams, ns, prev, rec, bitmap, logs, hdrs, sync, ranges, gaps,

@@ -1,0 +1,39 @@
+"""Encode throughput on highly repetitive inputs (device-resident batches): the inputs on which capped candidate records
+make the segment walkers ask for exact lengths most often.   python scripts/repetitive_bench.py"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import lzfse_rust_amd as lz
+ctx = lz.Context(0)
+dev = torch.device("cuda", 0)
+rng = np.random.default_rng(3)
+
+def periodic(per, n, mut):
+    chunk = rng.integers(0, 256, size=per, dtype=np.uint8)
+    a = np.tile(chunk, n // per + 1)[:n].copy()
+    if mut:
+        idx = rng.integers(0, n, size=n // mut)
+        a[idx] ^= rng.integers(1, 256, size=idx.size, dtype=np.uint8)
+    return a
+
+cases = [("period 300", lambda: periodic(300, 1 << 20, 0)), ("period 1100", lambda: periodic(1100, 1 << 20, 0)),
+         ("period 1100, 1 change per 700 B", lambda: periodic(1100, 1 << 20, 700)), ("period 40, 1 change per 60 B", lambda: periodic(40, 1 << 20, 60)),
+         ("period 5000, 1 change per 300 B", lambda: periodic(5000, 1 << 20, 300)), ("period 250000", lambda: periodic(250000, 1 << 20, 0)),
+         ("zeros", lambda: np.zeros(1 << 20, dtype=np.uint8))]
+for name, gen in cases:
+    parts = [gen() for _ in range(4)] * 64          # 256 streams of 1 MiB
+    n = parts[0].size
+    src = torch.from_numpy(np.concatenate(parts)).to(dev)
+    bound = (lz.encode_bound(n) + 255) & ~255
+    dst = torch.empty(bound * len(parts), dtype=torch.uint8, device=dev)
+    so = np.arange(len(parts), dtype=np.uint64) * n
+    sl = np.full(len(parts), n, dtype=np.uint64)
+    do = np.arange(len(parts), dtype=np.uint64) * bound
+    dc = np.full(len(parts), bound, dtype=np.uint64)
+    ctx.encode_batch_device(src.data_ptr(), so, sl, dst.data_ptr(), do, dc)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ol, st = ctx.encode_batch_device(src.data_ptr(), so, sl, dst.data_ptr(), do, dc)
+    t1 = time.perf_counter()
+    assert all(int(e) == 0 for e in st)
+    print(f"{name:34s} encode {src.numel() / (t1 - t0) / 1e9:6.2f} GB/s, ratio {src.numel() / float(sum(int(x) for x in ol)):.0f}")

@@ -81,7 +81,7 @@ def test_candidate_stage_matches_oracle(diag_ctx, oracle, snappy_raw):
         assert (fwd[exact] == fl[exact]).all(), name
         has = exact & (fl > 0)
         assert ((idx[has] - dist[has]) == mi[has]).all(), name
-        assert (fwd[capped] >= 1024).all() and (fl[capped] >= 1024).all(), name
+        assert (fwd[capped] == 1023).all() and (fl[capped] >= 1023).all(), name   # FCAP: "at least 1023"
 
 
 def test_encode_bit_exact_snappy(ctx, oracle, snappy_raw):
