@@ -587,6 +587,18 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
 
 // ------------------------------------------------------------------------------------ LZ stage
 
+// exactly n <= 24 bytes, given as three little-endian words, to byte-aligned LDS in at most five stores of 8 / 8 / 4 / 2 / 1 bytes
+// (gfx950 runs LDS in unaligned access mode; a byte loop costs the wave its longest run in iterations)
+__device__ __forceinline__ void lds_put24(uint8_t *q, uint32_t n, uint64_t w0, uint64_t w1, uint64_t w2) {
+    uint64_t cur = w0;
+    if (n >= 8) { __builtin_memcpy(q, &w0, 8); q += 8; cur = w1; }
+    if (n >= 16) { __builtin_memcpy(q, &w1, 8); q += 8; cur = w2; }
+    if (n == 24) { __builtin_memcpy(q, &w2, 8); return; }
+    if (n & 4) { const uint32_t c4 = (uint32_t)cur; __builtin_memcpy(q, &c4, 4); q += 4; cur >>= 32; }
+    if (n & 2) { const uint16_t c2 = (uint16_t)cur; __builtin_memcpy(q, &c2, 2); q += 2; cur >>= 16; }
+    if (n & 1) *q = (uint8_t)cur;
+}
+
 template <int NT>
 __device__ __forceinline__ void block_excl_scan2(uint32_t a, uint32_t b, uint32_t &ea, uint32_t &eb,
                                                  uint32_t &ta, uint32_t &tb, uint32_t *sh /* 2 * NT/64 + 2 */) {
@@ -808,11 +820,8 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
                         // three 8-byte loads in flight, then byte stores into the tile (the literal
                         // scratch has 256 bytes of slack behind its last byte)
                         const uint8_t *ls = blit + lit_run + ex_l;
-                        uint64_t w0 = ld_u64(ls), w1 = l > 8 ? ld_u64(ls + 8) : 0, w2 = l > 16 ? ld_u64(ls + 16) : 0;
-                        for (uint32_t k = 0; k < l; k++) {
-                            uint64_t w = k < 8 ? w0 : (k < 16 ? w1 : w2);
-                            t[ex_s + k] = (uint8_t)(w >> (8 * (k & 7)));
-                        }
+                        const uint64_t w0 = ld_u64(ls), w1 = l > 8 ? ld_u64(ls + 8) : 0, w2 = l > 16 ? ld_u64(ls + 16) : 0;
+                        lds_put24(t + ex_s, l, w0, w1, w2);
                     } else lit_long = true;
                 }
                 if (m) {
@@ -822,11 +831,8 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
                         if (m <= SHORT_COPY) {
                             const uint8_t *ms = dst + (p_match - dd);
                             if (p_match - dd + 24 <= tile_base) {  // 24 readable bytes of finished output
-                                uint64_t w0 = ld_u64(ms), w1 = m > 8 ? ld_u64(ms + 8) : 0, w2 = m > 16 ? ld_u64(ms + 16) : 0;
-                                for (uint32_t k = 0; k < m; k++) {
-                                    uint64_t w = k < 8 ? w0 : (k < 16 ? w1 : w2);
-                                    t[ex_s + l + k] = (uint8_t)(w >> (8 * (k & 7)));
-                                }
+                                const uint64_t w0 = ld_u64(ms), w1 = m > 8 ? ld_u64(ms + 8) : 0, w2 = m > 16 ? ld_u64(ms + 16) : 0;
+                                lds_put24(t + ex_s + l, m, w0, w1, w2);
                             } else {
                                 for (uint32_t k = 0; k < m; k++) t[ex_s + l + k] = ms[k];
                             }
