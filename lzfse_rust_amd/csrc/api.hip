@@ -108,7 +108,7 @@ struct lzfse_mi_ctx {
     // batch descriptors / results
     DevBuf d_streams, d_walk, d_plan, d_blocks, d_bres, d_sres;
     // decode scratch
-    DevBuf d_lmds, d_lits, d_origin, d_jerr, d_wcache;
+    DevBuf d_lmds, d_lits, d_origin, d_jerr, d_wcache, d_fwalk;
     // encode scratch (encode.hip)
     EncScratch enc;
     // host-pointer API staging
@@ -134,7 +134,7 @@ struct lzfse_mi_ctx {
     // lzfse_mi_set_option
     int opt_lanes_enc = 0, opt_lanes_dec = 0;  // sub-batches run side by side (0: chosen by size, 1: one)
     int opt_stagger = 0;
-    int diag_lz_jump = -1, diag_lz_variant = -1, diag_stats = 0, diag_chain = 0;  // diagnostic build only
+    int diag_lz_jump = -1, diag_lz_variant = -1, diag_stats = 0, diag_chain = 0, diag_walk = 0;  // diagnostic build only
 
     hipEvent_t get_event() {
         if (ev_used == ev_pool.size()) {
@@ -278,7 +278,7 @@ void lzfse_mi_destroy(lzfse_mi_ctx *c) {
     for (auto &g : c->gates) if (g.ev) (void)hipEventDestroy(g.ev);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->d_streams, &c->d_walk, &c->d_plan, &c->d_blocks, &c->d_bres, &c->d_sres,
-                      &c->d_lmds, &c->d_lits, &c->d_origin, &c->d_jerr, &c->d_wcache, &c->d_in, &c->d_out, &c->d_small})
+                      &c->d_lmds, &c->d_lits, &c->d_origin, &c->d_jerr, &c->d_wcache, &c->d_fwalk, &c->d_in, &c->d_out, &c->d_small})
         b->release();
     enc_scratch_release(c->enc);
     c->h_in.release();
@@ -410,11 +410,31 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
         !c->d_plan.ensure(ns * sizeof(StreamPlan)) || !c->d_sres.ensure(ns * sizeof(StreamResult)))
         return LZFSE_MI_IO;
     HIP_TRY(hipMemcpyAsync(c->d_streams.p, h_streams.data(), ns * sizeof(StreamIn), hipMemcpyHostToDevice, st));
-    // pass 1: count
+    // pass 1: count. Streams of 8 MiB and more (hundreds of blocks: the serial walk pays a round trip per block) first go
+    // through the parallel walk; what it cannot settle (and every smaller stream) is walked serially, one thread per stream.
     {
         StageTimer t(c, "dec_walk");
+        std::vector<uint32_t> elig;
+        uint64_t max_len = 0;
+        const uint64_t fw_min = c->diag_walk == 1 ? 0ull : (8ull << 20);
+        if (c->diag_walk != 2)
+            for (uint32_t i = 0; i < ns && elig.size() < 4096; i++)
+                if (src_len[i] >= fw_min && src_len[i] >= 36 && src_len[i] < 0xFFFFFFF0ull) { elig.push_back(i); max_len = std::max<uint64_t>(max_len, src_len[i]); }
+        const uint32_t *d_settled = nullptr;
+        if (!elig.empty()) {
+            const size_t ne = elig.size();
+            // layout: settled[ns] | count[ne] | elig[ne] | cand[ne * cap] (8-byte aligned)
+            const size_t head = ((size_t)ns + 2 * ne + 1) & ~(size_t)1;
+            if (!c->d_fwalk.ensure(head * 4 + ne * lzmi::fastwalk_cap() * sizeof(uint2))) return LZFSE_MI_IO;
+            uint32_t *fw = (uint32_t *)c->d_fwalk.p;
+            HIP_TRY(hipMemsetAsync(fw, 0, ((size_t)ns + ne) * 4, st));
+            HIP_TRY(hipMemcpyAsync(fw + ns + ne, elig.data(), ne * 4, hipMemcpyHostToDevice, st));
+            launch_dec_fastwalk((const uint8_t *)d_src, (const StreamIn *)c->d_streams.p, fw + ns + ne, (uint32_t)ne, max_len, fw + ns,
+                                (uint2 *)(fw + head), (StreamWalk *)c->d_walk.p, (BlockDesc *)c->d_wcache.p, fw, st);
+            d_settled = fw;
+        }
         launch_dec_walk(false, (const uint8_t *)d_src, (const StreamIn *)c->d_streams.p, ns,
-                        (StreamWalk *)c->d_walk.p, nullptr, (BlockDesc *)c->d_wcache.p, st);
+                        (StreamWalk *)c->d_walk.p, nullptr, (BlockDesc *)c->d_wcache.p, d_settled, st);
     }
     std::vector<StreamWalk> h_walk(ns);
     HIP_TRY(hipMemcpyAsync(h_walk.data(), c->d_walk.p, ns * sizeof(StreamWalk), hipMemcpyDeviceToHost, st));
@@ -480,7 +500,7 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
         for (uint32_t i = 0; i < ns; i++) rewalk |= !h_plan[i].skip && h_plan[i].n_blocks > h_streams[i].cache_cap;
         if (rewalk)
             launch_dec_walk(true, (const uint8_t *)d_src, (const StreamIn *)c->d_streams.p, ns, nullptr,
-                            (const StreamPlan *)c->d_plan.p, (BlockDesc *)c->d_blocks.p, st);
+                            (const StreamPlan *)c->d_plan.p, (BlockDesc *)c->d_blocks.p, nullptr, st);
     }
     {
         StageTimer t(c, "dec_fse");
@@ -656,7 +676,7 @@ static int split_batch(lzfse_mi_ctx *c, batch_dev_fn one, int lanes, bool stagge
         ok = hipStreamWaitEvent(c->shadow[k]->stream, c->split_ev, 0) == hipSuccess;
         c->shadow[k]->timing = c->timing;
         c->shadow[k]->diag_lz_jump = c->diag_lz_jump; c->shadow[k]->diag_lz_variant = c->diag_lz_variant;
-        c->shadow[k]->diag_stats = c->diag_stats; c->shadow[k]->diag_chain = c->diag_chain;
+        c->shadow[k]->diag_stats = c->diag_stats; c->shadow[k]->diag_chain = c->diag_chain; c->shadow[k]->diag_walk = c->diag_walk;
     }
     if (!ok) return unsplit();
     // staggered start (encode): lane k + 1 begins when lane k has queued its candidate kernel
@@ -734,11 +754,13 @@ int lzfse_mi_set_option(lzfse_mi_ctx *c, int option, int64_t value) {
     case LZFSE_MI_OPT_DIAG_LZ_TILE: c->diag_lz_variant = (int)value; return LZFSE_MI_OK;
     case LZFSE_MI_OPT_DIAG_STATS: c->diag_stats = (int)value; return LZFSE_MI_OK;
     case LZFSE_MI_OPT_DIAG_CHAIN: c->diag_chain = (int)value; return LZFSE_MI_OK;
+    case LZFSE_MI_OPT_DIAG_WALK: c->diag_walk = (int)value; return LZFSE_MI_OK;
 #else
     case LZFSE_MI_OPT_DIAG_LZ_PATH:
     case LZFSE_MI_OPT_DIAG_LZ_TILE:
     case LZFSE_MI_OPT_DIAG_STATS:
-    case LZFSE_MI_OPT_DIAG_CHAIN: return LZFSE_MI_UNSUPPORTED;
+    case LZFSE_MI_OPT_DIAG_CHAIN:
+    case LZFSE_MI_OPT_DIAG_WALK: return LZFSE_MI_UNSUPPORTED;
 #endif
     default: return LZFSE_MI_BAD_ARGUMENT;
     }

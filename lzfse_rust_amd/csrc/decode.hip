@@ -55,10 +55,12 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 template <bool EMIT>
 __global__ void dec_walk_kernel(const uint8_t *__restrict__ src, const StreamIn *__restrict__ streams,
                                 uint32_t n_streams, StreamWalk *__restrict__ walk,
-                                const StreamPlan *__restrict__ plan, BlockDesc *__restrict__ blocks) {
+                                const StreamPlan *__restrict__ plan, BlockDesc *__restrict__ blocks,
+                                const uint32_t *__restrict__ settled) {
     __shared__ BlockDesc stage[EMIT ? 1 : 64][EMIT ? 1 : 8];
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_streams) return;
+    if (!EMIT && settled && settled[s]) return;   // walked by dec_rank_kernel
     if (EMIT && (plan[s].skip || plan[s].n_blocks <= streams[s].cache_cap)) return;
     const StreamIn in = streams[s];
     const uint8_t *base = src + in.src_off;
@@ -149,6 +151,174 @@ __global__ void dec_walk_kernel(const uint8_t *__restrict__ src, const StreamIn 
         const uint64_t nc = w.n_blocks < in.cache_cap ? w.n_blocks : in.cache_cap;
         for (uint64_t k = nc & ~7ull; k < nc; k++) blocks[in.cache_off + k] = stage[threadIdx.x][k & 7];
         walk[s] = w;
+    }
+}
+
+// ---- Parallel header walk of LARGE streams. The serial walk is a chain of dependent loads, one round trip per block
+// (0.9 us: 0.77 ms for the 860 blocks of a 64 MiB text stream). Instead: every byte position of the stream is tested for
+// the bvx2 magic and a header that validates (dec_scan_kernel; a few false candidates inside payloads do no harm), the
+// candidates are sorted by position, every candidate finds the candidate that starts where it ends, and ONE thread
+// follows that chain from position 0 through LDS (dec_rank_kernel). The result is taken only when the chain runs from
+// position 0 over sound bvx2 blocks to the end-of-stream magic in the stream's last 4 bytes, i.e. when the serial walk
+// would have found exactly these blocks and no error; anything else (another block kind, a damaged or cut block, more
+// candidates or blocks than fit) leaves the stream to the serial walk, whose statuses are the reference's. ----
+constexpr uint32_t FW_CAP = 4096;       // candidates per stream
+constexpr uint32_t FW_SCAN_BYTES = 4096; // bytes per scan workgroup (256 threads x 16)
+
+__global__ __launch_bounds__(256) void dec_scan_kernel(const uint8_t *__restrict__ src, const StreamIn *__restrict__ streams,
+                                                       const uint32_t *__restrict__ elig, uint32_t *__restrict__ count,
+                                                       uint2 *__restrict__ cand) {
+    const uint32_t e = blockIdx.y, s = elig[e];
+    const StreamIn in = streams[s];
+    const uint64_t n = in.src_len;
+    const uint64_t q0 = (uint64_t)blockIdx.x * FW_SCAN_BYTES + (uint64_t)threadIdx.x * 16;
+    if (q0 >= n) return;
+    const uint8_t *base = src + in.src_off;
+    // 19 bytes cover the 16 magic positions of this thread
+    uint64_t lo8, hi8, top4;
+    if (q0 + 20 <= n) { lo8 = ld_u64(base + q0); hi8 = ld_u64(base + q0 + 8); top4 = ld_u32(base + q0 + 16); }
+    else {
+        lo8 = hi8 = top4 = 0;
+        for (int k = 0; k < 19; k++) {
+            const uint64_t v = q0 + k < n ? base[q0 + k] : 0;
+            if (k < 8) lo8 |= v << (8 * k); else if (k < 16) hi8 |= v << (8 * (k - 8)); else top4 |= v << (8 * (k - 16));
+        }
+    }
+    for (int k = 0; k < 16; k++) {
+        // bytes k .. k + 3 of the 19
+        const uint64_t a = k < 8 ? lo8 : hi8, b2 = k < 8 ? hi8 : top4;
+        const int sh = 8 * (k & 7);
+        const uint32_t magic = (uint32_t)(sh ? (a >> sh) | (b2 << (64 - sh)) : a);
+        if (magic != MAGIC_VX2) continue;
+        const uint64_t q = q0 + k;
+        if (q + V2_HEADER_SIZE > n) continue;
+        FseHeader h;
+        if (fse_parse_v2(ld_u64(base + q), ld_u64(base + q + 8), ld_u64(base + q + 16), ld_u64(base + q + 24), h)) continue;
+        const uint64_t total = (uint64_t)h.hdr_size + h.lit_payload + h.lmd_payload;
+        if (q + total + 4 > n) continue;   // a block of the chain is followed by at least the end-of-stream magic
+        const uint32_t slot = atomicAdd(&count[e], 1u);
+        if (slot < FW_CAP) cand[(uint64_t)e * FW_CAP + slot] = make_uint2((uint32_t)q, (uint32_t)total);
+    }
+}
+
+__global__ __launch_bounds__(1024) void dec_rank_kernel(const uint8_t *__restrict__ src, const StreamIn *__restrict__ streams,
+                                                        const uint32_t *__restrict__ elig, const uint32_t *__restrict__ count,
+                                                        const uint2 *__restrict__ cand, StreamWalk *__restrict__ walk,
+                                                        BlockDesc *__restrict__ cache, uint32_t *__restrict__ settled) {
+    __shared__ uint64_t key[FW_CAP];      // position << 32 | length, sorted; later: n_lmd << 32 | n_lit of the chain's blocks
+    __shared__ uint32_t aux[FW_CAP];      // next candidate of each candidate; later: n_raw of the chain's blocks
+    __shared__ uint16_t order[FW_CAP];    // candidates in chain order
+    __shared__ uint32_t sh_n;
+    __shared__ uint64_t sh_scan[3][16];
+    const uint32_t e = blockIdx.x, s = elig[e];
+    const int tid = threadIdx.x;
+    const StreamIn in = streams[s];
+    const uint32_t n = count[e];
+    if (n == 0 || n > FW_CAP || in.src_len > 0xFFFFFFF0ull) return;   // settled[s] stays 0: serial walk
+    const uint8_t *base = src + in.src_off;
+    uint32_t np2 = 64;                    // sort size: the power of two that holds the candidates
+    while (np2 < n) np2 <<= 1;
+    for (uint32_t i = tid; i < np2; i += 1024) {
+        const uint2 c = i < n ? cand[(uint64_t)e * FW_CAP + i] : make_uint2(0xFFFFFFFFu, 0u);
+        key[i] = ((uint64_t)c.x << 32) | c.y;
+    }
+    __syncthreads();
+    // bitonic sort (positions are distinct)
+    for (uint32_t k = 2; k <= np2; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < np2; i += 1024) {
+                const uint32_t ixj = i ^ j;
+                if (ixj > i) {
+                    const uint64_t a = key[i], b = key[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { key[i] = b; key[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // next candidate: the one that starts where this one ends; 0xFFFF: the end-of-stream magic in the last 4 bytes; 0xFFFE: none
+    for (uint32_t i = tid; i < n; i += 1024) {
+        const uint64_t kv = key[i];
+        const uint64_t target = (kv >> 32) + (uint32_t)kv;
+        uint32_t nx = 0xFFFEu;
+        if (target + 4 == in.src_len) { if (ld_u32(base + target) == MAGIC_EOS) nx = 0xFFFFu; }
+        else {
+            uint32_t lo = 0, hi = n;   // first candidate with position >= target
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((key[mid] >> 32) < target) lo = mid + 1; else hi = mid; }
+            if (lo < n && (key[lo] >> 32) == target) nx = lo;
+        }
+        aux[i] = nx;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t r = 0, i = 0;
+        bool ok = (key[0] >> 32) == 0;
+        while (ok) {
+            if (r >= n) { ok = false; break; }
+            order[r++] = (uint16_t)i;
+            const uint32_t nx = aux[i];
+            if (nx == 0xFFFFu) break;
+            if (nx == 0xFFFEu) { ok = false; break; }
+            i = nx;
+        }
+        sh_n = (ok && r <= in.cache_cap) ? r : 0u;
+    }
+    __syncthreads();
+    const uint32_t nb = sh_n;
+    if (nb == 0) return;
+    // the chain's blocks: counts from their headers, exclusive prefix sums in block order, descriptors into the walk cache
+    uint32_t my_pos[FW_CAP / 1024];
+    for (uint32_t q = 0; q < FW_CAP / 1024; q++) {
+        const uint32_t r = tid * (FW_CAP / 1024) + q;
+        my_pos[q] = r < nb ? (uint32_t)(key[order[r]] >> 32) : 0u;
+    }
+    __syncthreads();
+    uint64_t run_lmd = 0, run_lit = 0, run_raw = 0;
+    uint32_t v_lmd[FW_CAP / 1024], v_lit[FW_CAP / 1024], v_raw[FW_CAP / 1024];
+    for (uint32_t q = 0; q < FW_CAP / 1024; q++) {
+        const uint32_t r = tid * (FW_CAP / 1024) + q;
+        v_lmd[q] = 0; v_lit[q] = 0; v_raw[q] = 0;
+        if (r < nb) {
+            FseHeader h;
+            const uint8_t *hp = base + my_pos[q];
+            (void)fse_parse_v2(ld_u64(hp), ld_u64(hp + 8), ld_u64(hp + 16), ld_u64(hp + 24), h);   // validated by the scan
+            v_lmd[q] = h.lmd_num; v_lit[q] = h.lit_num; v_raw[q] = h.n_raw;
+        }
+        run_lmd += v_lmd[q]; run_lit += v_lit[q]; run_raw += v_raw[q];
+    }
+    // block-wide exclusive scan of the per-thread sums (1024 threads: 16 waves)
+    uint64_t il = run_lmd, it = run_lit, ir = run_raw;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        const uint64_t a = __shfl_up(il, dd), b2 = __shfl_up(it, dd), c2 = __shfl_up(ir, dd);
+        if (lane >= dd) { il += a; it += b2; ir += c2; }
+    }
+    if (lane == 63) { sh_scan[0][wave] = il; sh_scan[1][wave] = it; sh_scan[2][wave] = ir; }
+    __syncthreads();
+    uint64_t ol = 0, ot = 0, orr = 0, tl = 0, tt = 0, tr = 0;
+    for (int wv = 0; wv < 16; wv++) {
+        const uint64_t a = sh_scan[0][wv], b2 = sh_scan[1][wv], c2 = sh_scan[2][wv];
+        if (wv < wave) { ol += a; ot += b2; orr += c2; }
+        tl += a; tt += b2; tr += c2;
+    }
+    uint64_t ex_lmd = ol + il - run_lmd, ex_lit = ot + it - run_lit, ex_raw = orr + ir - run_raw;
+    for (uint32_t q = 0; q < FW_CAP / 1024; q++) {
+        const uint32_t r = tid * (FW_CAP / 1024) + q;
+        if (r < nb) {
+            BlockDesc d;
+            d.src_pos = in.src_off + my_pos[q]; d.src_end = in.src_off + in.src_len; d.dst_rel = ex_raw;
+            d.lmd_base = ex_lmd; d.lit_base = ex_lit; d.stream = s; d.kind = KIND_VX2;
+            d.n_lmd = v_lmd[q]; d.n_lit = v_lit[q]; d.n_raw = v_raw[q]; d.payload = 0;
+            cache[in.cache_off + r] = d;
+        }
+        ex_lmd += v_lmd[q]; ex_lit += v_lit[q]; ex_raw += v_raw[q];
+    }
+    if (tid == 0) {
+        StreamWalk w;
+        w.n_lmds = tl; w.n_lits = tt; w.raw_total = tr; w.n_blocks = nb; w.status = 0; w.err_block = 0; w.n_vxn = 0; w.detail = 0; w.pad = 0;
+        walk[s] = w;
+        settled[s] = 1;
     }
 }
 
@@ -1117,10 +1287,22 @@ __global__ void dec_jump_finish_kernel(const StreamPlan *__restrict__ plan, cons
 // ------------------------------------------------------------------------------------ launchers
 
 void launch_dec_walk(bool emit, const uint8_t *src, const StreamIn *streams, uint32_t n_streams,
-                     StreamWalk *walk, const StreamPlan *plan, BlockDesc *blocks, hipStream_t st) {
+                     StreamWalk *walk, const StreamPlan *plan, BlockDesc *blocks, const uint32_t *settled, hipStream_t st) {
     dim3 grid((n_streams + 63) / 64), block(64);
-    if (emit) hipLaunchKernelGGL(dec_walk_kernel<true>, grid, block, 0, st, src, streams, n_streams, walk, plan, blocks);
-    else hipLaunchKernelGGL(dec_walk_kernel<false>, grid, block, 0, st, src, streams, n_streams, walk, plan, blocks);
+    if (emit) hipLaunchKernelGGL(dec_walk_kernel<true>, grid, block, 0, st, src, streams, n_streams, walk, plan, blocks, settled);
+    else hipLaunchKernelGGL(dec_walk_kernel<false>, grid, block, 0, st, src, streams, n_streams, walk, plan, blocks, settled);
+}
+
+uint32_t fastwalk_cap() { return FW_CAP; }
+
+// parallel walk of the n_elig streams listed in `elig` (max_len: the longest of them); count: n_elig zeroed words;
+// cand: n_elig * fastwalk_cap() entries; settled: one zeroed word per stream of the batch
+void launch_dec_fastwalk(const uint8_t *src, const StreamIn *streams, const uint32_t *elig, uint32_t n_elig, uint64_t max_len,
+                         uint32_t *count, uint2 *cand, StreamWalk *walk, BlockDesc *cache, uint32_t *settled, hipStream_t st) {
+    if (!n_elig) return;
+    hipLaunchKernelGGL(dec_scan_kernel, dim3((uint32_t)((max_len + FW_SCAN_BYTES - 1) / FW_SCAN_BYTES), n_elig), dim3(256), 0, st, src, streams,
+                       elig, count, cand);
+    hipLaunchKernelGGL(dec_rank_kernel, dim3(n_elig), dim3(1024), 0, st, src, streams, elig, count, cand, walk, cache, settled);
 }
 
 void launch_dec_emit(const StreamIn *streams, uint32_t n_streams, const StreamPlan *plan, const BlockDesc *cache, uint64_t cache_total,

@@ -42,7 +42,10 @@ int ctx_diag_chain(lzfse_mi_ctx *c);  // LZFSE_MI_OPT_DIAG_CHAIN: 1 = every chai
 
 // ---- decode.hip ----
 void launch_dec_walk(bool emit, const uint8_t *src, const StreamIn *streams, uint32_t n_streams,
-                     StreamWalk *walk, const StreamPlan *plan, BlockDesc *blocks, hipStream_t st);
+                     StreamWalk *walk, const StreamPlan *plan, BlockDesc *blocks, const uint32_t *settled, hipStream_t st);
+uint32_t fastwalk_cap();
+void launch_dec_fastwalk(const uint8_t *src, const StreamIn *streams, const uint32_t *elig, uint32_t n_elig, uint64_t max_len,
+                         uint32_t *count, uint2 *cand, StreamWalk *walk, BlockDesc *cache, uint32_t *settled, hipStream_t st);
 void launch_dec_emit(const StreamIn *streams, uint32_t n_streams, const StreamPlan *plan, const BlockDesc *cache, uint64_t cache_total,
                      BlockDesc *blocks, hipStream_t st);
 void launch_dec_fse(const uint8_t *src, uint64_t src_total, const BlockDesc *blocks, uint32_t n_blocks,

@@ -1,5 +1,5 @@
 """One-off randomised parity campaign on a GPU box (not part of the test-suite: the suite's cases are fixed):
-    python scripts/fuzz_gpu.py [ROUNDS] [SEED]
+    python scripts/fuzz_gpu.py [ROUNDS] [SEED] [walk]      (walk: the diagnostic build, every stream through the parallel header walk first)
 Every round: ~120 streams of random structure and length (4 097 B .. 3 MiB, some at tile edges) are encoded by the device
 and compared with the CPU restatement's bytes, decoded back, and a damaged copy of every stream (one byte changed, or cut
 short) is decoded by both with the status codes and lengths compared."""
@@ -13,7 +13,11 @@ import oracle_py
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 O = oracle_py.Oracle()
-ctx = lz.Context(0)
+if len(sys.argv) > 3 and sys.argv[3] == "walk":
+    ctx = lz.Context(0, diag=True)
+    ctx.set_option("diag_walk", 1)
+else:
+    ctx = lz.Context(0)
 rng = np.random.default_rng(seed)
 words = [bytes(rng.integers(97, 123, size=int(rng.integers(1, 12)), dtype=np.uint8)) for _ in range(800)]
 TILE = 65472

@@ -105,6 +105,58 @@ def test_decode_capacity_too_small(ctx, oracle, snappy_raw):
     assert st[0] == 6
 
 
+def test_parallel_header_walk_matches_serial(diag_ctx, oracle, golden_dir, snappy_raw):
+    """Large streams have their block headers found by a magic scan + chain ranking instead of the serial walk; anything
+    that is not a clean run of bvx2 blocks from position 0 to the end-of-stream magic falls back to the serial walk. The
+    diagnostic build sends EVERY stream through the parallel walk first (1) or through the serial walk only (2): fixtures
+    of all block kinds, multi-block streams, payloads that contain the bvx2 magic, damaged and cut streams -- same bytes,
+    same status codes, both equal to the oracle's."""
+    fs = _fixture_files(golden_dir)
+    srcs = [open(f, "rb").read() for f in fs]
+    for k in ("raw", "vx1", "vx2", "vxn"):
+        srcs.append(open(os.path.join(golden_dir, "mutate", k + ".lzfse"), "rb").read())
+    srcs.append(open(os.path.join(golden_dir, "special", "compound.lzfse"), "rb").read())
+    rng = np.random.default_rng(17)
+    magic = b"bvx2" + bytes(rng.integers(0, 256, size=40, dtype=np.uint8))
+    raws = [snappy_raw["lcet10.txt"] * 3, bytes(rng.integers(0, 256, size=600000, dtype=np.uint8)),
+            (magic * 3000) + snappy_raw["html"], b"".join(bytes(rng.integers(0, 256, size=50, dtype=np.uint8)) + b"bvx2bvx$bvxnbvx-" for _ in range(20000))]
+    encs = [oracle.encode(r) for r in raws]
+    srcs += encs
+    big = encs[0]
+    for _ in range(60):      # damaged copies of a multi-block stream
+        m = bytearray(big)
+        if rng.random() < 0.3:
+            m = m[: int(rng.integers(4, len(m)))]
+        else:
+            m[int(rng.integers(0, len(m)))] ^= 1 << int(rng.integers(0, 8))
+        srcs.append(bytes(m))
+    srcs.append(big + b"\0")        # bytes behind the end-of-stream magic
+    srcs.append(big[:-4])            # no end-of-stream magic
+    caps = [max(oracle_cap(oracle, s_), 64) for s_ in srcs]
+    want = [(oracle.decode_status(s_, c_), s_, c_) for s_, c_ in zip(srcs, caps)]
+    got = {}
+    for mode in (1, 2):
+        diag_ctx.set_option("diag_walk", mode)
+        try:
+            got[mode] = diag_ctx.decode_batch(srcs, caps=caps)
+        finally:
+            diag_ctx.set_option("diag_walk", 0)
+    for i, (ws, s_, c_) in enumerate(want):
+        for mode in (1, 2):
+            outs, st = got[mode]
+            assert st[i] == ws, (i, mode, st[i], ws)
+            if ws == 0:
+                assert outs[i].tobytes() == oracle.decode(s_, cap=c_), (i, mode)
+
+
+def oracle_cap(oracle, stream):
+    """Capacity for a possibly damaged stream: what its headers promise, bounded."""
+    try:
+        return min(int(oracle.decode_size(stream)) + 64, 8 << 20)
+    except Exception:
+        return 4 << 20
+
+
 def test_decode_pointer_jumping_path(diag_ctx, oracle, golden_dir, snappy_raw):
     """The LZ stage for large streams (origin pointer jumping) forced on for every stream."""
     fs = _fixture_files(golden_dir)
