@@ -1227,7 +1227,14 @@ __global__ __launch_bounds__(256) void dec_jump_round_kernel(uint32_t *__restric
     if (round > 0 && flags[round - 1] == 0) return;
     bool changed = false;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
+    // Workgroups go to the 8 XCDs round-robin. In one pass of the grid every XCD takes ONE contiguous eighth of the
+    // entries in flight: an origin mostly points a match distance back (a few KB .. 256 KB), so the hops of an XCD's
+    // workgroups land in lines its own L2 already holds, instead of every L2 holding a copy of everything (the grid is a
+    // multiple of 8 workgroups).
+    const uint64_t per_xcd = stride / 8;
+    const uint64_t first = (uint64_t)(blockIdx.x & 7) * per_xcd + (uint64_t)(blockIdx.x >> 3) * blockDim.x + threadIdx.x;
+    for (uint64_t q = first; q < total + stride; q += stride) {
+        if (q >= total) break;
         uint32_t cur = origin[q];
         if (cur & JUMP_FINAL) continue;
         // up to three hops; an entry carrying JUMP_FINAL holds the final byte of its chain (itself for a literal)
@@ -1351,6 +1358,7 @@ void launch_dec_jump(const uint8_t *src, const StreamIn *streams, const StreamPl
     {
         StageTimer t(c, "dec_jump_rounds");
         uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256ull * 16);
+        grid = (grid + 7) & ~7u;   // (dec_jump_round_kernel: eight equal parts)
         // every round collapses chains by 4x (three dependent hops): 4^16 covers any stream below 4 GiB
         for (uint32_t r = 0; r < 17; r++)
             hipLaunchKernelGGL(dec_jump_round_kernel, dim3(grid), dim3(256), 0, st, origin, total, flags, r);
