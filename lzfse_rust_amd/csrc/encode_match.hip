@@ -260,7 +260,10 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
     __shared__ uint32_t q_dist[4][256], q_tab[4][64];  // distance of a head (by slot * 64 + lane); first head per distance hash
     __shared__ uint32_t s_win[4][52];                  // per wave: 192 source bytes around its 64 positions (+ read slack)
     const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const uint32_t t = (slot / CAND_BPT) * 8 + xcd, bx = slot % CAND_BPT;
+    // g: the g-th tile this XCD works on. An XCD takes 8 CONSECUTIVE tiles of every 64: a tile gathers from the up to
+    // four tiles before it (the 262 139-byte window), and those are then the tiles the same L2 has just worked on.
+    const uint32_t g = slot / CAND_BPT, bx = slot % CAND_BPT;
+    const uint32_t t = (g >> 3) * 64 + xcd * 8 + (g & 7);
     if (t >= n_tiles) return;
     const EncTile tl = tiles[t];
     const uint32_t i = tl.start + bx * blockDim.x + threadIdx.x;
@@ -564,7 +567,7 @@ void launch_enc_link(const EncStream *streams, const EncTile *tiles, uint32_t n_
 void launch_enc_cand(const uint8_t *src, const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, const uint32_t *prev, uint32_t *rec,
                      uint64_t *bitmap, hipStream_t st) {
     if (!n_tiles) return;
-    hipLaunchKernelGGL(enc_cand_kernel, dim3(((n_tiles + 7) / 8) * 8 * CAND_BPT), dim3(256), 0, st, src, streams, tiles, n_tiles, prev, rec, bitmap);
+    hipLaunchKernelGGL(enc_cand_kernel, dim3(((n_tiles + 63) / 64) * 64 * CAND_BPT), dim3(256), 0, st, src, streams, tiles, n_tiles, prev, rec, bitmap);
 }
 
 }  // namespace lzmi
