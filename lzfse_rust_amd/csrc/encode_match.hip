@@ -203,8 +203,11 @@ __global__ void enc_link_kernel(const EncStream *__restrict__ streams, const Enc
                                 uint32_t *__restrict__ prev, const uint32_t *__restrict__ summary,
                                 const uint32_t *__restrict__ flist, const uint32_t *__restrict__ fcount) {
     constexpr uint32_t BPT = (1u << HASH_BITS) / 256;  // workgroups per tile
-    const uint32_t t = blockIdx.x / BPT;
-    const uint32_t e = (blockIdx.x % BPT) * blockDim.x + threadIdx.x;
+    // (workgroups -> XCDs round-robin; as in enc_cand_kernel, an XCD takes whole tiles, 8 consecutive ones of every 64:
+    // the summaries a tile looks into are those of the tiles before it)
+    const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, g = slot / BPT;
+    const uint32_t t = (g >> 3) * 64 + xcd * 8 + (g & 7);
+    const uint32_t e = (slot % BPT) * blockDim.x + threadIdx.x;
     if (t >= n_tiles || e >= fcount[t]) return;
     const EncTile tl = tiles[t];
     const uint32_t ent = flist[(uint64_t)t * FL_STRIDE + e];
@@ -560,7 +563,7 @@ void launch_enc_chain(const uint8_t *src, const EncStream *streams, const EncTil
 void launch_enc_link(const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, uint32_t *prev, const uint32_t *summary,
                      const uint32_t *flist, const uint32_t *fcount, hipStream_t st) {
     if (!n_tiles) return;
-    hipLaunchKernelGGL(enc_link_kernel, dim3(n_tiles * ((1u << HASH_BITS) / 256)), dim3(256), 0, st, streams, tiles, n_tiles, prev, summary, flist,
+    hipLaunchKernelGGL(enc_link_kernel, dim3(((n_tiles + 63) / 64) * 64 * ((1u << HASH_BITS) / 256)), dim3(256), 0, st, streams, tiles, n_tiles, prev, summary, flist,
                        fcount);
 }
 
