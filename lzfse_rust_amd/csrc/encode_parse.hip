@@ -158,6 +158,24 @@ __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict_
     WState st;
     st.index = exists ? S : 0; st.lit = S; st.p_idx = 0; st.p_midx = 0; st.p_len = 0;
     uint32_t nev = 0, status = 0;
+    // Event log through LDS: a lane's events are 32 bytes each at its own place in memory, so storing them one by one
+    // costs two 16-byte write requests per event and lane, and the store rate is what this kernel pays for most after the
+    // record gathers. A lane collects SPEC_STAGE events in LDS (slot-major: the lanes' events of one slot are adjacent,
+    // no bank conflicts); when its stage is full the wave writes those bytes as whole lines, one lane per 16 bytes.
+    constexpr uint32_t SPEC_STAGE = 8;
+    __shared__ uint4 s_stage[SPEC_STAGE][64][2];
+    uint32_t n_staged = 0;      // events of this lane in LDS (they follow the nev - n_staged events already in memory)
+    auto flush_full = [&](uint64_t who) {
+        // every lane in `who` has its stage written out: lanes 0 .. 2 * count - 1 move 16 bytes each
+        while (who) {
+            const int L = __builtin_ctzll(who);
+            who &= who - 1;
+            const uint32_t cnt = e_readlane(n_staged, L), done = e_readlane(nev, L) - cnt;
+            const uint64_t eb = ((uint64_t)e_readlane((uint32_t)((uintptr_t)ev >> 32), L) << 32) | e_readlane((uint32_t)(uintptr_t)ev, L);
+            uint4 *dst = reinterpret_cast<uint4 *>((SpecEvent *)(uintptr_t)eb + done);
+            if ((uint32_t)lane < 2 * cnt) dst[lane] = s_stage[lane >> 1][L][lane & 1];
+        }
+    };
     uint32_t cw = NONE - 1;  // word index of w0 (w1 is the following word); nothing cached yet
     uint64_t w0 = 0, w1 = 0;
     bool running = exists && st.index < stop;
@@ -239,19 +257,32 @@ __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict_
                     st.lit = e_idx + e_len;
                     st.index = (p + 1 > st.lit) ? p + 1 : st.lit;
                     if (nev < SEG_EV_CAP) {
-                        SpecEvent e;
-                        e.e_idx = e_idx; e.e_len = e_len; e.e_dist = e_idx - e_midx; e.e_lit = lit_before;
-                        e.index_after = st.index;
-                        e.p_idx = st.p_len ? st.p_idx : 0; e.p_midx = st.p_len ? st.p_midx : 0; e.p_len = st.p_len;
-                        ev[nev] = e;
-                    }
-                    nev++;
+                        s_stage[n_staged][lane][0] = make_uint4(e_idx, e_len, e_idx - e_midx, lit_before);   // SpecEvent, first half
+                        s_stage[n_staged][lane][1] = make_uint4(st.index, st.p_len ? st.p_idx : 0, st.p_len ? st.p_midx : 0, st.p_len);
+                        n_staged++;
+                        nev++;
+                    } else nev = SEG_EV_CAP + 1;   // (log overflow: cannot happen, reported below)
                 } else {
                     st.index = p + 1;
                 }
                 if (st.index >= stop) running = false;
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t full = __ballot(n_staged == SPEC_STAGE);
+        if (full) {
+            flush_full(full);
+            if (n_staged == SPEC_STAGE) n_staged = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t rest = __ballot(n_staged != 0);
+        if (rest) flush_full(rest);
     }
     if (!exists) return;
     SpecHeader h;
