@@ -470,14 +470,32 @@ __global__ __launch_bounds__(BLK_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
             const uint32_t k = tid + u * BLK_THREADS;
             mnext[u] = k < n_lmd ? bl[n_lmd - 1 - k] : make_uint2(0, 0);
         }
+        // The literals of a chunk, 8 consecutive emissions per thread (emission k is literal n4 - 1 - k: one 8-byte load,
+        // emission u of the thread in byte 7 - u), are also fetched one pass ahead (they live in global scratch).
+        auto lit_fetch = [&](uint32_t le0_) -> uint64_t {
+            const uint32_t k0 = le0_ + (uint32_t)tid * 8;   // first emission of this thread in the chunk
+            if (k0 >= n4) return 0ull;
+            if (n4 - k0 >= 8) return ld_u64(lit + (n4 - 8 - k0));
+            return (uint64_t)ld_u32(lit) << 32;              // 4 left (n4 is a multiple of 4): literals 3, 2, 1, 0
+        };
+        uint64_t lnext = lit_fetch(0);
 #pragma unroll
         for (int u = 0; u < CE / BLK_THREADS; u++) asm volatile("" ::"v"(mnext[u].x), "v"(mnext[u].y));  // see below
+        asm volatile("" ::"v"((uint32_t)lnext), "v"((uint32_t)(lnext >> 32)));
         for (uint32_t it = 0; it < n_it; it++) {
             const uint32_t le0 = it * CL, me0 = it * CE;
             const uint32_t lcnt = le0 < n4 ? (n4 - le0 < CL ? n4 - le0 : CL) : 0;
             const uint32_t mcnt = me0 < n_lmd ? (n_lmd - me0 < CE ? n_lmd - me0 : CE) : 0;
             // ---- A0 ----
-            for (uint32_t k = tid; k < lcnt; k += BLK_THREADS) cl[(k & 3) * CH_ROW + ch_at(k >> 2)] = etab[104 + lit[n4 - 1 - (le0 + k)]];
+            {
+                const uint64_t lcur = lnext;
+                lnext = lit_fetch(le0 + CL);
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t k = (uint32_t)tid * 8 + u;
+                    if (k < lcnt) cl[(u & 3) * CH_ROW + ch_at(2 * (uint32_t)tid + (u >> 2))] = etab[104 + (uint32_t)((lcur >> (8 * (7 - u))) & 0xFF)];
+                }
+            }
             uint2 mrec[CE / BLK_THREADS];
 #pragma unroll
             for (int u = 0; u < CE / BLK_THREADS; u++) {
@@ -573,6 +591,7 @@ __global__ __launch_bounds__(BLK_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
             // loop's back edge the compiler could only wait for everything, the word stores below included.
 #pragma unroll
             for (int u = 0; u < CE / BLK_THREADS; u++) asm volatile("" ::"v"(mnext[u].x), "v"(mnext[u].y));
+            asm volatile("" ::"v"((uint32_t)lnext), "v"((uint32_t)(lnext >> 32)));
             // store completed words, carry the incomplete one to word 0
             {
                 uint32_t have = (lit_bits_done & 31) + ta, full = have >> 5;
