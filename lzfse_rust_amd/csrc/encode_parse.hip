@@ -139,6 +139,7 @@ __device__ uint32_t st_wave_lcs_bwd(const uint8_t *s, uint32_t a, uint32_t b, ui
 
 // All 64 lanes stay in the loop until every segment of the wave is finished, so that a lane whose
 // record is capped can have its exact lengths computed by the whole wave (one request at a time).
+template <bool STAGED>
 __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
                                                       const uint2 *__restrict__ segs, uint32_t n_segs,
                                                       const uint32_t *__restrict__ prev, const uint32_t *__restrict__ rec,
@@ -162,8 +163,10 @@ __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict_
     // costs two 16-byte write requests per event and lane, and the store rate is what this kernel pays for most after the
     // record gathers. A lane collects SPEC_STAGE events in LDS (slot-major: the lanes' events of one slot are adjacent,
     // no bank conflicts); when its stage is full the wave writes those bytes as whole lines, one lane per 16 bytes.
+    // (STAGED = false, small batches: every event is stored at once; such a launch is one round of resident waves whose
+    // time is the longest walk, and the flush loops would only lengthen its steps)
     constexpr uint32_t SPEC_STAGE = 8;
-    __shared__ uint4 s_stage[SPEC_STAGE][64][2];
+    __shared__ uint4 s_stage[STAGED ? SPEC_STAGE : 1][STAGED ? 64 : 1][2];
     uint32_t n_staged = 0;      // events of this lane in LDS (they follow the nev - n_staged events already in memory)
     auto flush_full = [&](uint64_t who) {
         // every lane in `who` has its stage written out: lanes 0 .. 2 * count - 1 move 16 bytes each
@@ -257,9 +260,10 @@ __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict_
                     st.lit = e_idx + e_len;
                     st.index = (p + 1 > st.lit) ? p + 1 : st.lit;
                     if (nev < SEG_EV_CAP) {
-                        s_stage[n_staged][lane][0] = make_uint4(e_idx, e_len, e_idx - e_midx, lit_before);   // SpecEvent, first half
-                        s_stage[n_staged][lane][1] = make_uint4(st.index, st.p_len ? st.p_idx : 0, st.p_len ? st.p_midx : 0, st.p_len);
-                        n_staged++;
+                        const uint4 h0 = make_uint4(e_idx, e_len, e_idx - e_midx, lit_before);   // SpecEvent, first half
+                        const uint4 h1 = make_uint4(st.index, st.p_len ? st.p_idx : 0, st.p_len ? st.p_midx : 0, st.p_len);
+                        if (STAGED) { s_stage[n_staged][lane][0] = h0; s_stage[n_staged][lane][1] = h1; n_staged++; }
+                        else { uint4 *de = reinterpret_cast<uint4 *>(ev + nev); de[0] = h0; de[1] = h1; }
                         nev++;
                     } else nev = SEG_EV_CAP + 1;   // (log overflow: cannot happen, reported below)
                 } else {
@@ -268,17 +272,19 @@ __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict_
                 if (st.index >= stop) running = false;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const uint64_t full = __ballot(n_staged == SPEC_STAGE);
-        if (full) {
-            flush_full(full);
-            if (n_staged == SPEC_STAGE) n_staged = 0;
+        if (STAGED) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            const uint64_t full = __ballot(n_staged == SPEC_STAGE);
+            if (full) {
+                flush_full(full);
+                if (n_staged == SPEC_STAGE) n_staged = 0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
         }
     }
-    {
+    if (STAGED) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const uint64_t rest = __ballot(n_staged != 0);
@@ -889,7 +895,10 @@ __global__ __launch_bounds__(256) void enc_lmd_kernel(const EncStream *__restric
 void launch_enc_spec(const uint8_t *src, const EncStream *streams, const uint2 *segs, uint32_t n_segs, const uint32_t *prev,
                      const uint32_t *rec, const uint64_t *bitmap, SpecEvent *logs, SpecHeader *hdrs, hipStream_t st) {
     if (!n_segs) return;
-    hipLaunchKernelGGL(enc_spec_kernel, dim3((n_segs + 63) / 64), dim3(64), 0, st, src, streams, segs, n_segs, prev, rec, bitmap, logs,
+    // staged event stores pay when the launch is bound by its store rate: more segments than the chip holds walkers at once
+    if (n_segs > 98304) hipLaunchKernelGGL(enc_spec_kernel<true>, dim3((n_segs + 63) / 64), dim3(64), 0, st, src, streams, segs, n_segs, prev, rec, bitmap, logs,
+                       hdrs);
+    else hipLaunchKernelGGL(enc_spec_kernel<false>, dim3((n_segs + 63) / 64), dim3(64), 0, st, src, streams, segs, n_segs, prev, rec, bitmap, logs,
                        hdrs);
 }
 void launch_enc_stitch(const uint8_t *src, const EncStream *streams, uint32_t ns, const uint2 *segs, uint32_t n_segs, const uint32_t *prev,
