@@ -34,50 +34,51 @@ constexpr uint32_t FL_STRIDE = (1u << HASH_BITS) + 64;
 // every lane checks what it got (a predecessor must lie before it) and a tile that ever sees anything else is redone
 // by enc_chain_ballot_kernel, which assumes nothing. LDS operations of a wave execute in issue order, so the exchanges
 // of a batch of steps are issued back to back and the wave waits once per batch, not once per step.
-__global__ __launch_bounds__(64) void enc_chain_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
-                                                       const EncTile *__restrict__ tiles, uint32_t n_tiles,
-                                                       uint32_t *__restrict__ prev, uint32_t *__restrict__ summary,
-                                                       uint32_t *__restrict__ flist, uint32_t *__restrict__ fcount,
-                                                       uint32_t *__restrict__ redo, uint32_t force_redo) {
+__global__ __launch_bounds__(128) void enc_chain_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
+                                                        const EncTile *__restrict__ tiles, uint32_t n_tiles,
+                                                        uint32_t *__restrict__ prev, uint32_t *__restrict__ summary,
+                                                        uint32_t *__restrict__ flist, uint32_t *__restrict__ fcount,
+                                                        uint32_t *__restrict__ redo, uint32_t force_redo) {
     __shared__ uint32_t last[1u << HASH_BITS];  // seen_make(): (offset in tile + 1) | check bits << 16, 0 = none
+    __shared__ uint32_t sh_nfirst, sh_wrong;
     const uint32_t t = blockIdx.x;
     if (t >= n_tiles) return;
-    const int lane = e_lane();
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (force_redo) {   // (diagnostic build: every tile goes through the ballot kernel)
-        if (lane == 0) redo[t] = 1;
+        if (tid == 0) redo[t] = 1;
         return;
     }
     const EncTile tl = tiles[t];
-    for (uint32_t k = lane; k < (1u << HASH_BITS); k += 64) last[k] = 0;
+    for (uint32_t k = tid; k < (1u << HASH_BITS); k += 128) last[k] = 0;
+    if (tid == 0) { sh_nfirst = 0; sh_wrong = 0; }
     const uint8_t *s = src + tl.src_off;
     uint32_t *pv = prev + tl.pos_base;  // link records (enc_common.h)
     const uint32_t n_pos = tl.n - 3;  // positions 0 .. n-4 are hashed (frontend_bytes.rs:166-170)
     const uint32_t t_end = tl.start + TILE_POS < n_pos ? tl.start + TILE_POS : n_pos;
     uint32_t *fl = flist + (uint64_t)t * FL_STRIDE;
-    uint32_t n_first = 0;
-    bool wrong = false;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // 16 steps (1024 positions) per batch; the source values of the next batch are loaded while this one runs. All loads
-    // are unconditional (addresses clamped to the tile's last position) and their values are consumed in straight-line
-    // code at the top of a batch: one wait per batch. (A load or a first use inside a divergent branch makes the
-    // compiler wait for ALL outstanding memory operations, the link stores included, at every later use.)
+    // Batches of 32 steps (2 048 positions). A batch has two phases: the exchanges, which must follow those of the batch
+    // before (the table is sequential), and the bookkeeping -- links, first-occurrence list -- which only needs the
+    // values the exchanges returned. TWO waves share the table and take the batches in turn: while one does the
+    // bookkeeping of batch b the other runs the exchanges of batch b + 1 (a workgroup barrier between the turns), so
+    // the two halves of the work of a batch overlap; a lone wave is bound by the latency of its own instructions. The
+    // source values of a wave's next batch are loaded while it works. All loads are unconditional (addresses clamped
+    // to the tile's last position) and the stores of a full batch too: straight-line code, counted waits.
     constexpr int CH_STEPS = 32;
-    uint32_t nx[CH_STEPS];
+    constexpr uint32_t CH_POS = 64 * CH_STEPS;
+    const uint32_t n_batches = (t_end - tl.start + CH_POS - 1) / CH_POS;
     const uint32_t q_last = t_end - 1;
+    uint32_t nx[CH_STEPS], key[CH_STEPS], old[CH_STEPS];
 #pragma unroll
     for (int j = 0; j < CH_STEPS; j++) {
-        const uint32_t q = tl.start + 64 * j + lane;
+        const uint32_t q = tl.start + (uint32_t)w * CH_POS + 64 * j + lane;
         nx[j] = ld_u32(s + (q < q_last ? q : q_last));
+        key[j] = 0; old[j] = 0;
     }
     uint32_t *pvt = pv + tl.start;   // records of the tile: offsets below 2^16
-    // One batch. FULL: all its positions lie inside the tile (no lane masks); LATER: not the first tile of its stream
-    // (first occurrences are listed). A full batch is straight-line code -- every store is unconditional -- so that the
-    // independent dependency chains of its steps can be interleaved; a lone wave per SIMD has nothing else to hide
-    // instruction latency with.
-    auto batch = [&](uint32_t pb, auto full_tag, auto later_tag) {
-        constexpr bool FULL = decltype(full_tag)::value, LATER = decltype(later_tag)::value;
-        uint32_t key[CH_STEPS], ent[CH_STEPS], old[CH_STEPS];
+    bool wrong = false;
+    auto exchanges = [&](uint32_t pb, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        uint32_t ent[CH_STEPS];
         const uint32_t off0 = pb - tl.start + (uint32_t)lane;   // offset in tile of this lane's position in step 0
 #pragma unroll
         for (int j = 0; j < CH_STEPS; j++) {
@@ -85,16 +86,21 @@ __global__ __launch_bounds__(64) void enc_chain_kernel(const uint8_t *__restrict
             ent[j] = seen_make(off0 + 64 * j + 1, nx[j]);
         }
 #pragma unroll
-        for (int j = 0; j < CH_STEPS; j++) {
-            const uint32_t q = pb + 64 * CH_STEPS + 64 * j + lane;
+        for (int j = 0; j < CH_STEPS; j++) {   // this wave's next batch
+            const uint32_t q = pb + 2 * CH_POS + 64 * j + lane;
             nx[j] = ld_u32(s + (q < q_last ? q : q_last));
         }
 #pragma unroll
         for (int j = 0; j < CH_STEPS; j++) {
             old[j] = 0;
             if (FULL || pb + 64 * j + lane < t_end)
-                old[j] = __hip_atomic_exchange(&last[key[j]], ent[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                old[j] = __hip_atomic_exchange(&last[key[j]], ent[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+    };
+    auto bookkeeping = [&](uint32_t pb, auto full_tag, auto later_tag) {
+        constexpr bool FULL = decltype(full_tag)::value, LATER = decltype(later_tag)::value;
+        const uint32_t off0 = pb - tl.start + (uint32_t)lane;
+        uint32_t n_first = LATER ? sh_nfirst : 0u;
 #pragma unroll
         for (int j = 0; j < CH_STEPS; j++) {
             if (!FULL && pb + 64 * j >= t_end) continue;  // (not break: the loop must stay fully unrolled, the arrays live in registers)
@@ -116,24 +122,30 @@ __global__ __launch_bounds__(64) void enc_chain_kernel(const uint8_t *__restrict
             if (FULL) pvt[off] = rec;
             else if (valid) pvt[off] = rec;
         }
+        if (LATER && lane == 0) sh_nfirst = n_first;
     };
-    uint32_t pb = tl.start;
-    if (tl.start != 0) {
-        for (; pb + 64 * CH_STEPS <= t_end; pb += 64 * CH_STEPS) batch(pb, std::true_type{}, std::true_type{});
-        if (pb < t_end) batch(pb, std::false_type{}, std::true_type{});
-    } else {
-        for (; pb + 64 * CH_STEPS <= t_end; pb += 64 * CH_STEPS) batch(pb, std::true_type{}, std::false_type{});
-        if (pb < t_end) batch(pb, std::false_type{}, std::false_type{});
+    __syncthreads();
+    const bool later = tl.start != 0;
+    for (uint32_t b = 0; b <= n_batches; b++) {
+        if ((int)(b & 1) == w) {
+            if (b < n_batches) {
+                const uint32_t pb = tl.start + b * CH_POS;
+                if (pb + CH_POS <= t_end) exchanges(pb, std::true_type{}); else exchanges(pb, std::false_type{});
+            }
+        } else if (b >= 1) {
+            const uint32_t pb = tl.start + (b - 1) * CH_POS;
+            const bool full = pb + CH_POS <= t_end;
+            if (later) { if (full) bookkeeping(pb, std::true_type{}, std::true_type{}); else bookkeeping(pb, std::false_type{}, std::true_type{}); }
+            else { if (full) bookkeeping(pb, std::true_type{}, std::false_type{}); else bookkeeping(pb, std::false_type{}, std::false_type{}); }
+        }
+        __syncthreads();
     }
-    if (lane == 0) { fcount[t] = n_first; redo[t] = 0; }
-    if (__any(wrong)) {
-        if (lane == 0) redo[t] = 1;
-        return;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    if (__any(wrong) && lane == 0) sh_wrong = 1;
+    __syncthreads();
+    if (tid == 0) { fcount[t] = sh_nfirst; redo[t] = sh_wrong; }
+    if (sh_wrong) return;
     uint32_t *sm = summary + (uint64_t)t * (1u << HASH_BITS);
-    for (uint32_t k = lane; k < (1u << HASH_BITS); k += 64) sm[k] = last[k];
+    for (uint32_t k = tid; k < (1u << HASH_BITS); k += 128) sm[k] = last[k];
 }
 
 // The same links without any assumption about the LDS: the nearest previous position with the same bucket is either a
@@ -555,7 +567,7 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
 void launch_enc_chain(const uint8_t *src, const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, uint32_t *prev, uint32_t *summary,
                       uint32_t *flist, uint32_t *fcount, uint32_t *redo, bool force_redo, hipStream_t st) {
     if (!n_tiles) return;
-    hipLaunchKernelGGL(enc_chain_kernel, dim3(n_tiles), dim3(64), 0, st, src, streams, tiles, n_tiles, prev, summary, flist, fcount, redo,
+    hipLaunchKernelGGL(enc_chain_kernel, dim3(n_tiles), dim3(128), 0, st, src, streams, tiles, n_tiles, prev, summary, flist, fcount, redo,
                        force_redo ? 1u : 0u);
     hipLaunchKernelGGL(enc_chain_ballot_kernel, dim3(n_tiles), dim3(64), 0, st, src, streams, tiles, n_tiles, prev, summary, flist, fcount, redo);
 }
