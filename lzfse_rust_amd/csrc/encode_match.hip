@@ -5,11 +5,12 @@
 // position i is a pure function of src[0..i+3] because every position is inserted exactly once,
 // in order (frontend_bytes.rs:187,336-344). That makes the expensive part position-parallel:
 //
-//   enc_chain_kernel   per 64 Ki-position tile: link[i] = distance to the previous position in the same bucket
-//                      (history.rs:221-224 hash, fse/object.rs:38-43), exact, in-order, with a
-//                      16 384-entry last-seen table in LDS and ballot matching inside a wave
+//   enc_chain_kernel   per 64 Ki-position tile: link record of every position = distance to the previous position of
+//                      its bucket (history.rs:221-224 hash, fse/object.rs:38-43) + check bits of that position, exact,
+//                      in order, one LDS exchange per position on a 16 384-entry last-seen table
+//                      (enc_chain_ballot_kernel: the same without the exchange, as a checked fallback)
 //   enc_link_kernel    first occurrences of a tile: link to earlier tiles (window 262 139)
-//   enc_cand_kernel    per position: walk <= 4 chain entries newest->oldest with the reference's
+//   enc_cand_kernel    per position: <= 4 chain entries newest->oldest (<= 3 dependent gathers) with the reference's
 //                      gates (frontend_bytes.rs:214-231), forward LCP (match_kit/match_fast.rs:
 //                      22-49) and un-gated backward LCS (:61-89), both capped
 //
@@ -27,13 +28,13 @@ namespace lzmi {
 // first-occurrence list of a tile: one slot per bucket + 64 slots where lanes that have nothing to list store
 constexpr uint32_t FL_STRIDE = (1u << HASH_BITS) + 64;
 
-// One wave per tile; positions in order, 64 per step. The last-seen table of the tile lives in LDS, one 32-bit entry
-// per bucket, and a step is ONE LDS exchange per lane: the entry a lane gets back is its predecessor in the bucket --
-// an earlier step's, or a lower lane's of the same step, because gfx950 serialises the lanes of one ds_wrxchg that hit
-// the same address in ascending lane order (measured; scripts/xchg_order.hip). That order is not architectural, so
-// every lane checks what it got (a predecessor must lie before it) and a tile that ever sees anything else is redone
-// by enc_chain_ballot_kernel, which assumes nothing. LDS operations of a wave execute in issue order, so the exchanges
-// of a batch of steps are issued back to back and the wave waits once per batch, not once per step.
+// One workgroup (two waves) per tile; positions in order, 64 per step. The last-seen table of the tile lives in LDS, one
+// 32-bit entry per bucket, and a step is ONE LDS exchange per lane: the entry a lane gets back is its predecessor in the
+// bucket -- an earlier step's, or a lower lane's of the same step, because gfx950 serialises the lanes of one ds_wrxchg
+// that hit the same address in ascending lane order (measured; scripts/micro/xchg_order.hip). That order is not
+// architectural, so every lane checks what it got (a predecessor must lie before it) and a tile that ever sees anything
+// else is redone by enc_chain_ballot_kernel, which assumes nothing. LDS operations of a wave execute in issue order, so
+// the exchanges of a batch of steps are issued back to back and the wave waits once per batch, not once per step.
 __global__ __launch_bounds__(128) void enc_chain_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
                                                         const EncTile *__restrict__ tiles, uint32_t n_tiles,
                                                         uint32_t *__restrict__ prev, uint32_t *__restrict__ summary,
