@@ -1,10 +1,12 @@
 // Decode side of the MI355X LZFSE codec: hand-written HIP kernels for gfx950 (wave64).
 //
 //   dec_walk_kernel   header walk per stream            decoder.rs:61-99, probe.rs:11-35
+//   dec_scan / rank   the same walk for large streams:  magic scan, candidates sorted, chain from position 0
 //   dec_fse_kernel    weights -> tables (LDS) -> FSE     fse_core.rs:49-141, weights.rs:83-105,
 //                     decode of literals and LMDs        decoder.rs:244-335, literals.rs:49-91
 //   dec_lz_kernel     literal / match copy (LZ77)        lz/writer.rs:97-186, lz/object.rs:27-74
 //                     + bvx- and bvxn blocks             raw/block.rs:46-93, vn/vn_core.rs:40-287
+//   dec_jump_*        the LZ stage of few large streams by pointer jumping over per-byte origins
 //
 // Parallelism: FSE is serial per bit stream, so the entropy stage runs one workgroup (two
 // waves: LMD stream, literal stream) per bvx2 block with its 7 KiB of tables in LDS and

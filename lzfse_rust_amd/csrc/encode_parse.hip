@@ -4,7 +4,7 @@
 // driven by the per-position candidate records of enc_cand_kernel. Two walkers that reach the
 // same state evolve identically, so:
 //
-//   enc_spec_kernel     one LANE per 4 KiB segment walks its segment (plus a 1 KiB overrun) from
+//   enc_spec_kernel     one LANE per 2 KiB segment walks its segment (plus a 512-byte overrun) from
 //                       the guessed state (index = lit = segment start, no pending) and logs every
 //                       emitted match together with the state after it
 //   enc_stitch_kernel   one wave per stream: the log of segment 0 is exact; for every boundary the
