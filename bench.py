@@ -362,12 +362,18 @@ class DeviceBatch:
 
 
 def kernel_source_sha():
-    """Identity of the kernels a PMC pass was taken on: SHA-256 over the HIP sources (the GPU box has no .git)."""
+    """Identity of the kernels a PMC pass was taken on: SHA-256 over the code lines of the HIP sources (the GPU box has
+    no .git)."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "lzfse_rust_amd", "csrc")
     for f in sorted(os.listdir(d)):
         h.update(f.encode())
-        h.update(open(os.path.join(d, f), "rb").read())
+        # code only: `//` comments and blank lines do not change a kernel
+        for line in open(os.path.join(d, f), "r", errors="replace"):
+            code = line.split("//", 1)[0].strip()
+            if code:
+                h.update(code.encode())
+                h.update(b"\n")
     return h.hexdigest()[:16]
 
 
