@@ -1223,6 +1223,37 @@ __global__ __launch_bounds__(JUMP_THREADS) void dec_jump_init_kernel(
     (void)wave;
 }
 
+// Chains collapsed chunk by chunk in LDS before the global rounds: a workgroup takes 16 Ki consecutive origins (64 KB of
+// LDS) and jumps every entry whose origin lies in the same chunk until it is final or points in front of the chunk. An
+// origin mostly points a match distance back, so most hops of most chains stay inside a chunk, where a hop is an LDS read
+// instead of a gather from a 4-byte-per-output-byte array far larger than any L2. Any intermediate state is valid
+// (an origin always names a byte with the same final value), so no ordering between threads is needed.
+constexpr uint32_t JC_N = 16384;
+__global__ __launch_bounds__(1024) void dec_jump_collapse_kernel(uint32_t *__restrict__ origin, uint64_t total) {
+    __shared__ uint32_t o[JC_N];
+    const uint64_t c0 = (uint64_t)blockIdx.x * JC_N;
+    if (c0 >= total) return;
+    const uint32_t n = total - c0 < JC_N ? (uint32_t)(total - c0) : JC_N;
+    const uint32_t base = (uint32_t)c0;
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) o[i] = origin[c0 + i];
+    __syncthreads();
+    for (;;) {
+        bool more = false;
+        for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+            uint32_t cur = o[i];
+#pragma unroll
+            for (int h = 0; h < 4; h++) {
+                if ((cur & JUMP_FINAL) || cur < base || cur - base >= n) break;   // final, or points out of the chunk
+                cur = o[cur - base];
+            }
+            o[i] = cur;
+            if (!(cur & JUMP_FINAL) && cur >= base && cur - base < n) more = true;
+        }
+        if (!__syncthreads_or(more)) break;
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) origin[c0 + i] = o[i];
+}
+
 // one jumping round over all origins; exits at once when the previous round changed nothing
 __global__ __launch_bounds__(256) void dec_jump_round_kernel(uint32_t *__restrict__ origin, uint64_t total, uint32_t *__restrict__ flags,
                                                              uint32_t round) {
@@ -1359,6 +1390,7 @@ void launch_dec_jump(const uint8_t *src, const StreamIn *streams, const StreamPl
     }
     {
         StageTimer t(c, "dec_jump_rounds");
+        hipLaunchKernelGGL(dec_jump_collapse_kernel, dim3((uint32_t)((total + JC_N - 1) / JC_N)), dim3(1024), 0, st, origin, total);
         uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256ull * 16);
         grid = (grid + 7) & ~7u;   // (dec_jump_round_kernel: eight equal parts)
         // every round collapses chains by 4x (three dependent hops): 4^16 covers any stream below 4 GiB
