@@ -442,9 +442,10 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
     std::vector<StreamPlan> h_plan(ns);
     uint64_t nb = 0, nl = 0, nu = 0, nj = 0;
     int jump_mode = c->diag_lz_jump;  // -1: by cost; the diagnostic build can force 0 (never) or 1 (always)
-    // Streams >= 2 MiB may take the pointer-jumping LZ path. One workgroup per stream copies ~0.6 GB/s whatever else
-    // runs, the jumping passes move ~25 GB/s over all eligible bytes together: jumping pays when the largest stream,
-    // not the batch, sets the time (one 64 MiB stream: yes; 128 streams of 4 MiB: no).
+    // Streams >= 2 MiB may take the pointer-jumping LZ path. One workgroup per stream copies ~0.63 GB/s whatever else
+    // runs, the jumping passes move ~40 GB/s over all eligible bytes of ALL sub-batches together (this is one of up to
+    // three running side by side, hence 42 and not 64): jumping pays when the largest stream, not the batch, sets the
+    // time (one 64 MiB stream: yes; 128 streams of 4 MiB: no).
     if (jump_mode < 0) {
         uint64_t el_bytes = 0, el_max = 0;
         for (uint32_t i = 0; i < ns; i++) {
