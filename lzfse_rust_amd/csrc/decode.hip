@@ -1287,7 +1287,7 @@ __global__ __launch_bounds__(256) void dec_jump_round_kernel(uint32_t *__restric
 __global__ __launch_bounds__(JUMP_THREADS) void dec_jump_apply_kernel(const StreamIn *__restrict__ streams, const StreamPlan *__restrict__ plan,
                                                                       const BlockDesc *__restrict__ blocks, uint32_t n_blocks,
                                                                       const BlockResult *__restrict__ bres, uint8_t *dst_all,
-                                                                      const uint32_t *__restrict__ origin, const uint32_t *__restrict__ jerr) {
+                                                                      const uint32_t *__restrict__ origin, uint32_t *__restrict__ jerr) {
     const uint32_t b = blockIdx.x;
     if (b >= n_blocks) return;
     const BlockDesc d = blocks[b];
@@ -1303,7 +1303,15 @@ __global__ __launch_bounds__(JUMP_THREADS) void dec_jump_apply_kernel(const Stre
         const uint32_t q = o0 + i;
         uint32_t w = 0;
         const uint32_t cnt = n - i < 4 ? n - i : 4;
-        for (uint32_t k = 0; k < cnt; k++) w |= (uint32_t)dst[(org[q + k] & ~JUMP_FINAL) - jb] << (8 * k);
+        bool loose = false;
+        for (uint32_t k = 0; k < cnt; k++) {
+            const uint32_t og = org[q + k];
+            loose |= !(og & JUMP_FINAL);
+            w |= (uint32_t)dst[(og & ~JUMP_FINAL) - jb] << (8 * k);
+        }
+        // every chain is resolved by now (launch_dec_jump sizes the rounds for that); should one not be, the stream fails
+        // instead of carrying a wrong byte
+        if (loose) atomicMin(&jerr[d.stream], (0xFFFFFEu << 8) | (uint32_t)LZFSE_MI_IO);
         if (cnt == 4) __builtin_memcpy(dst + q, &w, 4);
         else for (uint32_t k = 0; k < cnt; k++) dst[q + k] = (uint8_t)(w >> (8 * k));
     }
@@ -1393,8 +1401,11 @@ void launch_dec_jump(const uint8_t *src, const StreamIn *streams, const StreamPl
         hipLaunchKernelGGL(dec_jump_collapse_kernel, dim3((uint32_t)((total + JC_N - 1) / JC_N)), dim3(1024), 0, st, origin, total);
         uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256ull * 16);
         grid = (grid + 7) & ~7u;   // (dec_jump_round_kernel: eight equal parts)
-        // every round collapses chains by 4x (three dependent hops): 4^16 covers any stream below 4 GiB
-        for (uint32_t r = 0; r < 17; r++)
+        // every round collapses chains by 4x (three dependent hops): 4^16 covers any stream below 4 GiB. After the
+        // chunk-wise collapse a hop leaves its chunk, so a chain has at most as many hops as there are chunks.
+        uint32_t n_rounds = 2;
+        for (uint64_t reach = 1; reach < (total + JC_N - 1) / JC_N && n_rounds < 17; reach *= 4) n_rounds++;
+        for (uint32_t r = 0; r < n_rounds; r++)
             hipLaunchKernelGGL(dec_jump_round_kernel, dim3(grid), dim3(256), 0, st, origin, total, flags, r);
     }
     {
