@@ -177,6 +177,28 @@ typedef struct lzfse_mi_timings {
 LZFSE_MI_API int lzfse_mi_enable_timing(lzfse_mi_ctx *ctx, int enable);
 LZFSE_MI_API int lzfse_mi_get_timings(lzfse_mi_ctx *ctx, lzfse_mi_timings *out);
 
+/* The reference decodes into a Vec (decode/decoder.rs:52-57), so a damaged block that produces more than its header's
+ * n_raw_bytes runs to its last LMD and fails there (BadLmdPayload, fse/fse_core.rs:132-140) where a destination of exactly
+ * lzfse_mi_decode_size bytes reports LZFSE_MI_BUFFER_OVERFLOW first. A caller that wants the reference's status for such a
+ * stream decodes again with this many more bytes of capacity (an upper bound of what the stream's blocks can over-produce). */
+LZFSE_MI_API size_t lzfse_mi_decode_headroom(const uint8_t *src, size_t n);
+
+/* ---- Streaming decode (decode half): LzfseRingDecoder::decode(reader, writer),
+ * decode/ring_decoder.rs:58-68. Input arrives in pieces (lzfse_mi_dstream_feed), output leaves through `write` in
+ * pieces; the result is the slice path's: the same bytes, and for a damaged stream the same status at the feed call
+ * that completes the evidence (sticky afterwards). finish != 0 marks the end of the input: a stream that does not end
+ * with bvx$ in its last 4 bytes is an error (decode/decoder.rs:93-95). `window` (0 = LZFSE_MI_STREAM_WINDOW) is the
+ * number of raw bytes decoded per device call. `write` returns 0 to go on. */
+#define LZFSE_MI_STREAM_WINDOW ((size_t)16 << 20)
+typedef struct lzfse_mi_dstream lzfse_mi_dstream;
+typedef int (*lzfse_mi_write_fn)(void *user, const uint8_t *bytes, size_t n);
+LZFSE_MI_API int lzfse_mi_dstream_create(lzfse_mi_ctx *ctx, size_t window, lzfse_mi_dstream **out);
+LZFSE_MI_API int lzfse_mi_dstream_feed(lzfse_mi_dstream *s, const uint8_t *src, size_t n, int finish, lzfse_mi_write_fn write,
+                                       void *user);
+/* bytes of input consumed / of output written so far: the (u, v) LzfseRingDecoder::decode returns */
+LZFSE_MI_API int lzfse_mi_dstream_totals(const lzfse_mi_dstream *s, uint64_t *bytes_in, uint64_t *bytes_out);
+LZFSE_MI_API void lzfse_mi_dstream_destroy(lzfse_mi_dstream *s);
+
 #ifdef __cplusplus
 }
 #endif

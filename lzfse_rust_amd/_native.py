@@ -12,6 +12,8 @@ class Timings(C.Structure):
                 ("launches", C.c_uint64 * MAX_STAGES)]
 
 
+WRITE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)   # lzfse_mi_write_fn
+
 _lib = None
 _diag_lib = None
 
@@ -21,7 +23,8 @@ _SYMBOLS = [
     "lzfse_mi_encode_batch", "lzfse_mi_decode_batch", "lzfse_mi_decode_batch_device",
     "lzfse_mi_encode_batch_device", "lzfse_mi_enable_timing", "lzfse_mi_get_timings", "lzfse_mi_encode_small",
     "lzfse_mi_last_error_detail", "lzfse_mi_set_option", "lzfse_mi_chunked_bound", "lzfse_mi_encode_chunked",
-    "lzfse_mi_decode_chunked_size", "lzfse_mi_decode_chunked",
+    "lzfse_mi_decode_chunked_size", "lzfse_mi_decode_chunked", "lzfse_mi_dstream_create", "lzfse_mi_dstream_feed",
+    "lzfse_mi_dstream_totals", "lzfse_mi_dstream_destroy", "lzfse_mi_decode_headroom",
 ]
 
 
@@ -86,6 +89,16 @@ def _load(path):
     L.lzfse_mi_decode_chunked_size.argtypes = [vp, sz, u64p]
     L.lzfse_mi_decode_chunked.restype = C.c_int
     L.lzfse_mi_decode_chunked.argtypes = [C.POINTER(vp), C.c_int, vp, sz, vp, sz, C.POINTER(sz)]
+    L.lzfse_mi_decode_headroom.restype = sz
+    L.lzfse_mi_decode_headroom.argtypes = [vp, sz]
+    L.lzfse_mi_dstream_create.restype = C.c_int
+    L.lzfse_mi_dstream_create.argtypes = [vp, sz, C.POINTER(vp)]
+    L.lzfse_mi_dstream_feed.restype = C.c_int
+    L.lzfse_mi_dstream_feed.argtypes = [vp, vp, sz, C.c_int, WRITE_FN, vp]
+    L.lzfse_mi_dstream_totals.restype = C.c_int
+    L.lzfse_mi_dstream_totals.argtypes = [vp, u64p, u64p]
+    L.lzfse_mi_dstream_destroy.restype = None
+    L.lzfse_mi_dstream_destroy.argtypes = [vp]
     L.lzfse_mi_set_option.restype = C.c_int
     L.lzfse_mi_set_option.argtypes = [vp, C.c_int, C.c_int64]
     return L

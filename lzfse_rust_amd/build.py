@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, "csrc")
 LIB_PATH = os.path.join(_PKG, "liblzfse_mi.so")
 DIAG_LIB_PATH = os.path.join(_PKG, "liblzfse_mi_diag.so")
-SOURCES = ["api.hip", "decode.hip", "encode.hip", "encode_match.hip", "encode_parse.hip", "host_small.cpp", "chunked.cpp"]
+SOURCES = ["api.hip", "decode.hip", "encode.hip", "encode_match.hip", "encode_parse.hip", "host_small.cpp", "chunked.cpp", "stream.hip"]
 HEADERS = ["common.h", "internal.h", "enc_common.h", os.path.join("..", "..", "include", "lzfse_mi.h")]
 _OBJ = os.path.join(_PKG, "build")
 

@@ -15,6 +15,7 @@ import numpy as np
 from . import _native
 
 OK = 0
+BUFFER_OVERFLOW = 6
 
 
 class LzfseError(Exception):
@@ -171,10 +172,58 @@ class LzfseDecoder:
     def decode_bytes(self, src, dst):
         """Appends the decoded bytes of stream `src` to bytearray `dst`; returns bytes appended."""
         outs, st = self._ctx.decode_batch([src])
+        if st[0] == BUFFER_OVERFLOW:
+            # `dst` is a Vec in the reference: a block that produces more than its header says runs to its last LMD and
+            # fails there (fse/fse_core.rs:132-140); give it the room to reach that error
+            a = np.frombuffer(bytes(src), dtype=np.uint8)
+            room = self._ctx._lib.lzfse_mi_decode_headroom(a.ctypes.data if a.size else None, a.size)
+            outs, st = self._ctx.decode_batch([src], caps=[decode_size(src, partial=True) + room])
         if st[0] != OK:
             raise LzfseError(st[0], self._ctx.error_detail(0))
         dst += outs[0].tobytes()
         return len(outs[0])
+
+
+class LzfseRingDecoder:
+    """src/decode/ring_decoder.rs:17-68: decode(reader, writer) -> (bytes read, bytes written). `reader.read(n)` returns
+    b"" at the end of the input, `writer.write(b)` takes the output in pieces; `window` = raw bytes per device call."""
+
+    def __init__(self, device=0, context=None, window=0, read_size=1 << 20):
+        self._ctx = context or Context(device)
+        self._window = window
+        self._read_size = read_size
+
+    def decode(self, reader, writer):
+        lib = self._ctx._lib
+        h = C.c_void_p()
+        _check(lib.lzfse_mi_dstream_create(self._ctx._h, self._window, C.byref(h)))
+        failure = []
+
+        def _write(_user, p, n):
+            try:
+                writer.write(C.string_at(p, n))
+                return 0
+            except Exception as e:   # the sink's error travels back through the C layer as LZFSE_MI_IO
+                failure.append(e)
+                return 1
+
+        cb = _native.WRITE_FN(_write)
+        try:
+            while True:
+                piece = reader.read(self._read_size)
+                a = np.frombuffer(piece, dtype=np.uint8)
+                st = lib.lzfse_mi_dstream_feed(h, a.ctypes.data if a.size else None, a.size, 0 if a.size else 1, cb, None)
+                if failure:
+                    raise failure[0]
+                if st != OK:
+                    raise LzfseError(st, 0)
+                if not a.size:
+                    break
+            u, v = C.c_uint64(0), C.c_uint64(0)
+            _check(lib.lzfse_mi_dstream_totals(h, C.byref(u), C.byref(v)))
+            return u.value, v.value
+        finally:
+            lib.lzfse_mi_dstream_destroy(h)
 
 
 def encode_bytes(src, dst):

@@ -1,0 +1,215 @@
+// Streaming decode surface (decode half): what LzfseRingDecoder::decode(reader, writer) does
+// (decode/ring_decoder.rs:58-68) -- the same block loop as the slice path (decode/decoder.rs:73-99: blocks until bvx$,
+// which must be the last 4 bytes of the input) over a source that arrives in pieces and a sink that takes the output in
+// pieces. Host code over the public entry points: the input is cut at block boundaries, every window of complete blocks
+// (LZFSE_MI_STREAM_WINDOW = 16 MiB of raw bytes unless the caller says otherwise) is decoded as one stream on the device, and the 262 139 bytes a match may
+// reach back (fse/constants.rs:42) travel with it as a leading raw block (bvx-), so no kernel knows about windows. The
+// first error in stream order is reported with the slice path's code: the windows before it decoded cleanly, and the
+// window that holds it is decoded by the same kernels.
+//
+// (The encode half of the rank -- the ring front ends, frontend_ring.rs -- produces other bytes than the slice encoder
+// and would need a CPU restatement of its own to be checked against; not built.)
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "common.h"
+
+using namespace lzmi;
+
+struct lzfse_mi_dstream {
+    lzfse_mi_ctx *ctx = nullptr;
+    size_t window = 0;
+    std::vector<uint8_t> in;       // bytes fed; in[in_pos..] are not yet decoded
+    size_t in_pos = 0;
+    std::vector<uint8_t> hist;     // the last <= MAX_D_VALUE bytes of output
+    std::vector<uint8_t> tmp_src;
+    uint8_t *tmp_dst = nullptr;    // malloc'd, never zero-filled: a damaged header may promise gigabytes that are never written
+    size_t tmp_dst_cap = 0;
+    ~lzfse_mi_dstream() { std::free(tmp_dst); }
+    uint64_t total_in = 0, total_out = 0;
+    int status = 0;                // sticky
+    bool eos_seen = false;         // bvx$ consumed: any further byte is PayloadOverflow (decoder.rs:93-95)
+};
+
+extern "C" LZFSE_MI_API size_t lzfse_mi_decode_headroom(const uint8_t *src, size_t n);
+
+namespace {
+
+// extent of the block at p: 0 = known (len, n_raw, eos), 1 = more input needed, 2 = cannot be told here (damaged or
+// unknown: the device decides, with the slice path's error)
+int block_extent(const uint8_t *p, size_t avail, uint64_t &len, uint64_t &n_raw, bool &eos) {
+    eos = false; len = 0; n_raw = 0;
+    if (avail < 4) return 1;
+    const uint32_t magic = ld_u32(p);
+    if (magic == MAGIC_EOS) { eos = true; len = 4; return 0; }
+    if (magic == MAGIC_VX2) {
+        if (avail < V2_HEADER_SIZE) return 1;
+        FseHeader h;
+        if (fse_load_v2(p, h)) return 2;
+        len = (uint64_t)h.hdr_size + h.lit_payload + h.lmd_payload; n_raw = h.n_raw;
+        return avail < len ? 1 : 0;
+    }
+    if (magic == MAGIC_VX1) {
+        if (avail < V1_HEADER_SIZE) return 1;
+        FseHeader h;
+        if (fse_load_v1(p, h)) return 2;
+        len = (uint64_t)h.hdr_size + h.lit_payload + h.lmd_payload; n_raw = h.n_raw;
+        return avail < len ? 1 : 0;
+    }
+    if (magic == MAGIC_VXN) {
+        if (avail < 12) return 1;
+        n_raw = ld_u32(p + 4); len = 12ull + ld_u32(p + 8);
+        return avail < len ? 1 : 0;
+    }
+    if (magic == MAGIC_RAW) {
+        if (avail < 8) return 1;
+        n_raw = ld_u32(p + 4); len = 8ull + n_raw;
+        return avail < len ? 1 : 0;
+    }
+    return 2;
+}
+
+bool grow_dst(lzfse_mi_dstream *s, uint64_t cap) {
+    if (s->tmp_dst_cap >= cap + 64) return true;
+    std::free(s->tmp_dst);
+    s->tmp_dst_cap = 0;
+    s->tmp_dst = (uint8_t *)std::malloc((size_t)cap + 64);
+    if (!s->tmp_dst) return false;
+    s->tmp_dst_cap = (size_t)cap + 64;
+    return true;
+}
+
+// decode in[0 .. span) as one stream behind the history block; with_eos: the span's blocks are complete and bvx$ is added
+int decode_span(lzfse_mi_dstream *s, size_t span, uint64_t raw, bool with_eos, lzfse_mi_write_fn write, void *user) {
+    const size_t nh = s->hist.size();
+    s->tmp_src.clear();
+    if (nh) {
+        uint8_t hd[8];
+        const uint32_t m = MAGIC_RAW, n32 = (uint32_t)nh;
+        std::memcpy(hd, &m, 4); std::memcpy(hd + 4, &n32, 4);
+        s->tmp_src.insert(s->tmp_src.end(), hd, hd + 8);
+        s->tmp_src.insert(s->tmp_src.end(), s->hist.begin(), s->hist.end());
+    }
+    s->tmp_src.insert(s->tmp_src.end(), s->in.begin() + s->in_pos, s->in.begin() + s->in_pos + span);
+    if (with_eos) { const uint32_t m = MAGIC_EOS; const uint8_t *q = (const uint8_t *)&m; s->tmp_src.insert(s->tmp_src.end(), q, q + 4); }
+    uint64_t cap64 = nh + raw;
+    if (!with_eos) {   // a tail the parser could not delimit: what its headers promise, as the slice path's caller would size it
+        uint64_t promised = 0;
+        (void)lzfse_mi_decode_size(s->tmp_src.data(), s->tmp_src.size(), &promised);
+        cap64 = std::max<uint64_t>(cap64, promised);
+    }
+    if (!grow_dst(s, cap64)) return LZFSE_MI_IO;
+    size_t got = 0;
+    int st = lzfse_mi_decode(s->ctx, s->tmp_src.data(), s->tmp_src.size(), s->tmp_dst, (size_t)cap64, &got);
+    if (st == LZFSE_MI_BUFFER_OVERFLOW) {   // the sink is unbounded: find the error the reference's Vec would have met
+        cap64 += lzfse_mi_decode_headroom(s->tmp_src.data(), s->tmp_src.size());
+        if (!grow_dst(s, cap64)) return LZFSE_MI_IO;
+        st = lzfse_mi_decode(s->ctx, s->tmp_src.data(), s->tmp_src.size(), s->tmp_dst, (size_t)cap64, &got);
+    }
+    if (st) return st;
+    if (got < nh) return LZFSE_MI_IO;
+    const size_t fresh = got - nh;
+    if (fresh && write && write(user, s->tmp_dst + nh, fresh)) return LZFSE_MI_IO;
+    s->total_out += fresh;
+    // history for the next window
+    s->hist.assign(s->tmp_dst + (got >= MAX_D_VALUE ? got - MAX_D_VALUE : 0), s->tmp_dst + got);
+    s->in_pos += span;
+    s->total_in += span;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// The reference writes into a Vec: a damaged block that produces MORE than its header's n_raw_bytes is decoded to its last
+// LMD and then fails with BadLmdPayload / a bad D on the way (fse/fse_core.rs:103-140), where a destination of exactly
+// lzfse_mi_decode_size bytes ends in BUFFER_OVERFLOW first. This is how much more such a block can write: 40 000 literals
+// + 10 000 matches of 2 359 bytes for a bvx1/bvx2 block (fse/constants.rs), 136 bytes per payload byte for a bvxn block.
+LZFSE_MI_API size_t lzfse_mi_decode_headroom(const uint8_t *src, size_t n) {
+    if (!src) return 0;
+    size_t pos = 0;
+    uint64_t vn = 0;
+    bool fse = false;
+    while (n - pos >= 4) {
+        uint64_t len, nr; bool eos;
+        const uint32_t magic = ld_u32(src + pos);
+        const int why = block_extent(src + pos, n - pos, len, nr, eos);
+        if (magic == MAGIC_VX1 || magic == MAGIC_VX2) fse = true;
+        if (magic == MAGIC_VXN) vn += std::min<uint64_t>(why == 0 ? len : n - pos, n - pos);
+        if (why || eos) break;
+        pos += (size_t)len;
+    }
+    return (size_t)((fse ? (uint64_t)LITERALS_PER_BLOCK + (uint64_t)LMDS_PER_BLOCK * MAX_M_VALUE : 0) + 136 * vn);
+}
+
+LZFSE_MI_API int lzfse_mi_dstream_create(lzfse_mi_ctx *ctx, size_t window, lzfse_mi_dstream **out) {
+    if (!ctx || !out) return LZFSE_MI_BAD_ARGUMENT;
+    lzfse_mi_dstream *s = new (std::nothrow) lzfse_mi_dstream;
+    if (!s) return LZFSE_MI_IO;
+    s->ctx = ctx;
+    s->window = window ? window : (size_t)LZFSE_MI_STREAM_WINDOW;
+    *out = s;
+    return LZFSE_MI_OK;
+}
+
+LZFSE_MI_API void lzfse_mi_dstream_destroy(lzfse_mi_dstream *s) { delete s; }
+
+LZFSE_MI_API int lzfse_mi_dstream_totals(const lzfse_mi_dstream *s, uint64_t *bytes_in, uint64_t *bytes_out) {
+    if (!s) return LZFSE_MI_BAD_ARGUMENT;
+    if (bytes_in) *bytes_in = s->total_in;
+    if (bytes_out) *bytes_out = s->total_out;
+    return LZFSE_MI_OK;
+}
+
+LZFSE_MI_API int lzfse_mi_dstream_feed(lzfse_mi_dstream *s, const uint8_t *src, size_t n, int finish, lzfse_mi_write_fn write, void *user) {
+    if (!s || (!src && n)) return LZFSE_MI_BAD_ARGUMENT;
+    if (s->status) return s->status;
+    if (n) {
+        if (s->in_pos && s->in_pos >= s->in.size() / 2) { s->in.erase(s->in.begin(), s->in.begin() + s->in_pos); s->in_pos = 0; }
+        s->in.insert(s->in.end(), src, src + n);
+    }
+    for (;;) {
+        if (s->eos_seen) {
+            if (s->in.size() > s->in_pos) return s->status = LZFSE_MI_PAYLOAD_OVERFLOW;   // bytes behind bvx$ (decoder.rs:93-95)
+            return LZFSE_MI_OK;
+        }
+        // the longest run of complete blocks at the front of the input, up to a window of raw bytes
+        size_t span = 0;
+        uint64_t raw = 0;
+        int why = 1;   // why the run ended: 0 bvx$, 1 input exhausted, 2 undecidable block, 3 window full
+        while (true) {
+            uint64_t len, nr; bool eos;
+            why = block_extent(s->in.data() + s->in_pos + span, s->in.size() - s->in_pos - span, len, nr, eos);
+            if (why) break;
+            if (eos) break;
+            span += (size_t)len; raw += nr;
+            if (raw >= s->window) { why = 3; break; }
+        }
+        if (why == 0) {
+            // bvx$ follows the run: decode the run, consume the magic; whether it ends the input shows at once or later
+            if (span) { const int st = decode_span(s, span, raw, true, write, user); if (st) return s->status = st; }
+            s->in_pos += 4;
+            s->total_in += 4;
+            s->eos_seen = true;
+            continue;
+        }
+        if (why == 3) { const int st = decode_span(s, span, raw, true, write, user); if (st) return s->status = st; continue; }
+        if (why == 1 && !finish) {
+            // wait for more input; decode what is complete if it is worth a launch
+            if (raw >= s->window / 2 && span) { const int st = decode_span(s, span, raw, true, write, user); if (st) return s->status = st; }
+            return LZFSE_MI_OK;
+        }
+        // the input ends inside a block, or a block cannot be delimited: the rest goes to the device as it is, which
+        // reports what the slice path reports for it (PayloadUnderflow, BadBlock, a header error ...)
+        {
+            const int st = decode_span(s, s->in.size() - s->in_pos, raw, false, write, user);
+            return s->status = st ? st : LZFSE_MI_PAYLOAD_UNDERFLOW;   // (no bvx$: cannot have decoded cleanly)
+        }
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,46 @@
+"""Streaming decode (lzfse_mi_dstream_*) against the slice call on the same stream: host-pointer rates, PCIe included.
+    python scripts/stream_bench.py [MB]"""
+import io
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+
+import lzfse_rust_amd as m
+from bench import synth_text
+
+
+class Sink:
+    def __init__(self):
+        self.n = 0
+
+    def write(self, b):
+        self.n += len(b)
+
+
+def main():
+    mb = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    ctx = m.Context(0)
+    raw = bytes(synth_text(mb << 20))
+    encs, st = ctx.encode_batch([raw])
+    assert st[0] == 0
+    enc = encs[0].tobytes()
+    for _ in range(2):
+        t = time.perf_counter()
+        outs, st = ctx.decode_batch([enc])
+        dt = time.perf_counter() - t
+    print(f"slice decode (host pointers): {len(raw) / dt / 1e6:9.1f} MB/s")
+    for window in (1 << 20, 4 << 20, 16 << 20, 64 << 20):
+        for _ in range(2):
+            s = Sink()
+            t = time.perf_counter()
+            u, v = m.LzfseRingDecoder(context=ctx, window=window, read_size=1 << 20).decode(io.BytesIO(enc), s)
+            dt = time.perf_counter() - t
+        assert (u, v, s.n) == (len(enc), len(raw), len(raw))
+        print(f"stream decode, window {window >> 20:3d} MiB: {len(raw) / dt / 1e6:9.1f} MB/s")
+
+
+if __name__ == "__main__":
+    main()

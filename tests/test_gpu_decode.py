@@ -99,6 +99,21 @@ def test_decode_errors_match_oracle(ctx, oracle, golden_dir, snappy_raw):
     assert st[-1] == 22  # BadLmdPayload for n_raw_bytes + 1 (fse/test.rs:434,458)
 
 
+def test_decode_bytes_has_vec_semantics(ctx, oracle, snappy_raw):
+    """decode_bytes appends to a Vec (decode/decoder.rs:52-57): a block that produces MORE than its n_raw_bytes fails with
+    BadLmdPayload at its end (fse/fse_core.rs:132-140), not with the fixed-capacity status of the C entry points."""
+    import lzfse_rust_amd as m
+    enc = bytearray(oracle.encode(snappy_raw["html"]))
+    n = int.from_bytes(enc[4:8], "little")
+    enc[4:8] = (n - 1).to_bytes(4, "little")
+    assert oracle.decode_status(bytes(enc), 1 << 26) == 22
+    outs, st = ctx.decode_batch([bytes(enc)])
+    assert st[0] == 6
+    with pytest.raises(m.LzfseError) as e:
+        m.LzfseDecoder(context=ctx).decode_bytes(bytes(enc), bytearray())
+    assert e.value.status == 22
+
+
 def test_decode_capacity_too_small(ctx, oracle, snappy_raw):
     enc = oracle.encode(snappy_raw["html"])
     outs, st = ctx.decode_batch([enc], caps=[1000])

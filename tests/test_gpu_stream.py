@@ -1,0 +1,156 @@
+"""GPU parity tests (streaming decode): LzfseRingDecoder::decode(reader, writer) over the HIP path -- the same bytes and
+the same errors as the slice path, whatever the sizes of the pieces the input arrives in (decode/ring_decoder.rs:58-68)."""
+import ctypes as C
+import glob
+import io
+import os
+
+import numpy as np
+import pytest
+
+from oracle_py import rng_gen_vec
+
+pytestmark = pytest.mark.gpu
+
+BIG_CAP = 64 << 20
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import lzfse_rust_amd as m
+    return m.Context(0)
+
+
+class PieceReader:
+    """read() hands out the stream in pieces of the given sizes (cycled), then b""."""
+
+    def __init__(self, data, sizes):
+        self.data, self.sizes, self.pos, self.k = bytes(data), list(sizes), 0, 0
+
+    def read(self, _n):
+        n = self.sizes[self.k % len(self.sizes)]
+        self.k += 1
+        piece = self.data[self.pos:self.pos + n]
+        self.pos += len(piece)
+        return piece
+
+
+def _stream(ctx, src, sizes, window=0):
+    import lzfse_rust_amd as m
+    out = io.BytesIO()
+    dec = m.LzfseRingDecoder(context=ctx, window=window)
+    u, v = dec.decode(PieceReader(src, sizes), out)
+    return u, v, out.getvalue()
+
+
+def _status(ctx, src, sizes, window=0):
+    import lzfse_rust_amd as m
+    try:
+        _stream(ctx, src, sizes, window)
+        return 0
+    except m.LzfseError as e:
+        return e.status
+
+
+def test_stream_fixtures_any_piece_size(ctx, oracle, golden_dir):
+    """Every fixture of the reference (all block kinds), pieces from 1 byte to the whole file, windows from one block up."""
+    fs = []
+    for sub in ("snappy", "special", "mutate"):
+        fs += sorted(glob.glob(os.path.join(golden_dir, sub, "*.lzfse")))
+    rng = np.random.default_rng(5)
+    for f in fs:
+        src = open(f, "rb").read()
+        bad = oracle.decode_status(src, BIG_CAP)
+        if bad:      # special/null.vx2.lzfse: a block the reference rejects
+            assert _status(ctx, src, [7]) == bad, f
+            continue
+        want = oracle.decode(src)
+        for window in (0, 1, 100000):
+            sizes = [int(x) for x in rng.integers(1, max(2, len(src) // 3), size=7)]
+            u, v, got = _stream(ctx, src, sizes, window)
+            assert got == want, (f, window, sizes)
+            assert (u, v) == (len(src), len(want)), f
+    small = open(os.path.join(golden_dir, "mutate", "vx2.lzfse"), "rb").read()
+    assert _stream(ctx, small, [1])[2] == oracle.decode(small)      # byte by byte
+    assert _stream(ctx, b"bvx$", [1]) == (4, 0, b"")
+
+
+def test_stream_windows_carry_the_match_window(ctx, oracle, snappy_raw):
+    """Matches reach back up to 262 139 bytes across the boundary of two device calls: a 250 000-byte random page repeated
+    (every match is about that far), text, and a long run; default and small windows."""
+    page = rng_gen_vec(9, 250000)
+    raws = [page * 40, snappy_raw["lcet10.txt"] * 25, bytes(9 << 20) + page + bytes(1 << 20) + page]
+    for raw in raws:
+        enc = oracle.encode(raw)
+        for window, sizes in ((0, [1 << 20]), (300000, [70001, 13]), (1 << 20, [len(enc)])):
+            u, v, got = _stream(ctx, enc, sizes, window)
+            assert got == raw and (u, v) == (len(enc), len(raw)), (len(raw), window)
+
+
+def test_stream_errors_match_the_slice_path(ctx, oracle, golden_dir, snappy_raw):
+    """Damaged, cut and over-long streams: the status of LzfseDecoder::decode_bytes on the whole input, for any piece size
+    (mutate_0.rs; decode/decoder.rs:93-95 for bytes behind bvx$)."""
+    rng = np.random.default_rng(23)
+    cases = []
+    for k in ("raw", "vx1", "vx2", "vxn"):
+        base = open(os.path.join(golden_dir, "mutate", k + ".lzfse"), "rb").read()
+        for i in rng.choice(len(base), size=min(60, len(base)), replace=False):
+            m = bytearray(base)
+            m[i] ^= 1 << int(rng.integers(0, 8))
+            cases.append(bytes(m))
+    big = oracle.encode(snappy_raw["lcet10.txt"] * 3)      # 30+ blocks
+    for _ in range(40):
+        m = bytearray(big)
+        if rng.random() < 0.4:
+            m = m[: int(rng.integers(0, len(m)))]
+        else:
+            for _ in range(int(rng.integers(1, 4))):
+                m[int(rng.integers(0, len(m)))] ^= 1 << int(rng.integers(0, 8))
+        cases.append(bytes(m))
+    enc = oracle.encode(snappy_raw["html"])
+    cases += [enc[:-1], enc[:-4], enc[:-5], enc + b"\0", enc + enc, b"abcd" + enc, enc[:100], b"", b"bvx", b"bvx$bvx$", big + b"x"]
+    n_err = 0
+    for c in cases:
+        want = oracle.decode_status(c, BIG_CAP)
+        if want == 6:      # the oracle's buffer, not the stream: a header that promises more than BIG_CAP
+            continue
+        n_err += want != 0
+        for window, sizes in ((0, [len(c) + 1]), (50000, [int(x) for x in rng.integers(1, 5000, size=5)])):
+            got = _status(ctx, c, sizes, window)
+            assert got == want, (got, want, len(c), window)
+    assert n_err > 100
+    assert _status(ctx, enc + b"\0", [len(enc), 1]) == oracle.decode_status(enc + b"\0", BIG_CAP) != 0
+
+
+def test_stream_output_before_an_error_is_the_true_prefix(ctx, oracle, snappy_raw):
+    """What the sink received before a late error is what the stream decodes to up to there (the ring decoder flushes as it
+    goes), and the error is sticky."""
+    import lzfse_rust_amd as m
+    raw = snappy_raw["lcet10.txt"] * 12
+    enc = bytearray(oracle.encode(raw))
+    enc[-3000] ^= 0x55      # in the last block
+    out = io.BytesIO()
+    with pytest.raises(m.LzfseError):
+        m.LzfseRingDecoder(context=ctx, window=1 << 20).decode(PieceReader(enc, [100000]), out)
+    got = out.getvalue()
+    assert len(got) >= 3 << 20 and raw.startswith(got)
+    L = ctx._lib
+    h = C.c_void_p()
+    assert L.lzfse_mi_dstream_create(ctx._h, 0, C.byref(h)) == 0
+    from lzfse_rust_amd import _native
+    cb = _native.WRITE_FN(lambda _u, _p, _n: 0)
+    a = np.frombuffer(b"bvxQ....", dtype=np.uint8)
+    st = L.lzfse_mi_dstream_feed(h, a.ctypes.data, a.size, 0, cb, None)
+    assert st == oracle.decode_status(b"bvxQ....", 100) != 0
+    assert L.lzfse_mi_dstream_feed(h, a.ctypes.data, a.size, 1, cb, None) == st
+    L.lzfse_mi_dstream_destroy(h)
+
+
+def test_stream_sink_failure_travels_back(ctx, oracle, snappy_raw):
+    class Full:
+        def write(self, _b):
+            raise OSError("disk full")
+
+    import lzfse_rust_amd as m
+    with pytest.raises(OSError):
+        m.LzfseRingDecoder(context=ctx).decode(PieceReader(oracle.encode(snappy_raw["html"]), [4096]), Full())
