@@ -87,6 +87,9 @@ enum {
     LZFSE_MI_OPT_ENCODE_LANES = 1,  /* 0: chosen by batch size (default), 1: one pass ("exclusive" kernel timing), 2..4 */
     LZFSE_MI_OPT_DECODE_LANES = 2,
     LZFSE_MI_OPT_STAGGER = 3,       /* 1: encode lanes start one after the other (default 0: together) */
+    LZFSE_MI_OPT_DECODE_PIPE = 4,   /* several workgroups per stream in the LZ stage of decode: 0 by the batch's shape (default),
+                                       1 never, else K | variant << 8: K workgroups (2..64) for every stream of the tile
+                                       kernel, variant 0 = 256 threads / 8 KiB tiles, 1 = 1024 threads / 32 KiB tiles */
     LZFSE_MI_OPT_DIAG_LZ_PATH = 100, /* -1: by cost, 0: tile kernel only, 1: pointer jumping for every stream */
     LZFSE_MI_OPT_DIAG_LZ_TILE = 101, /* -1: by stream count, 0: 256-thread / 8 KiB tile, 1: 1024-thread / 32 KiB tile */
     LZFSE_MI_OPT_DIAG_STATS = 102,   /* bit mask: per-stage statistics on stderr */

@@ -108,7 +108,7 @@ struct lzfse_mi_ctx {
     // batch descriptors / results
     DevBuf d_streams, d_walk, d_plan, d_blocks, d_bres, d_sres;
     // decode scratch
-    DevBuf d_lmds, d_lits, d_origin, d_jerr, d_wcache, d_fwalk;
+    DevBuf d_lmds, d_lits, d_origin, d_jerr, d_wcache, d_fwalk, d_ck, d_lzp;
     // encode scratch (encode.hip)
     EncScratch enc;
     // host-pointer API staging
@@ -134,6 +134,9 @@ struct lzfse_mi_ctx {
     // lzfse_mi_set_option
     int opt_lanes_enc = 0, opt_lanes_dec = 0;  // sub-batches run side by side (0: chosen by size, 1: one)
     int opt_stagger = 0;
+    int opt_pipe = 0;      // LZFSE_MI_OPT_DECODE_PIPE
+    bool pipe_broken = false;   // a launch found the workgroups of one stream on different XCDs: never again on this context
+    int lane_share = 1;    // sub-batches running side by side with this one (split_batch)
     int diag_lz_jump = -1, diag_lz_variant = -1, diag_stats = 0, diag_chain = 0, diag_walk = 0;  // diagnostic build only
 
     hipEvent_t get_event() {
@@ -278,7 +281,7 @@ void lzfse_mi_destroy(lzfse_mi_ctx *c) {
     for (auto &g : c->gates) if (g.ev) (void)hipEventDestroy(g.ev);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->d_streams, &c->d_walk, &c->d_plan, &c->d_blocks, &c->d_bres, &c->d_sres,
-                      &c->d_lmds, &c->d_lits, &c->d_origin, &c->d_jerr, &c->d_wcache, &c->d_fwalk, &c->d_in, &c->d_out, &c->d_small})
+                      &c->d_lmds, &c->d_lits, &c->d_origin, &c->d_jerr, &c->d_wcache, &c->d_fwalk, &c->d_ck, &c->d_lzp, &c->d_in, &c->d_out, &c->d_small})
         b->release();
     enc_scratch_release(c->enc);
     c->h_in.release();
@@ -457,7 +460,7 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
     for (uint32_t i = 0; i < ns; i++) {
         StreamPlan &p = h_plan[i];
         p.blk_base = nb; p.lmd_base = nl; p.lit_base = nu; p.n_blocks = h_walk[i].n_blocks; p.skip = 0;
-        p.jbase = 0; p.jump = 0; p.turn = i;
+        p.jbase = 0; p.jump = 0; p.turn = i; p.pipe = 0; p.pad = 0;
         statuses[i] = LZFSE_MI_OK;
         out_lens[i] = 0;
         // A stream whose walk failed at block k still has its first k blocks decoded: the reference decodes in order, so
@@ -475,12 +478,40 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
         }
     }
     if (nb > 0x7FFFFFFFull) return LZFSE_MI_UNSUPPORTED;
+    // Streams of the tile kernel that are large and few share several workgroups each (dec_lzp_kernel): with hundreds of
+    // streams, or small ones, one workgroup per stream already fills the chip.
+    std::vector<uint32_t> mlist;
+    int pipe_variant = 1;
+    uint32_t pipe_k = 0;
+    if (c->opt_pipe != 1 && !c->pipe_broken) {
+        const bool forced = c->opt_pipe > 1;
+        for (uint32_t i = 0; i < ns; i++)
+            if (!h_plan[i].skip && !h_plan[i].jump && h_plan[i].n_blocks && h_walk[i].n_vxn == 0 && (forced || h_walk[i].raw_total >= (512ull << 10)))
+                mlist.push_back(i);
+        const size_t share = (size_t)std::max(1, c->lane_share);
+        if (mlist.empty()) pipe_k = 0;
+        else if (forced) { pipe_k = (uint32_t)(c->opt_pipe & 0xFF); pipe_variant = (c->opt_pipe >> 8) & 1; }
+        else if (mlist.size() * share <= 128) { pipe_variant = 1; pipe_k = (uint32_t)std::min<size_t>(8, 256 / (mlist.size() * share)); }
+        else { pipe_variant = 0; pipe_k = (uint32_t)std::min<size_t>(16, 1280 / (mlist.size() * share)); }
+        if (pipe_k < 2 && !forced) { mlist.clear(); pipe_k = 0; }
+        if (pipe_k < 1) mlist.clear();
+        for (uint32_t i : mlist) h_plan[i].pipe = pipe_k;
+    }
     {
         // order of the tile kernel's workgroups: streams by decreasing size (plan[b].turn)
         std::vector<uint32_t> turn(ns);
         for (uint32_t i = 0; i < ns; i++) turn[i] = i;
         std::stable_sort(turn.begin(), turn.end(), [&](uint32_t a, uint32_t b) { return h_walk[a].raw_total > h_walk[b].raw_total; });
         for (uint32_t b = 0; b < ns; b++) h_plan[b].turn = turn[b];
+        std::stable_sort(mlist.begin(), mlist.end(), [&](uint32_t a, uint32_t b) { return h_walk[a].raw_total > h_walk[b].raw_total; });
+    }
+    uint32_t *d_lzp_state = nullptr, *d_mlist = nullptr;
+    if (!mlist.empty()) {
+        if (!c->d_ck.ensure(((nl >> 8) + nb + 2) * sizeof(uint2)) || !c->d_lzp.ensure(((size_t)4 * ns + mlist.size()) * 4)) return LZFSE_MI_IO;
+        d_lzp_state = (uint32_t *)c->d_lzp.p;
+        d_mlist = d_lzp_state + 4 * (size_t)ns;
+        HIP_TRY(hipMemsetAsync(d_lzp_state, 0, (size_t)4 * ns * 4, st));
+        HIP_TRY(hipMemcpyAsync(d_mlist, mlist.data(), mlist.size() * 4, hipMemcpyHostToDevice, st));
     }
     if (!c->d_blocks.ensure((nb + 1) * sizeof(BlockDesc)) || !c->d_bres.ensure((nb + 1) * sizeof(BlockResult)) ||
         !c->d_lmds.ensure((nl + 64) * sizeof(LmdRec)) || !c->d_lits.ensure(nu + 256) || !c->d_origin.ensure((nj + 16) * 4) ||
@@ -518,6 +549,11 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
                       (const StreamPlan *)c->d_plan.p, ns, (const BlockDesc *)c->d_blocks.p,
                       (const BlockResult *)c->d_bres.p, (const LmdRec *)c->d_lmds.p, (const uint8_t *)c->d_lits.p,
                       (uint8_t *)d_dst, (StreamResult *)c->d_sres.p, st);
+        if (!mlist.empty())
+            launch_dec_lzp(pipe_variant, pipe_k, (const uint8_t *)d_src, (const StreamIn *)c->d_streams.p,
+                           (const StreamPlan *)c->d_plan.p, d_mlist, (uint32_t)mlist.size(), (const BlockDesc *)c->d_blocks.p,
+                           (uint32_t)nb, (const BlockResult *)c->d_bres.p, (const LmdRec *)c->d_lmds.p, (const uint8_t *)c->d_lits.p,
+                           (uint2 *)c->d_ck.p, (uint8_t *)d_dst, (StreamResult *)c->d_sres.p, d_lzp_state, st);
     }
     if (nj) {
         launch_dec_jump((const uint8_t *)d_src, (const StreamIn *)c->d_streams.p, (const StreamPlan *)c->d_plan.p,
@@ -529,6 +565,24 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
     HIP_TRY(hipMemcpyAsync(h_sres.data(), c->d_sres.p, ns * sizeof(StreamResult), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (hipGetLastError() != hipSuccess) return LZFSE_MI_IO;
+    {
+        // The pipelined LZ kernel hands data from workgroup to workgroup through one XCD's L2 and checks that it may
+        // (XCC id of every workgroup that touches a stream). If a launch ever says no, its streams are decoded again by
+        // the one-workgroup kernel, and this context stops using the pipelined one.
+        bool again = false;
+        for (uint32_t i : mlist) again |= h_sres[i].status == LZP_PLACEMENT_STATUS;
+        if (again) {
+            c->pipe_broken = true;
+            for (uint32_t i : mlist) h_plan[i].pipe = 0;
+            HIP_TRY(hipMemcpyAsync(c->d_plan.p, h_plan.data(), ns * sizeof(StreamPlan), hipMemcpyHostToDevice, st));
+            launch_dec_lz(1, (const uint8_t *)d_src, (const StreamIn *)c->d_streams.p, (const StreamPlan *)c->d_plan.p, ns,
+                          (const BlockDesc *)c->d_blocks.p, (const BlockResult *)c->d_bres.p, (const LmdRec *)c->d_lmds.p,
+                          (const uint8_t *)c->d_lits.p, (uint8_t *)d_dst, (StreamResult *)c->d_sres.p, st);
+            HIP_TRY(hipMemcpyAsync(h_sres.data(), c->d_sres.p, ns * sizeof(StreamResult), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (hipGetLastError() != hipSuccess) return LZFSE_MI_IO;
+        }
+    }
     if ((c->diag_stats & 4) && nj) {
         uint32_t hf[20] = {};
         if (hipMemcpy(hf, d_jflags, sizeof hf, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -638,6 +692,7 @@ static int split_batch(lzfse_mi_ctx *c, batch_dev_fn one, int lanes, bool stagge
     if (lanes > LZFSE_MI_MAX_LANES) lanes = LZFSE_MI_MAX_LANES;
     while (lanes > 1 && (count < (size_t)4 * lanes || total < ((uint64_t)lanes << 21))) lanes--;
     auto unsplit = [&]() {
+        c->lane_share = 1;
         c->detail.clear();
         const int r = one(c, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap, out_lens, statuses);
         c->detail_out = c->detail;
@@ -676,6 +731,7 @@ static int split_batch(lzfse_mi_ctx *c, batch_dev_fn one, int lanes, bool stagge
     for (int k = 0; ok && k + 1 < lanes; k++) {
         ok = hipStreamWaitEvent(c->shadow[k]->stream, c->split_ev, 0) == hipSuccess;
         c->shadow[k]->timing = c->timing;
+        c->shadow[k]->opt_pipe = c->opt_pipe;
         c->shadow[k]->diag_lz_jump = c->diag_lz_jump; c->shadow[k]->diag_lz_variant = c->diag_lz_variant;
         c->shadow[k]->diag_stats = c->diag_stats; c->shadow[k]->diag_chain = c->diag_chain; c->shadow[k]->diag_walk = c->diag_walk;
     }
@@ -687,6 +743,7 @@ static int split_batch(lzfse_mi_ctx *c, batch_dev_fn one, int lanes, bool stagge
     }
     for (int k = 0; k < lanes; k++) {
         lzfse_mi_ctx *cx = k == 0 ? c : c->shadow[k - 1];
+        cx->lane_share = lanes;
         cx->gate_in = (stagger && k > 0) ? &c->gates[k - 1] : nullptr;
         cx->gate_out = (stagger && k + 1 < lanes) ? &c->gates[k] : nullptr;
         if (cx->gate_out) cx->gate_out->arm();
@@ -750,6 +807,10 @@ int lzfse_mi_set_option(lzfse_mi_ctx *c, int option, int64_t value) {
         (option == LZFSE_MI_OPT_ENCODE_LANES ? c->opt_lanes_enc : c->opt_lanes_dec) = (int)value;
         return LZFSE_MI_OK;
     case LZFSE_MI_OPT_STAGGER: c->opt_stagger = value != 0; return LZFSE_MI_OK;
+    case LZFSE_MI_OPT_DECODE_PIPE:
+        if (value < 0 || value > 0x1FF || (value > 1 && (value & 0xFF) > 64) || (value > 1 && (value & 0xFF) == 0)) return LZFSE_MI_BAD_ARGUMENT;
+        c->opt_pipe = (int)value;
+        return LZFSE_MI_OK;
 #ifdef LZFSE_MI_DIAG
     case LZFSE_MI_OPT_DIAG_LZ_PATH: c->diag_lz_jump = (int)value; return LZFSE_MI_OK;
     case LZFSE_MI_OPT_DIAG_LZ_TILE: c->diag_lz_variant = (int)value; return LZFSE_MI_OK;

@@ -53,6 +53,8 @@ struct StreamPlan {
     uint64_t jbase;  // pointer-jumping LZ path: first entry of the stream in the origin array
     int32_t jump;    // != 0: LZ stage by pointer jumping (large streams), else by the tile kernel
     uint32_t turn;   // plan[b].turn = the stream workgroup b of the tile kernel decodes: longest streams first
+    uint32_t pipe;   // != 0: LZ stage by the pipelined tile kernel (several workgroups per stream), else one workgroup
+    uint32_t pad;
 };
 
 struct BlockDesc {

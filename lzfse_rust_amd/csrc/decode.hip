@@ -909,7 +909,7 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
     const uint32_t s = plan[blockIdx.x].turn;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const StreamPlan pl = plan[s];
-    if (pl.skip || pl.jump) return;
+    if (pl.skip || pl.jump || pl.pipe) return;
     const StreamIn in = streams[s];
     uint8_t *dst = dst_all + in.dst_off;
     uint64_t out_pos = 0;  // bytes produced so far in this stream
@@ -1138,6 +1138,377 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------------------------ LZ stage, several workgroups per stream
+//
+// One workgroup per stream copies ~0.6 GB/s: with a few dozen streams of some MiB most of the chip idles while the
+// stream sets the time. Most of a tile's work does not need the output of the tiles before it: the scan of the LMD
+// lengths, the literal copies, the origins of the matches that read the tile itself and their pointer jumping -- about
+// three quarters of the cycles. Only the copies from earlier output, the final gather and the write-back do. So K
+// workgroups share a stream: a ticket is one group of NT consecutive LMDs of a block (dec_ck_kernel leaves the literal
+// and output offset of every group); a workgroup draws the next ticket, does the independent part, waits until all
+// earlier tickets are published (done[s] == ticket), does the dependent part, publishes. Tickets are drawn in order by
+// running workgroups, so the holder of the ticket somebody waits for is always running: no assumption on residency.
+// Errors are raised by a ticket at its turn only, so the first error in stream order is the one reported, as in the
+// one-workgroup kernel (and the reference); everybody else sees the flag and leaves.
+
+// Loads of what ANOTHER workgroup of the same XCD wrote during this launch: past this CU's L1 (which may hold the line as it
+// was before), served by the XCD's L2, where the writer's stores are once they are acknowledged. Volatile accesses carry the
+// sc0 sc1 bits; scripts/micro/l1_inv.hip shows the stale line without them and that buffer_inv sc0 does not help.
+typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+__device__ __forceinline__ uint64_t ld_u64_l2(const uint8_t *p) {
+    return *(const volatile __attribute__((address_space(1))) u64_unaligned *)(uintptr_t)p;
+}
+__device__ __forceinline__ uint8_t ld_u8_l2(const uint8_t *p) { return *(const volatile __attribute__((address_space(1))) uint8_t *)(uintptr_t)p; }
+__device__ __forceinline__ uint32_t xcc_id() {
+    uint32_t x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & 15u;
+}
+
+
+constexpr uint32_t LZP_ERR = 0x80000000u;       // done[s]: the stream has failed, its result is written
+constexpr uint32_t LZP_SPIN_MAX = 1u << 22;     // polls of done[s] before a workgroup gives up (never reached: a seized launch must still drain)
+
+// literal / output offsets (block-relative) at the start of every 256 LMDs of a block: ck[(lmd_base >> 8) + block + group]
+__global__ __launch_bounds__(256) void dec_ck_kernel(const StreamPlan *__restrict__ plan, const BlockDesc *__restrict__ blocks,
+                                                     uint32_t n_blocks, const BlockResult *__restrict__ bres,
+                                                     const LmdRec *__restrict__ lmds, uint2 *__restrict__ ck) {
+    __shared__ uint32_t sh[2 * 4 + 4];
+    const uint32_t b = blockIdx.x;
+    if (b >= n_blocks) return;
+    const BlockDesc d = blocks[b];
+    if (d.kind != KIND_VX1 && d.kind != KIND_VX2) return;
+    const StreamPlan pl = plan[d.stream];
+    if (pl.skip || !pl.pipe || bres[b].status) return;
+    const LmdRec *bl = lmds + d.lmd_base;
+    uint2 *out = ck + (d.lmd_base >> 8) + b;
+    uint32_t run_l = 0, run_s = 0;
+    for (uint32_t g0 = 0; g0 < d.n_lmd; g0 += 256) {
+        const uint32_t idx = g0 + threadIdx.x;
+        const LmdRec r = idx < d.n_lmd ? bl[idx] : make_uint2(0, 0);
+        const uint32_t l = r.x & 0xFFFF, m = r.x >> 16;
+        uint32_t ex_l, ex_s, tot_l, tot_s;
+        block_excl_scan2<256>(l, l + m, ex_l, ex_s, tot_l, tot_s, sh);
+        if (threadIdx.x == 0) out[g0 >> 8] = make_uint2(run_l, run_s);
+        run_l += tot_l; run_s += tot_s;
+    }
+}
+
+template <int NT, int TILE>
+__global__ __launch_bounds__(NT) void dec_lzp_kernel(
+    const uint8_t *__restrict__ src, const StreamIn *__restrict__ streams, const StreamPlan *__restrict__ plan,
+    const uint32_t *__restrict__ mlist, uint32_t n_multi, uint32_t K,
+    const BlockDesc *__restrict__ blocks, const BlockResult *__restrict__ bres,
+    const LmdRec *__restrict__ lmds, const uint8_t *__restrict__ lits, const uint2 *__restrict__ ck, uint8_t *dst_all,
+    StreamResult *__restrict__ sres, uint32_t *__restrict__ state) {
+    constexpr int NW = NT / 64;
+    __shared__ __attribute__((aligned(16))) uint8_t tile[TILE + 32];
+    __shared__ uint32_t s_off[NT];
+    __shared__ uint32_t s_lm[NT];
+    __shared__ uint32_t s_d[NT];
+    __shared__ uint32_t s_lit[NT];
+    __shared__ uint16_t s_org[TILE];
+    __shared__ uint32_t s_dm[NT];
+    __shared__ uint32_t s_long[2 * NT];   // slot * 4 + kind: 0 long literal run, 1 long match from earlier output, 2 long match that reads the tile
+    __shared__ uint32_t s_scan[2 * NW + 4];
+    __shared__ uint32_t s_cnt[4];
+    __shared__ uint32_t s_tk[2];
+    __shared__ int s_status;
+
+    // the K workgroups of a stream on one XCD (workgroups go to the XCDs round robin): what one writes the next one
+    // finds in the same L2
+    const uint32_t xcd = blockIdx.x & 7, wq = blockIdx.x >> 3;
+    const uint32_t j = (wq / K) * 8 + xcd;
+    if (j >= n_multi) return;
+    const uint32_t s = mlist[j];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const StreamPlan pl = plan[s];
+    const StreamIn in = streams[s];
+    uint8_t *dst = dst_all + in.dst_off;
+    uint32_t *next = state + 4 * (size_t)s, *done = next + 1, *home = next + 2;
+    if (pl.n_blocks == 0) {
+        if (wq % K == 0 && tid == 0) { StreamResult r = {}; sres[s] = r; }
+        return;
+    }
+    auto n_tickets = [](const BlockDesc &bd) -> uint32_t {
+        if (bd.kind != KIND_VX1 && bd.kind != KIND_VX2) return 1u;
+        return bd.n_lmd ? (bd.n_lmd + NT - 1) / NT : 1u;
+    };
+    // all threads: false when the stream has failed (or the wait gave up) -- leave
+    auto wait_turn = [&](uint32_t T) -> bool {
+        if (tid == 0) {
+            uint32_t v, spins = 0;
+            while ((v = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != T) {
+                if (v & LZP_ERR) break;
+                if (++spins > LZP_SPIN_MAX) {
+                    StreamResult r = {}; r.status = LZFSE_MI_IO; sres[s] = r;
+                    __hip_atomic_store(done, LZP_ERR, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    v = LZP_ERR;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            s_tk[1] = v;
+        }
+        __syncthreads();
+        const uint32_t v = s_tk[1];
+        __syncthreads();
+        if (v != T) return false;
+        return true;
+    };
+    // all threads, at the ticket's turn: the stream ends here with `status`
+    auto fail = [&](int status, uint64_t out_len) {
+        if (tid == 0) {
+            StreamResult r = {}; r.out_len = out_len; r.status = status; sres[s] = r;
+            __hip_atomic_store(done, LZP_ERR, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    // all threads, at the end of the ticket's turn: everything this workgroup stored is at L2 before the flag moves
+    auto publish = [&](uint32_t T, bool last, uint64_t out_len) {
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (tid == 0) {
+            if (last) { StreamResult r = {}; r.out_len = out_len; r.status = 0; sres[s] = r; }
+            __hip_atomic_store(done, T + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+
+    uint32_t bi = 0, tick_lo = 0;
+    bool placed = false;
+    BlockDesc d = blocks[pl.blk_base];
+    uint32_t nt_b = n_tickets(d);
+    if (tid == 0) s_status = 0;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s_tk[0] = atomicAdd(next, 1u);
+        __syncthreads();
+        const uint32_t T = s_tk[0];
+        while (T >= tick_lo + nt_b) {
+            tick_lo += nt_b;
+            if (++bi >= pl.n_blocks) break;
+            d = blocks[pl.blk_base + bi];
+            nt_b = n_tickets(d);
+        }
+        if (bi >= pl.n_blocks) break;
+        const uint32_t g = T - tick_lo;
+        const bool last = bi + 1 == pl.n_blocks && g + 1 == nt_b;
+        if (!placed) {
+            // the hand-over below relies on one L2: every workgroup that works on the stream must be on the same XCD
+            if (tid == 0) {
+                const uint32_t mine = xcc_id() + 1;
+                const uint32_t was = atomicCAS(home, 0u, mine);
+                s_tk[1] = (was == 0 || was == mine) ? 1u : 0u;
+            }
+            __syncthreads();
+            const bool ok = s_tk[1] != 0;
+            __syncthreads();
+            if (!ok) {
+                if (wait_turn(T)) fail(LZP_PLACEMENT_STATUS, 0);
+                break;
+            }
+            placed = true;
+        }
+        const uint64_t blk_end = d.dst_rel + d.n_raw;
+
+        if (d.kind == KIND_RAW) {
+            if (!wait_turn(T)) break;
+            if (blk_end > in.dst_cap) { fail(LZFSE_MI_BUFFER_OVERFLOW, d.dst_rel); break; }
+            const uint8_t *p = src + d.src_pos + 8;
+            for (uint32_t i = tid; i < d.n_raw; i += NT) dst[d.dst_rel + i] = p[i];
+            publish(T, last, blk_end);
+            continue;
+        }
+        if (d.kind == KIND_VXN) {   // (the host keeps streams with LZVN blocks on the one-workgroup kernel)
+            if (!wait_turn(T)) break;
+            fail(LZFSE_MI_IO, d.dst_rel);
+            break;
+        }
+        const BlockResult br = bres[pl.blk_base + bi];
+        const LmdRec *bl = lmds + d.lmd_base;
+        if (br.status || blk_end > in.dst_cap) {
+            // nothing of this block is written; its first ticket says what the reference's loop would have met first,
+            // the others (their checkpoints may not exist) only wait for that
+            if (!wait_turn(T)) break;
+            int e = LZFSE_MI_IO;
+            if (g == 0) {
+                e = lmds_first_fault<NT>(bl, br.status ? br.ok_until : d.n_lmd, d.dst_rel, in.dst_cap, s_scan);
+                if (!e) e = br.status ? br.status : LZFSE_MI_BUFFER_OVERFLOW;
+            }
+            fail(e, d.dst_rel);
+            break;
+        }
+        const uint8_t *blit = lits + d.lit_base;
+        const uint2 c0 = d.n_lmd ? ck[(d.lmd_base >> 8) + (pl.blk_base + bi) + ((g * NT) >> 8)] : make_uint2(0, 0);
+        uint32_t lit_run = c0.x;
+        uint64_t out_pos = d.dst_rel + c0.y;
+        const uint32_t g_end = min(d.n_lmd, (g + 1) * (uint32_t)NT);
+        bool have_turn = false, gone = false;
+        for (uint32_t g0 = g * NT; g0 < g_end;) {
+            const uint32_t idx = g0 + tid;
+            const bool valid = idx < g_end;
+            LmdRec r = valid ? bl[idx] : make_uint2(0, 0);
+            const uint32_t l = r.x & 0xFFFF, m = r.x >> 16, dd = r.y;
+            const uint32_t span = l + m;
+            uint32_t ex_l, ex_s, tot_l, tot_s;
+            block_excl_scan2<NT>(l, span, ex_l, ex_s, tot_l, tot_s, s_scan);
+            const bool part = valid && (ex_s + span <= (uint32_t)TILE);
+            if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; s_cnt[2] = 0; s_cnt[3] = 0; }
+            __syncthreads();
+            unsigned long long pb = __ballot(part);
+            if (lane == 0 && pb) atomicAdd(&s_cnt[0], (uint32_t)__popcll(pb));
+            __syncthreads();
+            const uint32_t cnt = s_cnt[0];
+            if (tid == (int)cnt - 1) s_cnt[1] = ex_s + span;
+            __syncthreads();
+            const uint32_t tile_len = s_cnt[1];
+            const uint64_t tile_base = out_pos;
+            const uint32_t pad = (uint32_t)((uintptr_t)(dst + tile_base) & 15);
+            uint8_t *t = tile + pad;
+
+            // ---- independent part: classification, literals, origins of the matches that read the tile ----
+            const uint64_t p_match = tile_base + ex_s + l;
+            const bool bad_d = part && m != 0 && (dd == 0 || (uint64_t)dd > p_match);
+            bool dep = false, far = false, lit_long = false;
+            if (part && !bad_d) {
+                s_off[tid] = ex_s; s_lm[tid] = r.x; s_d[tid] = dd; s_lit[tid] = lit_run + ex_l;
+                if (l) {
+                    if (l <= SHORT_COPY) {
+                        const uint8_t *ls = blit + lit_run + ex_l;
+                        const uint64_t w0 = ld_u64(ls), w1 = l > 8 ? ld_u64(ls + 8) : 0, w2 = l > 16 ? ld_u64(ls + 16) : 0;
+                        lds_put24(t + ex_s, l, w0, w1, w2);
+                    } else lit_long = true;
+                }
+                if (m) {
+                    const uint32_t slen = m < dd ? m : dd;
+                    if (dd >= m && p_match - dd + slen <= tile_base) far = true; else dep = true;
+                }
+            }
+            const bool m_long = (far || dep) && m > SHORT_COPY;
+            unsigned long long bb = __ballot(bad_d);
+            if (bb && lane == 0) atomicOr((int *)&s_status, LZFSE_MI_BAD_D_VALUE);
+            const uint32_t nl = (lit_long ? 1u : 0u) + (m_long ? 1u : 0u);
+            uint32_t ex_dep, ex_long, tot_dep, tot_long;
+            block_excl_scan2<NT>(dep ? 1u : 0u, nl, ex_dep, ex_long, tot_dep, tot_long, s_scan);
+            if (lit_long) s_long[ex_long++] = tid * 4;
+            if (m_long) s_long[ex_long] = tid * 4 + (far ? 1 : 2);
+            const uint32_t mo = ex_s + l;
+            const int64_t so = (int64_t)mo - (int64_t)dd;
+            static_assert(TILE / NT <= 32 && (NT & (NT - 1)) == 0, "one mask bit per owned byte");
+            constexpr uint32_t NTS = 31 - __builtin_clz((unsigned)NT);
+            s_dm[tid] = 0;
+            __syncthreads();
+            const bool tile_bad = s_status != 0;
+            if (!tile_bad) {
+                if (dep && m <= SHORT_COPY) {
+                    for (uint32_t k = 0; k < m; k++) {
+                        const int64_t sp = so + k;
+                        const uint32_t q = mo + k;
+                        if (sp >= 0) { s_org[q] = (uint16_t)sp; atomicOr(&s_dm[q & (NT - 1)], 1u << (q >> NTS)); }
+                    }
+                }
+                for (uint32_t q = wave; q < tot_long; q += NW) {
+                    const uint32_t e = s_long[q], slot = e >> 2, kind = e & 3;
+                    const uint32_t o = s_off[slot], lm = s_lm[slot];
+                    const uint32_t ll = lm & 0xFFFF, mm = lm >> 16;
+                    if (kind == 0) {
+                        const uint8_t *ls = blit + s_lit[slot];
+                        for (uint32_t k = lane; k < ll; k += 64) t[o + k] = ls[k];
+                    } else if (kind == 2) {
+                        const uint32_t mq = o + ll;
+                        const int64_t sq = (int64_t)mq - (int64_t)s_d[slot];
+                        for (uint32_t k = lane; k < mm; k += 64) {
+                            const int64_t sp = sq + k;
+                            const uint32_t qq = mq + k;
+                            if (sp >= 0) { s_org[qq] = (uint16_t)sp; atomicOr(&s_dm[qq & (NT - 1)], 1u << (qq >> NTS)); }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t dm = s_dm[tid];
+            if (!tile_bad && tot_dep) {
+                uint32_t um = dm;
+                for (;;) {
+#pragma unroll 1
+                    for (int sweep = 0; sweep < JUMP_SWEEPS && um; sweep++)
+                        for (uint32_t m2 = um; m2; m2 &= m2 - 1) {
+                            const uint32_t k = (uint32_t)__builtin_ctz(m2), b = tid + (k << NTS);
+                            const uint32_t o = s_org[b];
+                            if (!((s_dm[o & (NT - 1)] >> (o >> NTS)) & 1u)) { um &= ~(1u << k); continue; }
+                            const uint32_t o1 = s_org[o];
+                            if (!((s_dm[o1 & (NT - 1)] >> (o1 >> NTS)) & 1u)) { s_org[b] = (uint16_t)o1; um &= ~(1u << k); continue; }
+                            s_org[b] = s_org[o1];
+                        }
+                    if (!__syncthreads_or(um != 0)) break;
+                }
+            }
+
+            // ---- the ticket's turn: everything before this tile is written ----
+            if (!have_turn) {
+                if (!wait_turn(T)) { gone = true; break; }
+                have_turn = true;
+            }
+            if (tile_bad) { fail(LZFSE_MI_BAD_D_VALUE, tile_base); gone = true; break; }
+            if (part && m && !m_long) {
+                if (far) {
+                    const uint8_t *ms = dst + (p_match - dd);
+                    if (p_match - dd + 24 <= tile_base) {
+                        const uint64_t w0 = ld_u64_l2(ms), w1 = m > 8 ? ld_u64_l2(ms + 8) : 0, w2 = m > 16 ? ld_u64_l2(ms + 16) : 0;
+                        lds_put24(t + mo, m, w0, w1, w2);
+                    } else {
+                        for (uint32_t k = 0; k < m; k++) t[mo + k] = ld_u8_l2(ms + k);
+                    }
+                } else if (so < 0) {
+                    const uint32_t nb = (uint32_t)min((int64_t)m, -so);
+                    for (uint32_t k = 0; k < nb; k++) t[mo + k] = ld_u8_l2(dst + ((int64_t)tile_base + so + k));
+                }
+            }
+            for (uint32_t q = wave; q < tot_long; q += NW) {
+                const uint32_t e = s_long[q], slot = e >> 2, kind = e & 3;
+                if (kind == 0) continue;
+                const uint32_t lm = s_lm[slot];
+                const uint32_t mq = s_off[slot] + (lm & 0xFFFF), mm = lm >> 16;
+                const int64_t sq = (int64_t)mq - (int64_t)s_d[slot];
+                const uint8_t *ms = dst + ((int64_t)tile_base + sq);
+                if (kind == 1) {
+                    for (uint32_t k = lane; k < mm; k += 64) t[mq + k] = ld_u8_l2(ms + k);
+                } else if (sq < 0) {
+                    const uint32_t nb = (uint32_t)min((int64_t)mm, -sq);
+                    for (uint32_t k = lane; k < nb; k += 64) t[mq + k] = ld_u8_l2(ms + k);
+                }
+            }
+            __syncthreads();
+            if (tot_dep)
+                for (uint32_t m2 = dm; m2; m2 &= m2 - 1) {
+                    const uint32_t b2 = tid + ((uint32_t)__builtin_ctz(m2) << NTS);
+                    t[b2] = t[s_org[b2]];
+                }
+            __syncthreads();
+            {
+                uint8_t *gp = dst + tile_base;
+                uint32_t head = pad ? (16 - pad) : 0;
+                if (head > tile_len) head = tile_len;
+                const uint32_t body = (tile_len - head) & ~15u;
+                if (tid < (int)head) gp[tid] = t[tid];
+                const uint4 *ts = (const uint4 *)(t + head);
+                uint4 *gd = (uint4 *)(gp + head);
+                for (uint32_t k = tid; k < body / 16; k += NT) gd[k] = ts[k];
+                const uint32_t tail0 = head + body;
+                if (tail0 + tid < tile_len && tid < 16) gp[tail0 + tid] = t[tail0 + tid];
+            }
+            out_pos += tile_len;
+            if (tid == (int)cnt - 1) s_cnt[2] = ex_l + l;
+            __syncthreads();
+            lit_run += s_cnt[2];
+            g0 += cnt;
+            __syncthreads();
+        }
+        if (gone) break;
+        if (!have_turn) { if (!wait_turn(T)) break; }   // a block without LMDs
+        publish(T, last, blk_end);
+    }
+}
 
 // ------------------------------------------------------------------------------------ LZ stage by pointer jumping
 //
@@ -1381,6 +1752,21 @@ void launch_dec_lz(int variant, const uint8_t *src, const StreamIn *streams, con
     else
         hipLaunchKernelGGL((dec_lz_kernel<1024, 32768>), dim3(n_streams), dim3(1024), 0, st, src, streams, plan,
                            blocks, bres, lmds, lits, dst, sres);
+}
+
+void launch_dec_lzp(int variant, uint32_t K, const uint8_t *src, const StreamIn *streams, const StreamPlan *plan,
+                    const uint32_t *mlist, uint32_t n_multi, const BlockDesc *blocks, uint32_t n_blocks, const BlockResult *bres,
+                    const LmdRec *lmds, const uint8_t *lits, uint2 *ck, uint8_t *dst, StreamResult *sres, uint32_t *state,
+                    hipStream_t st) {
+    if (!n_multi || !K) return;
+    hipLaunchKernelGGL(dec_ck_kernel, dim3(n_blocks), dim3(256), 0, st, plan, blocks, n_blocks, bres, lmds, ck);
+    const uint32_t grid = ((n_multi + 7) / 8) * 8 * K;
+    if (variant == 0)
+        hipLaunchKernelGGL((dec_lzp_kernel<256, 8192>), dim3(grid), dim3(256), 0, st, src, streams, plan, mlist, n_multi, K,
+                           blocks, bres, lmds, lits, ck, dst, sres, state);
+    else
+        hipLaunchKernelGGL((dec_lzp_kernel<1024, 32768>), dim3(grid), dim3(1024), 0, st, src, streams, plan, mlist, n_multi, K,
+                           blocks, bres, lmds, lits, ck, dst, sres, state);
 }
 
 void launch_dec_jump(const uint8_t *src, const StreamIn *streams, const StreamPlan *plan, const StreamWalk *walk, uint32_t n_streams,
