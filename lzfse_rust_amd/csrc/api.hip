@@ -507,10 +507,10 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
     }
     uint32_t *d_lzp_state = nullptr, *d_mlist = nullptr;
     if (!mlist.empty()) {
-        if (!c->d_ck.ensure(((nl >> 8) + nb + 2) * sizeof(uint2)) || !c->d_lzp.ensure(((size_t)4 * ns + mlist.size()) * 4)) return LZFSE_MI_IO;
+        if (!c->d_ck.ensure(((nl >> 8) + nb + 2) * sizeof(uint2)) || !c->d_lzp.ensure(((size_t)LZP_STATE_WORDS * ns + mlist.size()) * 4)) return LZFSE_MI_IO;
         d_lzp_state = (uint32_t *)c->d_lzp.p;
-        d_mlist = d_lzp_state + 4 * (size_t)ns;
-        HIP_TRY(hipMemsetAsync(d_lzp_state, 0, (size_t)4 * ns * 4, st));
+        d_mlist = d_lzp_state + LZP_STATE_WORDS * (size_t)ns;
+        HIP_TRY(hipMemsetAsync(d_lzp_state, 0, (size_t)LZP_STATE_WORDS * ns * 4, st));
         HIP_TRY(hipMemcpyAsync(d_mlist, mlist.data(), mlist.size() * 4, hipMemcpyHostToDevice, st));
     }
     if (!c->d_blocks.ensure((nb + 1) * sizeof(BlockDesc)) || !c->d_bres.ensure((nb + 1) * sizeof(BlockResult)) ||
@@ -562,7 +562,9 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
                         (uint32_t *)c->d_origin.p, nj, d_jerr, d_jflags, (StreamResult *)c->d_sres.p, c, st);
     }
     std::vector<StreamResult> h_sres(ns);
+    std::vector<uint32_t> h_state(mlist.empty() ? 0 : (size_t)LZP_STATE_WORDS * ns);
     HIP_TRY(hipMemcpyAsync(h_sres.data(), c->d_sres.p, ns * sizeof(StreamResult), hipMemcpyDeviceToHost, st));
+    if (!mlist.empty()) HIP_TRY(hipMemcpyAsync(h_state.data(), d_lzp_state, h_state.size() * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (hipGetLastError() != hipSuccess) return LZFSE_MI_IO;
     {
@@ -570,7 +572,7 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
         // (XCC id of every workgroup that touches a stream). If a launch ever says no, its streams are decoded again by
         // the one-workgroup kernel, and this context stops using the pipelined one.
         bool again = false;
-        for (uint32_t i : mlist) again |= h_sres[i].status == LZP_PLACEMENT_STATUS;
+        for (uint32_t i : mlist) again |= h_state[(size_t)LZP_STATE_WORDS * i + 3] != 0;   // the word a misplaced workgroup sets
         if (again) {
             c->pipe_broken = true;
             for (uint32_t i : mlist) h_plan[i].pipe = 0;
@@ -589,6 +591,14 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
             fprintf(stderr, "jump rounds that still moved bytes:");
             for (int r2 = 0; r2 < 17; r2++) fprintf(stderr, " %u", hf[r2]);
             fprintf(stderr, "\n");
+        }
+    }
+    if ((c->diag_stats & 4) && !mlist.empty()) {
+        for (size_t k = 0; k < mlist.size() && k < 4; k++) {
+            const uint64_t *q = (const uint64_t *)(h_state.data() + (size_t)LZP_STATE_WORDS * mlist[k] + 4);
+            fprintf(stderr, "lzp[%u] K=%u tickets=%llu cycles: setup=%llu ahead=%llu wait=%llu turn=%llu (copies from earlier output %llu, gather %llu, write-back and hand-over %llu)\n", mlist[k], pipe_k,
+                    (unsigned long long)q[4], (unsigned long long)q[0], (unsigned long long)q[1], (unsigned long long)q[2],
+                    (unsigned long long)q[3], (unsigned long long)q[5], (unsigned long long)q[6], (unsigned long long)q[7]);
         }
     }
     if (c->diag_stats & 4) {

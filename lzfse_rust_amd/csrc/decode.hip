@@ -1159,6 +1159,7 @@ typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
 __device__ __forceinline__ uint64_t ld_u64_l2(const uint8_t *p) {
     return *(const volatile __attribute__((address_space(1))) u64_unaligned *)(uintptr_t)p;
 }
+__device__ __forceinline__ uint32_t ld_u32_l2(const uint32_t *p) { return *(const volatile __attribute__((address_space(1))) uint32_t *)(uintptr_t)p; }
 __device__ __forceinline__ uint8_t ld_u8_l2(const uint8_t *p) { return *(const volatile __attribute__((address_space(1))) uint8_t *)(uintptr_t)p; }
 __device__ __forceinline__ uint32_t xcc_id() {
     uint32_t x;
@@ -1226,7 +1227,8 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
     const StreamPlan pl = plan[s];
     const StreamIn in = streams[s];
     uint8_t *dst = dst_all + in.dst_off;
-    uint32_t *next = state + 4 * (size_t)s, *done = next + 1, *home = next + 2;
+    uint32_t *next = state + LZP_STATE_WORDS * (size_t)s, *done = next + 1, *home = next + 2, *bad = next + 3;
+    uint64_t cy_setup = 0, cy_ahead = 0, cy_wait = 0, cy_turn = 0, n_tk = 0, cy_far = 0, cy_gat = 0, cy_wb = 0;   // diagnostics: where a ticket's cycles go
     if (pl.n_blocks == 0) {
         if (wq % K == 0 && tid == 0) { StreamResult r = {}; sres[s] = r; }
         return;
@@ -1239,29 +1241,28 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
     auto wait_turn = [&](uint32_t T) -> bool {
         if (tid == 0) {
             uint32_t v, spins = 0;
-            while ((v = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != T) {
+            while ((v = ld_u32_l2(done)) != T) {
                 if (v & LZP_ERR) break;
-                if (++spins > LZP_SPIN_MAX) {
-                    StreamResult r = {}; r.status = LZFSE_MI_IO; sres[s] = r;
-                    __hip_atomic_store(done, LZP_ERR, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                // (the slow word: a workgroup on another XCD cannot reach this L2, and says so through memory)
+                if ((++spins & 63u) == 0 && (spins > LZP_SPIN_MAX || __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    if (spins > LZP_SPIN_MAX) __hip_atomic_store(bad, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     v = LZP_ERR;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(4);
+                __builtin_amdgcn_s_sleep(1);
             }
             s_tk[1] = v;
         }
         __syncthreads();
         const uint32_t v = s_tk[1];
         __syncthreads();
-        if (v != T) return false;
-        return true;
+        return v == T;
     };
     // all threads, at the ticket's turn: the stream ends here with `status`
     auto fail = [&](int status, uint64_t out_len) {
         if (tid == 0) {
             StreamResult r = {}; r.out_len = out_len; r.status = status; sres[s] = r;
-            __hip_atomic_store(done, LZP_ERR, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(done, LZP_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
     // all threads, at the end of the ticket's turn: everything this workgroup stored is at L2 before the flag moves
@@ -1270,16 +1271,20 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
         __syncthreads();
         if (tid == 0) {
             if (last) { StreamResult r = {}; r.out_len = out_len; r.status = 0; sres[s] = r; }
-            __hip_atomic_store(done, T + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(done, T + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // a plain store: into this XCD's L2
         }
     };
 
     uint32_t bi = 0, tick_lo = 0;
     bool placed = false;
+    // Everything before the end of this workgroup's previous ticket is final (it was published in order): copies from
+    // there need not wait for the turn. What is in flight is at most the K - 1 tickets in between.
+    uint64_t prev_end = 0;
     BlockDesc d = blocks[pl.blk_base];
     uint32_t nt_b = n_tickets(d);
     if (tid == 0) s_status = 0;
     for (;;) {
+        const uint64_t t0 = __builtin_amdgcn_s_memtime();
         __syncthreads();
         if (tid == 0) s_tk[0] = atomicAdd(next, 1u);
         __syncthreads();
@@ -1304,7 +1309,7 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
             const bool ok = s_tk[1] != 0;
             __syncthreads();
             if (!ok) {
-                if (wait_turn(T)) fail(LZP_PLACEMENT_STATUS, 0);
+                if (tid == 0) __hip_atomic_store(bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
             placed = true;
@@ -1317,6 +1322,7 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
             const uint8_t *p = src + d.src_pos + 8;
             for (uint32_t i = tid; i < d.n_raw; i += NT) dst[d.dst_rel + i] = p[i];
             publish(T, last, blk_end);
+            prev_end = blk_end;
             continue;
         }
         if (d.kind == KIND_VXN) {   // (the host keeps streams with LZVN blocks on the one-workgroup kernel)
@@ -1344,6 +1350,8 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
         uint64_t out_pos = d.dst_rel + c0.y;
         const uint32_t g_end = min(d.n_lmd, (g + 1) * (uint32_t)NT);
         bool have_turn = false, gone = false;
+        uint64_t t1 = __builtin_amdgcn_s_memtime(), t2 = t1, t3 = t1, t3b = t1;
+        cy_setup += t1 - t0; n_tk++;
         for (uint32_t g0 = g * NT; g0 < g_end;) {
             const uint32_t idx = g0 + tid;
             const bool valid = idx < g_end;
@@ -1369,7 +1377,7 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
             // ---- independent part: classification, literals, origins of the matches that read the tile ----
             const uint64_t p_match = tile_base + ex_s + l;
             const bool bad_d = part && m != 0 && (dd == 0 || (uint64_t)dd > p_match);
-            bool dep = false, far = false, lit_long = false;
+            bool dep = false, far = false, lit_long = false, early = false;
             if (part && !bad_d) {
                 s_off[tid] = ex_s; s_lm[tid] = r.x; s_d[tid] = dd; s_lit[tid] = lit_run + ex_l;
                 if (l) {
@@ -1381,7 +1389,16 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
                 }
                 if (m) {
                     const uint32_t slen = m < dd ? m : dd;
-                    if (dd >= m && p_match - dd + slen <= tile_base) far = true; else dep = true;
+                    if (dd >= m && p_match - dd + slen <= tile_base) {
+                        far = true;
+                        early = p_match - dd + 24 <= prev_end;    // 24 readable bytes of final output
+                        if (early && m <= SHORT_COPY) {
+                            const uint8_t *ms = dst + (p_match - dd);
+                            const uint64_t w0 = ld_u64_l2(ms), w1 = m > 8 ? ld_u64_l2(ms + 8) : 0, w2 = m > 16 ? ld_u64_l2(ms + 16) : 0;
+                            lds_put24(t + ex_s + l, m, w0, w1, w2);
+                        }
+                        if (early && m > SHORT_COPY) early = p_match - dd + m <= prev_end;   // the whole source
+                    } else dep = true;
                 }
             }
             const bool m_long = (far || dep) && m > SHORT_COPY;
@@ -1391,7 +1408,7 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
             uint32_t ex_dep, ex_long, tot_dep, tot_long;
             block_excl_scan2<NT>(dep ? 1u : 0u, nl, ex_dep, ex_long, tot_dep, tot_long, s_scan);
             if (lit_long) s_long[ex_long++] = tid * 4;
-            if (m_long) s_long[ex_long] = tid * 4 + (far ? 1 : 2);
+            if (m_long) s_long[ex_long] = tid * 4 + (far ? (early ? 3 : 1) : 2);
             const uint32_t mo = ex_s + l;
             const int64_t so = (int64_t)mo - (int64_t)dd;
             static_assert(TILE / NT <= 32 && (NT & (NT - 1)) == 0, "one mask bit per owned byte");
@@ -1414,6 +1431,14 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
                     if (kind == 0) {
                         const uint8_t *ls = blit + s_lit[slot];
                         for (uint32_t k = lane; k < ll; k += 64) t[o + k] = ls[k];
+                    } else if (kind == 3) {
+                        const uint32_t mq = o + ll;
+                        const uint8_t *ms = dst + ((int64_t)tile_base + (int64_t)mq - (int64_t)s_d[slot]);
+                        for (uint32_t k = lane * 8; k < mm; k += 512) {   // (the whole source is final: 8 bytes may be read wherever 8 remain)
+                            const uint32_t nv = min(8u, mm - k);
+                            if (nv == 8) *(u64_unaligned *)(t + mq + k) = ld_u64_l2(ms + k);
+                            else for (uint32_t x = 0; x < nv; x++) t[mq + k + x] = ld_u8_l2(ms + k + x);
+                        }
                     } else if (kind == 2) {
                         const uint32_t mq = o + ll;
                         const int64_t sq = (int64_t)mq - (int64_t)s_d[slot];
@@ -1446,11 +1471,13 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
 
             // ---- the ticket's turn: everything before this tile is written ----
             if (!have_turn) {
+                t2 = __builtin_amdgcn_s_memtime();
                 if (!wait_turn(T)) { gone = true; break; }
                 have_turn = true;
+                t3 = __builtin_amdgcn_s_memtime();
             }
             if (tile_bad) { fail(LZFSE_MI_BAD_D_VALUE, tile_base); gone = true; break; }
-            if (part && m && !m_long) {
+            if (part && m && !m_long && !early) {
                 if (far) {
                     const uint8_t *ms = dst + (p_match - dd);
                     if (p_match - dd + 24 <= tile_base) {
@@ -1466,25 +1493,39 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
             }
             for (uint32_t q = wave; q < tot_long; q += NW) {
                 const uint32_t e = s_long[q], slot = e >> 2, kind = e & 3;
-                if (kind == 0) continue;
+                if (kind == 0 || kind == 3) continue;
                 const uint32_t lm = s_lm[slot];
                 const uint32_t mq = s_off[slot] + (lm & 0xFFFF), mm = lm >> 16;
                 const int64_t sq = (int64_t)mq - (int64_t)s_d[slot];
                 const uint8_t *ms = dst + ((int64_t)tile_base + sq);
                 if (kind == 1) {
-                    for (uint32_t k = lane; k < mm; k += 64) t[mq + k] = ld_u8_l2(ms + k);
+                    // 8 bytes per lane and step where 8 bytes of finished output can be read, single bytes at the very end
+                    const uint64_t src_pos = (uint64_t)((int64_t)tile_base + sq);
+                    for (uint32_t k = lane * 8; k < mm; k += 512) {
+                        const uint32_t nv = min(8u, mm - k);
+                        if (src_pos + k + 8 <= tile_base) {
+                            const uint64_t w = ld_u64_l2(ms + k);
+                            if (nv == 8) *(u64_unaligned *)(t + mq + k) = w;
+                            else for (uint32_t x = 0; x < nv; x++) t[mq + k + x] = (uint8_t)(w >> (8 * x));
+                        } else {
+                            for (uint32_t x = 0; x < nv; x++) t[mq + k + x] = ld_u8_l2(ms + k + x);
+                        }
+                    }
                 } else if (sq < 0) {
                     const uint32_t nb = (uint32_t)min((int64_t)mm, -sq);
                     for (uint32_t k = lane; k < nb; k += 64) t[mq + k] = ld_u8_l2(ms + k);
                 }
             }
             __syncthreads();
+            const uint64_t u1 = __builtin_amdgcn_s_memtime();
             if (tot_dep)
                 for (uint32_t m2 = dm; m2; m2 &= m2 - 1) {
                     const uint32_t b2 = tid + ((uint32_t)__builtin_ctz(m2) << NTS);
                     t[b2] = t[s_org[b2]];
                 }
             __syncthreads();
+            const uint64_t u2 = __builtin_amdgcn_s_memtime();
+            cy_far += u1 - t3; cy_gat += u2 - u1; t3b = u2;
             {
                 uint8_t *gp = dst + tile_base;
                 uint32_t head = pad ? (16 - pad) : 0;
@@ -1507,6 +1548,14 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
         if (gone) break;
         if (!have_turn) { if (!wait_turn(T)) break; }   // a block without LMDs
         publish(T, last, blk_end);
+        prev_end = d.n_lmd ? out_pos : blk_end;
+        const uint64_t t4 = __builtin_amdgcn_s_memtime();
+        cy_ahead += t2 - t1; cy_wait += t3 - t2; cy_turn += t4 - t3; cy_wb += t4 - t3b;
+    }
+    if (tid == 0) {
+        unsigned long long *q = (unsigned long long *)(next + 4);
+        atomicAdd(q, cy_setup); atomicAdd(q + 1, cy_ahead); atomicAdd(q + 2, cy_wait); atomicAdd(q + 3, cy_turn); atomicAdd(q + 4, n_tk);
+        atomicAdd(q + 5, cy_far); atomicAdd(q + 6, cy_gat); atomicAdd(q + 7, cy_wb);
     }
 }
 

@@ -54,7 +54,7 @@ void launch_dec_lz(int variant, const uint8_t *src, const StreamIn *streams, con
                    uint32_t n_streams, const BlockDesc *blocks, const BlockResult *bres, const LmdRec *lmds,
                    const uint8_t *lits, uint8_t *dst, StreamResult *sres, hipStream_t st);
 
-constexpr int LZP_PLACEMENT_STATUS = 0x7F01;   // dec_lzp_kernel: workgroups of one stream on different XCDs (never leaves the library)
+constexpr uint32_t LZP_STATE_WORDS = 24;   // per stream: next ticket, done, home XCC + 1, bad, then u64 diagnostics (cycles)
 void launch_dec_lzp(int variant, uint32_t K, const uint8_t *src, const StreamIn *streams, const StreamPlan *plan,
                     const uint32_t *mlist, uint32_t n_multi, const BlockDesc *blocks, uint32_t n_blocks, const BlockResult *bres,
                     const LmdRec *lmds, const uint8_t *lits, uint2 *ck, uint8_t *dst, StreamResult *sres, uint32_t *state,
