@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the exclusive pass, PCIe-inclusive and copy-peak measurements")
     ap.add_argument("--lanes", type=int, default=0, help="sub-batches run side by side per call (0: library default, 1: unsplit)")
+    ap.add_argument("--decode-pipe", type=int, default=0, help="LZFSE_MI_OPT_DECODE_PIPE (0: by the batch's shape, 1: never)")
     ap.add_argument("--stagger", action="store_true", help="encode lanes start one after the other instead of together")
     ap.add_argument("--skip-verify", action="store_true", help=argparse.SUPPRESS)  # timing of deliberately broken ablation builds
     ap.add_argument("--per-file", type=int, default=0, metavar="R",
@@ -166,6 +167,8 @@ def main():
     from lzfse_rust_amd import sharding
     ctx = lz.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    if args.decode_pipe:
+        ctx.set_option("decode_pipe", args.decode_pipe)
     if args.lanes:
         ctx.set_option("encode_lanes", args.lanes)
         ctx.set_option("decode_lanes", args.lanes)

@@ -137,7 +137,7 @@ struct lzfse_mi_ctx {
     int opt_pipe = 0;      // LZFSE_MI_OPT_DECODE_PIPE
     bool pipe_broken = false;   // a launch found the workgroups of one stream on different XCDs: never again on this context
     int lane_share = 1;    // sub-batches running side by side with this one (split_batch)
-    int diag_lz_jump = -1, diag_lz_variant = -1, diag_stats = 0, diag_chain = 0, diag_walk = 0;  // diagnostic build only
+    int diag_lz_jump = -1, diag_lz_variant = -1, diag_stats = 0, diag_chain = 0, diag_walk = 0, diag_pipe_scatter = 0;  // diagnostic build only
 
     hipEvent_t get_event() {
         if (ev_used == ev_pool.size()) {
@@ -386,6 +386,9 @@ int lzfse_mi_decode_size(const uint8_t *src, size_t n, uint64_t *raw_len) {
 
 // ---------------------------------------------------------------------------- decode (device)
 
+// streams from this size on are worth several workgroups in the LZ stage (measured on the Snappy files: never slower from 100 KB on)
+static constexpr uint64_t PIPE_MIN_RAW = 96ull << 10;
+
 static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_src, const uint64_t *src_off,
                                    const uint64_t *src_len, void *d_dst, const uint64_t *dst_off,
                                    const uint64_t *dst_cap, uint64_t *out_lens, int *statuses) {
@@ -455,7 +458,9 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
             if (h_walk[i].raw_total > dst_cap[i] || h_walk[i].n_vxn != 0) continue;
             if (h_walk[i].raw_total >= (2ull << 20)) { el_bytes += h_walk[i].raw_total; el_max = std::max<uint64_t>(el_max, h_walk[i].raw_total); }
         }
-        if (el_max * 42 <= el_bytes) jump_mode = 0;
+        // (with at most 64 streams the tile path gives each of them four workgroups and about 1.7 GB/s: dec_lzp_kernel)
+        const bool piped = c->opt_pipe != 1 && !c->pipe_broken && (size_t)ns * (size_t)std::max(1, c->lane_share) <= 64;
+        if (el_max * (piped ? 24 : 42) <= el_bytes) jump_mode = 0;
     }
     for (uint32_t i = 0; i < ns; i++) {
         StreamPlan &p = h_plan[i];
@@ -485,15 +490,22 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
     uint32_t pipe_k = 0;
     if (c->opt_pipe != 1 && !c->pipe_broken) {
         const bool forced = c->opt_pipe > 1;
-        for (uint32_t i = 0; i < ns; i++)
-            if (!h_plan[i].skip && !h_plan[i].jump && h_plan[i].n_blocks && h_walk[i].n_vxn == 0 && (forced || h_walk[i].raw_total >= (512ull << 10)))
-                mlist.push_back(i);
+        size_t n_tile = 0;   // streams of the tile kernel: one workgroup each fills the chip when they are many
+        for (uint32_t i = 0; i < ns; i++) {
+            if (h_plan[i].skip || h_plan[i].jump || !h_plan[i].n_blocks) continue;
+            n_tile++;
+            if (h_walk[i].n_vxn == 0 && (forced || h_walk[i].raw_total >= PIPE_MIN_RAW)) mlist.push_back(i);
+        }
         const size_t share = (size_t)std::max(1, c->lane_share);
         if (mlist.empty()) pipe_k = 0;
         else if (forced) { pipe_k = (uint32_t)(c->opt_pipe & 0xFF); pipe_variant = (c->opt_pipe >> 8) & 1; }
-        else if (mlist.size() * share <= 128) { pipe_variant = 1; pipe_k = (uint32_t)std::min<size_t>(8, 256 / (mlist.size() * share)); }
-        else { pipe_variant = 0; pipe_k = (uint32_t)std::min<size_t>(16, 1280 / (mlist.size() * share)); }
-        if (pipe_k < 2 && !forced) { mlist.clear(); pipe_k = 0; }
+        else if (n_tile * share <= 128) {
+            // 1024 threads and 124 KB of LDS: one workgroup per CU, and the hand-over chain of a stream (about 5 us per
+            // ticket) is what bounds it from K = 4 on
+            pipe_variant = 1;
+            pipe_k = (uint32_t)std::min<size_t>(4, 256 / (mlist.size() * share));
+            if (pipe_k < 2) pipe_k = 0;
+        }
         if (pipe_k < 1) mlist.clear();
         for (uint32_t i : mlist) h_plan[i].pipe = pipe_k;
     }
@@ -553,7 +565,7 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
             launch_dec_lzp(pipe_variant, pipe_k, (const uint8_t *)d_src, (const StreamIn *)c->d_streams.p,
                            (const StreamPlan *)c->d_plan.p, d_mlist, (uint32_t)mlist.size(), (const BlockDesc *)c->d_blocks.p,
                            (uint32_t)nb, (const BlockResult *)c->d_bres.p, (const LmdRec *)c->d_lmds.p, (const uint8_t *)c->d_lits.p,
-                           (uint2 *)c->d_ck.p, (uint8_t *)d_dst, (StreamResult *)c->d_sres.p, d_lzp_state, st);
+                           (uint2 *)c->d_ck.p, (uint8_t *)d_dst, (StreamResult *)c->d_sres.p, d_lzp_state, c->diag_pipe_scatter != 0, st);
     }
     if (nj) {
         launch_dec_jump((const uint8_t *)d_src, (const StreamIn *)c->d_streams.p, (const StreamPlan *)c->d_plan.p,
@@ -577,9 +589,12 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
             c->pipe_broken = true;
             for (uint32_t i : mlist) h_plan[i].pipe = 0;
             HIP_TRY(hipMemcpyAsync(c->d_plan.p, h_plan.data(), ns * sizeof(StreamPlan), hipMemcpyHostToDevice, st));
-            launch_dec_lz(1, (const uint8_t *)d_src, (const StreamIn *)c->d_streams.p, (const StreamPlan *)c->d_plan.p, ns,
-                          (const BlockDesc *)c->d_blocks.p, (const BlockResult *)c->d_bres.p, (const LmdRec *)c->d_lmds.p,
-                          (const uint8_t *)c->d_lits.p, (uint8_t *)d_dst, (StreamResult *)c->d_sres.p, st);
+            {
+                StageTimer t(c, "dec_lz_again");
+                launch_dec_lz(1, (const uint8_t *)d_src, (const StreamIn *)c->d_streams.p, (const StreamPlan *)c->d_plan.p, ns,
+                              (const BlockDesc *)c->d_blocks.p, (const BlockResult *)c->d_bres.p, (const LmdRec *)c->d_lmds.p,
+                              (const uint8_t *)c->d_lits.p, (uint8_t *)d_dst, (StreamResult *)c->d_sres.p, st);
+            }
             HIP_TRY(hipMemcpyAsync(h_sres.data(), c->d_sres.p, ns * sizeof(StreamResult), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             if (hipGetLastError() != hipSuccess) return LZFSE_MI_IO;
@@ -744,6 +759,7 @@ static int split_batch(lzfse_mi_ctx *c, batch_dev_fn one, int lanes, bool stagge
         c->shadow[k]->opt_pipe = c->opt_pipe;
         c->shadow[k]->diag_lz_jump = c->diag_lz_jump; c->shadow[k]->diag_lz_variant = c->diag_lz_variant;
         c->shadow[k]->diag_stats = c->diag_stats; c->shadow[k]->diag_chain = c->diag_chain; c->shadow[k]->diag_walk = c->diag_walk;
+        c->shadow[k]->diag_pipe_scatter = c->diag_pipe_scatter;
     }
     if (!ok) return unsplit();
     // staggered start (encode): lane k + 1 begins when lane k has queued its candidate kernel
@@ -789,7 +805,15 @@ int lzfse_mi_decode_batch_device(lzfse_mi_ctx *c, size_t count, const void *d_sr
                                  const uint64_t *src_len, void *d_dst, const uint64_t *dst_off,
                                  const uint64_t *dst_cap, uint64_t *out_lens, int *statuses) {
     if (!c) return LZFSE_MI_BAD_ARGUMENT;
-    return split_batch(c, decode_batch_device_one, c->opt_lanes_dec ? c->opt_lanes_dec : 2, false, count, d_src, src_off, src_len, d_dst,
+    int lanes = c->opt_lanes_dec ? c->opt_lanes_dec : 2;
+    if (!c->opt_lanes_dec && c->opt_pipe != 1 && !c->pipe_broken && count <= 128 && dst_cap) {
+        // few streams, some of them large: the LZ stage gives every stream several workgroups (dec_lzp_kernel), which
+        // wants the whole chip for one pass; sub-batches side by side would take the CUs from each other
+        bool big = false;
+        for (size_t i = 0; i < count; i++) big |= dst_cap[i] >= PIPE_MIN_RAW;
+        if (big) lanes = 1;
+    }
+    return split_batch(c, decode_batch_device_one, lanes, false, count, d_src, src_off, src_len, d_dst,
                        dst_off, dst_cap, out_lens, statuses);
 }
 
@@ -827,12 +851,14 @@ int lzfse_mi_set_option(lzfse_mi_ctx *c, int option, int64_t value) {
     case LZFSE_MI_OPT_DIAG_STATS: c->diag_stats = (int)value; return LZFSE_MI_OK;
     case LZFSE_MI_OPT_DIAG_CHAIN: c->diag_chain = (int)value; return LZFSE_MI_OK;
     case LZFSE_MI_OPT_DIAG_WALK: c->diag_walk = (int)value; return LZFSE_MI_OK;
+    case LZFSE_MI_OPT_DIAG_PIPE_SCATTER: c->diag_pipe_scatter = (int)value; c->pipe_broken = false; return LZFSE_MI_OK;
 #else
     case LZFSE_MI_OPT_DIAG_LZ_PATH:
     case LZFSE_MI_OPT_DIAG_LZ_TILE:
     case LZFSE_MI_OPT_DIAG_STATS:
     case LZFSE_MI_OPT_DIAG_CHAIN:
-    case LZFSE_MI_OPT_DIAG_WALK: return LZFSE_MI_UNSUPPORTED;
+    case LZFSE_MI_OPT_DIAG_WALK:
+    case LZFSE_MI_OPT_DIAG_PIPE_SCATTER: return LZFSE_MI_UNSUPPORTED;
 #endif
     default: return LZFSE_MI_BAD_ARGUMENT;
     }

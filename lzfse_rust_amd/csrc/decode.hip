@@ -1202,7 +1202,7 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
     const uint32_t *__restrict__ mlist, uint32_t n_multi, uint32_t K,
     const BlockDesc *__restrict__ blocks, const BlockResult *__restrict__ bres,
     const LmdRec *__restrict__ lmds, const uint8_t *__restrict__ lits, const uint2 *__restrict__ ck, uint8_t *dst_all,
-    StreamResult *__restrict__ sres, uint32_t *__restrict__ state) {
+    StreamResult *__restrict__ sres, uint32_t *__restrict__ state, uint32_t scatter /* diagnostic: pretend the workgroups of a stream sit on different XCDs */) {
     constexpr int NW = NT / 64;
     __shared__ __attribute__((aligned(16))) uint8_t tile[TILE + 32];
     __shared__ uint32_t s_off[NT];
@@ -1301,7 +1301,7 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
         if (!placed) {
             // the hand-over below relies on one L2: every workgroup that works on the stream must be on the same XCD
             if (tid == 0) {
-                const uint32_t mine = xcc_id() + 1;
+                const uint32_t mine = xcc_id() + 1 + (scatter ? (wq % K) * 16 : 0);
                 const uint32_t was = atomicCAS(home, 0u, mine);
                 s_tk[1] = (was == 0 || was == mine) ? 1u : 0u;
             }
@@ -1806,16 +1806,16 @@ void launch_dec_lz(int variant, const uint8_t *src, const StreamIn *streams, con
 void launch_dec_lzp(int variant, uint32_t K, const uint8_t *src, const StreamIn *streams, const StreamPlan *plan,
                     const uint32_t *mlist, uint32_t n_multi, const BlockDesc *blocks, uint32_t n_blocks, const BlockResult *bres,
                     const LmdRec *lmds, const uint8_t *lits, uint2 *ck, uint8_t *dst, StreamResult *sres, uint32_t *state,
-                    hipStream_t st) {
+                    bool scatter, hipStream_t st) {
     if (!n_multi || !K) return;
     hipLaunchKernelGGL(dec_ck_kernel, dim3(n_blocks), dim3(256), 0, st, plan, blocks, n_blocks, bres, lmds, ck);
     const uint32_t grid = ((n_multi + 7) / 8) * 8 * K;
     if (variant == 0)
         hipLaunchKernelGGL((dec_lzp_kernel<256, 8192>), dim3(grid), dim3(256), 0, st, src, streams, plan, mlist, n_multi, K,
-                           blocks, bres, lmds, lits, ck, dst, sres, state);
+                           blocks, bres, lmds, lits, ck, dst, sres, state, scatter ? 1u : 0u);
     else
         hipLaunchKernelGGL((dec_lzp_kernel<1024, 32768>), dim3(grid), dim3(1024), 0, st, src, streams, plan, mlist, n_multi, K,
-                           blocks, bres, lmds, lits, ck, dst, sres, state);
+                           blocks, bres, lmds, lits, ck, dst, sres, state, scatter ? 1u : 0u);
 }
 
 void launch_dec_jump(const uint8_t *src, const StreamIn *streams, const StreamPlan *plan, const StreamWalk *walk, uint32_t n_streams,

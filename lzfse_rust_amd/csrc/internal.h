@@ -58,7 +58,7 @@ constexpr uint32_t LZP_STATE_WORDS = 24;   // per stream: next ticket, done, hom
 void launch_dec_lzp(int variant, uint32_t K, const uint8_t *src, const StreamIn *streams, const StreamPlan *plan,
                     const uint32_t *mlist, uint32_t n_multi, const BlockDesc *blocks, uint32_t n_blocks, const BlockResult *bres,
                     const LmdRec *lmds, const uint8_t *lits, uint2 *ck, uint8_t *dst, StreamResult *sres, uint32_t *state,
-                    hipStream_t st);
+                    bool scatter, hipStream_t st);
 void launch_dec_jump(const uint8_t *src, const StreamIn *streams, const StreamPlan *plan, const StreamWalk *walk, uint32_t n_streams,
                      const BlockDesc *blocks, uint32_t n_blocks, const BlockResult *bres, const LmdRec *lmds, const uint8_t *lits,
                      uint8_t *dst, uint32_t *origin, uint64_t total, uint32_t *jerr, uint32_t *flags, StreamResult *sres,

@@ -91,3 +91,33 @@ def test_pipe_is_chosen_for_few_mid_size_streams(ctx, oracle, snappy_raw):
     ctx.set_option("decode_pipe", 0)
     outs, st = ctx.decode_batch([enc] * 64)
     assert all(e == 0 for e in st) and all(o.tobytes() == raw for o in outs)
+
+
+def test_pipe_refuses_streams_spread_over_xcds(oracle, snappy_raw):
+    """The hand-over goes through ONE XCD's L2, so every workgroup that works on a stream checks the XCC id it runs on against
+    the stream's. The diagnostic build can make them disagree: nothing may be taken from that launch -- the streams are
+    decoded again by the one-workgroup kernel (stage dec_lz_again), and the context stops using the pipelined kernel."""
+    import lzfse_rust_amd as m
+    diag_ctx = m.Context(0, diag=True)      # its own context: the test leaves it without the pipelined kernel
+    raws = [snappy_raw["lcet10.txt"] * 2, snappy_raw["urls.10K"], snappy_raw["html"] * 3, snappy_raw["alice29.txt"]]
+    encs = [oracle.encode(r) for r in raws]
+    bad = bytearray(encs[1]); bad[len(bad) // 2] ^= 0x40
+    encs.append(bytes(bad))
+    want = [oracle.decode_status(e, 1 << 22) for e in encs]
+    diag_ctx.enable_timing(True)
+    try:
+        diag_ctx.set_option("decode_pipe", 0x104)
+        outs, st = diag_ctx.decode_batch(encs, caps=[1 << 22] * len(encs))
+        assert "dec_lz_again" not in diag_ctx.timings()
+        assert list(st) == want and all(o.tobytes() == r for o, r in zip(outs, raws))
+        diag_ctx.set_option("diag_pipe_scatter", 1)
+        outs, st = diag_ctx.decode_batch(encs, caps=[1 << 22] * len(encs))
+        assert diag_ctx.timings()["dec_lz_again"][1] == 1
+        assert list(st) == want and all(o.tobytes() == r for o, r in zip(outs, raws))
+        outs, st = diag_ctx.decode_batch(encs, caps=[1 << 22] * len(encs))      # given up: the plain kernel from the start
+        assert "dec_lz_again" not in diag_ctx.timings()
+        assert list(st) == want and all(o.tobytes() == r for o, r in zip(outs, raws))
+    finally:
+        diag_ctx.set_option("diag_pipe_scatter", 0)
+        diag_ctx.set_option("decode_pipe", 0)
+        diag_ctx.enable_timing(False)
