@@ -1211,7 +1211,8 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
     __shared__ uint32_t s_lit[NT];
     __shared__ uint16_t s_org[TILE];
     __shared__ uint32_t s_dm[NT];
-    __shared__ uint32_t s_long[2 * NT];   // slot * 4 + kind: 0 long literal run, 1 long match from earlier output, 2 long match that reads the tile
+    __shared__ uint32_t s_long[2 * NT];   // slot * 4 + kind: 0 long literal run, 1 long match from earlier output, 2 long match that reads the tile, 3 = 1 but its source is final already
+    __shared__ uint32_t s_turn[NT];       // what has to wait for the turn: slot * 2 + (0: kind 1, 1: the part of a kind 2 match that lies before the tile)
     __shared__ uint32_t s_scan[2 * NW + 4];
     __shared__ uint32_t s_cnt[4];
     __shared__ uint32_t s_tk[2];
@@ -1411,6 +1412,7 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
             if (m_long) s_long[ex_long] = tid * 4 + (far ? (early ? 3 : 1) : 2);
             const uint32_t mo = ex_s + l;
             const int64_t so = (int64_t)mo - (int64_t)dd;
+            if (m_long && ((far && !early) || (dep && so < 0))) s_turn[atomicAdd(&s_cnt[3], 1u)] = tid * 2 + (far ? 0u : 1u);
             static_assert(TILE / NT <= 32 && (NT & (NT - 1)) == 0, "one mask bit per owned byte");
             constexpr uint32_t NTS = 31 - __builtin_clz((unsigned)NT);
             s_dm[tid] = 0;
@@ -1477,10 +1479,52 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
                 t3 = __builtin_amdgcn_s_memtime();
             }
             if (tile_bad) { fail(LZFSE_MI_BAD_D_VALUE, tile_base); gone = true; break; }
+            // long copies from earlier output: one wave per match, 8 bytes per lane and step where 8 bytes of finished
+            // output can be read (single bytes at the very end). The first step of a wave's first match is loaded before
+            // the short copies below are, so that both are one round trip to the L2.
+            const uint32_t n_turn = s_cnt[3];
+            auto turn_copy = [&](uint32_t e, bool have_first, uint64_t first) {
+                const uint32_t slot = e >> 1;
+                const uint32_t lm = s_lm[slot];
+                const uint32_t mq = s_off[slot] + (lm & 0xFFFF), mm = lm >> 16;
+                const int64_t sq = (int64_t)mq - (int64_t)s_d[slot];
+                const uint8_t *ms = dst + ((int64_t)tile_base + sq);
+                if (e & 1) {
+                    const uint32_t nb = (uint32_t)min((int64_t)mm, -sq);
+                    for (uint32_t k = lane; k < nb; k += 64) t[mq + k] = ld_u8_l2(ms + k);
+                    return;
+                }
+                const uint64_t src_pos = (uint64_t)((int64_t)tile_base + sq);
+                for (uint32_t k = lane * 8; k < mm; k += 512) {
+                    const uint32_t nv = min(8u, mm - k);
+                    if (src_pos + k + 8 <= tile_base + tile_len) {   // (as above: bytes past the source are read, not used)
+                        const uint64_t w = (have_first && k < 512) ? first : ld_u64_l2(ms + k);
+                        if (nv == 8) *(u64_unaligned *)(t + mq + k) = w;
+                        else for (uint32_t x = 0; x < nv; x++) t[mq + k + x] = (uint8_t)(w >> (8 * x));
+                    } else {
+                        for (uint32_t x = 0; x < nv; x++) t[mq + k + x] = ld_u8_l2(ms + k + x);
+                    }
+                }
+            };
+            uint32_t e_first = 0;
+            uint64_t w_first = 0;
+            bool pre_first = false;
+            if ((uint32_t)wave < n_turn) {
+                e_first = s_turn[wave];
+                if (!(e_first & 1)) {
+                    const uint32_t slot = e_first >> 1, lm = s_lm[slot];
+                    const uint32_t mq = s_off[slot] + (lm & 0xFFFF), mm = lm >> 16;
+                    const uint64_t src_pos = tile_base + mq - s_d[slot];
+                    if (lane * 8u < mm && src_pos + lane * 8u + 8 <= tile_base + tile_len) { w_first = ld_u64_l2(dst + src_pos + lane * 8u); pre_first = true; }
+                }
+            }
             if (part && m && !m_long && !early) {
+                // (24 bytes are read wherever they lie inside this stream's output so far INCLUDING this tile's own place,
+                // which is allocated and not yet written: only the first m of them are used. Byte by byte these copies are one
+                // round trip each, and a tile's first matches often start a few bytes before it.)
                 if (far) {
                     const uint8_t *ms = dst + (p_match - dd);
-                    if (p_match - dd + 24 <= tile_base) {
+                    if (p_match - dd + 24 <= tile_base + tile_len) {
                         const uint64_t w0 = ld_u64_l2(ms), w1 = m > 8 ? ld_u64_l2(ms + 8) : 0, w2 = m > 16 ? ld_u64_l2(ms + 16) : 0;
                         lds_put24(t + mo, m, w0, w1, w2);
                     } else {
@@ -1488,34 +1532,17 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
                     }
                 } else if (so < 0) {
                     const uint32_t nb = (uint32_t)min((int64_t)m, -so);
-                    for (uint32_t k = 0; k < nb; k++) t[mo + k] = ld_u8_l2(dst + ((int64_t)tile_base + so + k));
-                }
-            }
-            for (uint32_t q = wave; q < tot_long; q += NW) {
-                const uint32_t e = s_long[q], slot = e >> 2, kind = e & 3;
-                if (kind == 0 || kind == 3) continue;
-                const uint32_t lm = s_lm[slot];
-                const uint32_t mq = s_off[slot] + (lm & 0xFFFF), mm = lm >> 16;
-                const int64_t sq = (int64_t)mq - (int64_t)s_d[slot];
-                const uint8_t *ms = dst + ((int64_t)tile_base + sq);
-                if (kind == 1) {
-                    // 8 bytes per lane and step where 8 bytes of finished output can be read, single bytes at the very end
-                    const uint64_t src_pos = (uint64_t)((int64_t)tile_base + sq);
-                    for (uint32_t k = lane * 8; k < mm; k += 512) {
-                        const uint32_t nv = min(8u, mm - k);
-                        if (src_pos + k + 8 <= tile_base) {
-                            const uint64_t w = ld_u64_l2(ms + k);
-                            if (nv == 8) *(u64_unaligned *)(t + mq + k) = w;
-                            else for (uint32_t x = 0; x < nv; x++) t[mq + k + x] = (uint8_t)(w >> (8 * x));
-                        } else {
-                            for (uint32_t x = 0; x < nv; x++) t[mq + k + x] = ld_u8_l2(ms + k + x);
-                        }
+                    const uint8_t *ms = dst + ((int64_t)tile_base + so);
+                    if (so + 24 <= (int64_t)tile_len) {
+                        const uint64_t w0 = ld_u64_l2(ms), w1 = nb > 8 ? ld_u64_l2(ms + 8) : 0, w2 = nb > 16 ? ld_u64_l2(ms + 16) : 0;
+                        lds_put24(t + mo, nb, w0, w1, w2);
+                    } else {
+                        for (uint32_t k = 0; k < nb; k++) t[mo + k] = ld_u8_l2(ms + k);
                     }
-                } else if (sq < 0) {
-                    const uint32_t nb = (uint32_t)min((int64_t)mm, -sq);
-                    for (uint32_t k = lane; k < nb; k += 64) t[mq + k] = ld_u8_l2(ms + k);
                 }
             }
+            if ((uint32_t)wave < n_turn) turn_copy(e_first, pre_first, w_first);
+            for (uint32_t q = wave + NW; q < n_turn; q += NW) turn_copy(s_turn[q], false, 0);
             __syncthreads();
             const uint64_t u1 = __builtin_amdgcn_s_memtime();
             if (tot_dep)
