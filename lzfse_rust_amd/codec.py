@@ -15,7 +15,9 @@ import numpy as np
 from . import _native
 
 OK = 0
+BAD_READER_STATE = 5
 BUFFER_OVERFLOW = 6
+PAYLOAD_OVERFLOW = 7
 
 
 class LzfseError(Exception):
@@ -224,6 +226,80 @@ class LzfseRingDecoder:
             return u.value, v.value
         finally:
             lib.lzfse_mi_dstream_destroy(h)
+
+    def reader(self, inner):
+        """LzfseRingDecoder::reader (decode/ring_decoder.rs:75-80)."""
+        return LzfseReader(self._ctx, inner, self._window, self._read_size)
+
+    def reader_bytes(self, data):
+        """LzfseRingDecoder::reader_bytes (decode/ring_decoder.rs:82-89)."""
+        import io
+        return LzfseReader(self._ctx, io.BytesIO(bytes(data)), self._window, self._read_size)
+
+
+class LzfseReader:
+    """LzfseReader / LzfseReaderBytes (decode/ring_decoder.rs:75-90, 135-170; Read impl decode/reader_core.rs:170-188): a
+    reader over the decoded bytes of `inner`. read(n) returns n bytes unless the stream ends first, b"" from then on; a
+    decode error is raised by the read that reaches it; after PayloadOverflow (bytes behind bvx$) the reader is in
+    State::Err and every further read is BadReaderState (reader_core.rs:62-76, 160-168)."""
+
+    def __init__(self, context, inner, window=0, read_size=1 << 20):
+        self._ctx, self._inner, self._read_size = context, inner, read_size
+        self._lib = context._lib
+        self._h = C.c_void_p()
+        _check(self._lib.lzfse_mi_dstream_create(context._h, window, C.byref(self._h)))
+        self._out = bytearray()
+        self._pos = 0
+        self._done = False
+        self._error = None
+        self._cb = _native.WRITE_FN(self._sink)
+
+    def _sink(self, _user, p, n):
+        self._out += C.string_at(p, n)
+        return 0
+
+    def _fill(self):
+        piece = self._inner.read(self._read_size)
+        a = np.frombuffer(piece, dtype=np.uint8)
+        st = self._lib.lzfse_mi_dstream_feed(self._h, a.ctypes.data if a.size else None, a.size, 0 if a.size else 1, self._cb, None)
+        if st != OK:
+            self._error = BAD_READER_STATE if st == PAYLOAD_OVERFLOW else st
+            raise LzfseError(st, self._ctx.error_detail(0) if st != PAYLOAD_OVERFLOW else 0)
+        if not a.size:
+            self._done = True
+
+    def read(self, n=-1):
+        if self._error is not None:
+            raise LzfseError(self._error)
+        while not self._done and (n < 0 or len(self._out) - self._pos < n):
+            self._fill()
+        end = len(self._out) if n < 0 else min(len(self._out), self._pos + n)
+        piece = bytes(self._out[self._pos:end])
+        self._pos = end
+        if self._pos > (1 << 22):      # drop what has been handed out
+            del self._out[:self._pos]
+            self._pos = 0
+        return piece
+
+    def readinto(self, b):
+        piece = self.read(len(b))
+        b[:len(piece)] = piece
+        return len(piece)
+
+    def into_inner(self):
+        self.close()
+        return self._inner
+
+    def close(self):
+        if self._h:
+            self._lib.lzfse_mi_dstream_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def encode_bytes(src, dst):

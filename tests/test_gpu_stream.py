@@ -154,3 +154,44 @@ def test_stream_sink_failure_travels_back(ctx, oracle, snappy_raw):
     import lzfse_rust_amd as m
     with pytest.raises(OSError):
         m.LzfseRingDecoder(context=ctx).decode(PieceReader(oracle.encode(snappy_raw["html"]), [4096]), Full())
+
+
+def test_reader_pulls_the_decoded_bytes(ctx, oracle, golden_dir, snappy_raw):
+    """LzfseRingDecoder::reader / reader_bytes (decode/ring_decoder.rs:75-90): read(n) gives n bytes until the stream ends,
+    b"" afterwards; errors come out of the read that reaches them; after PayloadOverflow the reader is in State::Err
+    (decode/reader_core.rs:62-76, 160-168)."""
+    import lzfse_rust_amd as m
+    rng = np.random.default_rng(3)
+    dec = m.LzfseRingDecoder(context=ctx, window=200000, read_size=5000)
+    for name in ("alice29.txt", "html_x_4", "fireworks.jpeg"):
+        enc = open(os.path.join(golden_dir, "snappy", name + ".lzfse"), "rb").read()
+        want = oracle.decode(enc)
+        r = dec.reader(io.BytesIO(enc))
+        got = bytearray()
+        while True:
+            n = int(rng.integers(1, 70000))
+            piece = r.read(n)
+            assert len(piece) == n or len(got) + len(piece) == len(want)
+            if not piece:
+                break
+            got += piece
+        assert bytes(got) == want and r.read(10) == b""
+        assert isinstance(r.into_inner(), io.BytesIO)
+    raw = snappy_raw["lcet10.txt"] * 9
+    assert dec.reader_bytes(oracle.encode(raw)).read() == raw
+    buf = bytearray(1000)
+    assert dec.reader_bytes(oracle.encode(raw)).readinto(buf) == 1000 and bytes(buf) == raw[:1000]
+    enc = oracle.encode(snappy_raw["html"])
+    r = dec.reader_bytes(enc + b"\0")
+    with pytest.raises(m.LzfseError) as e:
+        r.read()
+    assert e.value.status == 7
+    with pytest.raises(m.LzfseError) as e:
+        r.read(1)
+    assert e.value.status == 5
+    bad = oracle.encode(raw)[:-3000]
+    r = dec.reader_bytes(bad)
+    assert r.read(1 << 20) == raw[: 1 << 20]              # the stream is cut 3 MB further on
+    with pytest.raises(m.LzfseError) as e:
+        r.read()
+    assert e.value.status == oracle.decode_status(bytes(bad), 1 << 23) != 0
