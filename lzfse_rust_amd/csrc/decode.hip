@@ -6,14 +6,16 @@
 //                     decode of literals and LMDs        decoder.rs:244-335, literals.rs:49-91
 //   dec_lz_kernel     literal / match copy (LZ77)        lz/writer.rs:97-186, lz/object.rs:27-74
 //                     + bvx- and bvxn blocks             raw/block.rs:46-93, vn/vn_core.rs:40-287
+//   dec_ck / dec_lzp  the same LZ stage with several workgroups per stream (few streams of some size): tickets of one LMD
+//                     group, the part of a tile that needs no earlier output done ahead of the ticket's turn
 //   dec_jump_*        the LZ stage of few large streams by pointer jumping over per-byte origins
 //
 // Parallelism: FSE is serial per bit stream, so the entropy stage runs one workgroup (two
 // waves: LMD stream, literal stream) per bvx2 block with its 7 KiB of tables in LDS and
 // uses lanes 0..2 / 0..3 of a wave for the interleaved L,M,D / four literal states
 // (one LDS table fetch + a DPP prefix sum over bit counts per step). The LZ stage runs one
-// workgroup per stream, stages a tile of output in LDS, resolves near matches there and
-// writes the tile back with coalesced 16-byte stores.
+// workgroup per stream (up to four when the streams are few), stages a tile of output in LDS,
+// resolves near matches there and writes the tile back with coalesced 16-byte stores.
 #include <algorithm>
 
 #include "internal.h"
