@@ -114,6 +114,7 @@ struct lzfse_mi_ctx {
     // host-pointer API staging
     DevBuf d_in, d_out, d_small;
     HostBuf h_in, h_out, h_small;
+    std::vector<hipEvent_t> host_ev;   // host_batch: one per output group in flight
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
@@ -284,6 +285,8 @@ void lzfse_mi_destroy(lzfse_mi_ctx *c) {
                       &c->d_lmds, &c->d_lits, &c->d_origin, &c->d_jerr, &c->d_wcache, &c->d_fwalk, &c->d_ck, &c->d_lzp, &c->d_in, &c->d_out, &c->d_small})
         b->release();
     enc_scratch_release(c->enc);
+    for (hipEvent_t e : c->host_ev) (void)hipEventDestroy(e);
+    c->host_ev.clear();
     c->h_in.release();
     c->h_out.release();
     c->h_small.release();
@@ -866,7 +869,55 @@ int lzfse_mi_set_option(lzfse_mi_ctx *c, int option, int64_t value) {
 
 // ---------------------------------------------------------------------------- host-pointer API
 
-static int host_batch(lzfse_mi_ctx *c, batch_dev_fn fn, size_t count, const uint8_t *const *srcs,
+// Host buffers in, host buffers out (what a binding hands over: Vec<u8> / &[u8]). Pageable memory cannot be the end of a
+// DMA, so everything passes through pinned staging; one memcpy thread moves ~10 GB/s, less than the link, so the staging
+// copies are spread over a few threads (large calls only) and run group by group beside the DMA of the group before /
+// after. Encoded streams are a third of their capacity: they are packed on the device before they travel.
+struct CopyJob {
+    uint8_t *dst;
+    const uint8_t *src;
+    size_t len;
+};
+
+// bytes [lo, hi) of the concatenation of the jobs, shared by a few threads
+static void par_copy(const std::vector<CopyJob> &jobs, const std::vector<uint64_t> &pre, uint64_t lo, uint64_t hi) {
+    if (hi <= lo) return;
+    const uint64_t total = hi - lo;
+    unsigned T = 1;
+    if (total >= ((uint64_t)8 << 20)) {
+        const unsigned hc = std::thread::hardware_concurrency();
+        T = std::min<unsigned>(8u, std::max<unsigned>(1u, hc / 2));
+        T = (unsigned)std::min<uint64_t>(T, total >> 21);
+    }
+    auto work = [&](unsigned t) {
+        const uint64_t a = lo + total * t / T, b = lo + total * (t + 1) / T;
+        size_t k = (size_t)(std::upper_bound(pre.begin(), pre.end(), a) - pre.begin()) - 1;   // the job that holds byte a
+        for (; k < jobs.size() && pre[k] < b; k++) {
+            const CopyJob &j = jobs[k];
+            const uint64_t x = std::max(a, pre[k]), y = std::min(b, pre[k] + j.len);
+            if (x < y) memcpy(j.dst + (x - pre[k]), j.src + (x - pre[k]), (size_t)(y - x));
+        }
+    };
+    if (T <= 1) { work(0); return; }
+    std::vector<std::thread> th;
+    th.reserve(T - 1);
+    for (unsigned t = 1; t < T; t++) {
+        try { th.emplace_back(work, t); } catch (...) { work(t); }
+    }
+    work(0);
+    for (auto &x : th) x.join();
+}
+
+static constexpr uint64_t HOST_GROUP = (uint64_t)16 << 20;   // staging granule: copied by the threads while the DMA moves the granule before / after
+
+// The staged image of byte `pos` of the concatenation: jobs are in staging order, stage[k] = staging offset of job k.
+static uint64_t staged_at(const std::vector<CopyJob> &jobs, const std::vector<uint64_t> &pre, const std::vector<uint64_t> &stage, uint64_t pos) {
+    const size_t k = (size_t)(std::upper_bound(pre.begin(), pre.end(), pos) - pre.begin()) - 1;
+    (void)jobs;
+    return stage[k] + (pos - pre[k]);
+}
+
+static int host_batch(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, size_t count, const uint8_t *const *srcs,
                       const size_t *lens, uint8_t *const *dsts, const size_t *caps, size_t *out_lens,
                       int *statuses) {
     if (!c || (count && (!srcs || !lens || !dsts || !caps || !out_lens || !statuses))) return LZFSE_MI_BAD_ARGUMENT;
@@ -883,34 +934,89 @@ static int host_batch(lzfse_mi_ctx *c, batch_dev_fn fn, size_t count, const uint
     if (!c->d_in.ensure(in_total + 256) || !c->d_out.ensure(out_total + 256) || !c->h_in.ensure(in_total + 256) ||
         !c->h_out.ensure(out_total + 256))
         return LZFSE_MI_IO;
+    std::vector<CopyJob> jobs;
+    std::vector<uint64_t> pre, stage;   // per job: first byte in the concatenation, offset in the staging buffer
+    jobs.reserve(count); pre.reserve(count + 1); stage.reserve(count);
+    // ---- in: granules of HOST_GROUP bytes (a large stream is several); the DMA of one runs under the staging copy of the next ----
+    uint64_t n_in = 0;
     for (size_t i = 0; i < count; i++)
-        if (lens[i]) memcpy((uint8_t *)c->h_in.p + so[i], srcs[i], lens[i]);
-    HIP_TRY(hipMemcpyAsync(c->d_in.p, c->h_in.p, in_total, hipMemcpyHostToDevice, c->stream));
+        if (lens[i]) { jobs.push_back({(uint8_t *)c->h_in.p + so[i], srcs[i], lens[i]}); pre.push_back(n_in); stage.push_back(so[i]); n_in += lens[i]; }
+    for (uint64_t lo = 0; lo < n_in; lo += HOST_GROUP) {
+        const uint64_t hi = std::min(n_in, lo + HOST_GROUP);
+        par_copy(jobs, pre, lo, hi);
+        const uint64_t a = staged_at(jobs, pre, stage, lo), b = staged_at(jobs, pre, stage, hi - 1) + 1;
+        HIP_TRY(hipMemcpyAsync((uint8_t *)c->d_in.p + a, (uint8_t *)c->h_in.p + a, b - a, hipMemcpyHostToDevice, c->stream));
+    }
     int r = fn(c, count, c->d_in.p, so.data(), sl.data(), c->d_out.p, dof.data(), dc.data(), ol.data(), statuses);
     if (r) return r;
-    // copy back only what was produced
-    uint64_t hi = 0;
-    for (size_t i = 0; i < count; i++)
-        if (statuses[i] == 0 && ol[i]) hi = std::max(hi, dof[i] + ol[i]);
-    if (hi) {
-        HIP_TRY(hipMemcpyAsync(c->h_out.p, c->d_out.p, hi, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    }
+    // ---- out: where each stream's bytes are on the device (packed first when they fill little of their capacity) ----
+    std::vector<uint64_t> at(count);        // offset of stream i's output in the buffer that travels
+    uint64_t produced = 0, hi_off = 0;
+    bool fits32 = count <= 0x7FFFFFFFu;
     for (size_t i = 0; i < count; i++) {
         out_lens[i] = statuses[i] == 0 ? (size_t)ol[i] : 0;
-        if (statuses[i] == 0 && ol[i]) memcpy(dsts[i], (uint8_t *)c->h_out.p + dof[i], ol[i]);
+        at[i] = dof[i];
+        fits32 &= out_lens[i] <= 0xFFFFFFFFull;
+        if (out_lens[i]) { produced += out_lens[i]; hi_off = std::max(hi_off, dof[i] + ol[i]); }
+    }
+    if (!produced) return LZFSE_MI_OK;
+    const uint8_t *d_from = (const uint8_t *)c->d_out.p;
+    if (pack_outputs && fits32 && produced + (produced >> 2) < hi_off) {
+        uint64_t pk = 0;
+        std::vector<SmallDesc> desc;
+        std::vector<uint64_t> packed(count, 0);
+        desc.reserve(count);
+        for (size_t i = 0; i < count; i++) {
+            packed[i] = pk;
+            if (!out_lens[i]) continue;
+            desc.push_back({dof[i], pk, (uint32_t)out_lens[i], 0u});
+            pk += (out_lens[i] + 15) & ~(uint64_t)15;
+        }
+        // (the inputs are dead: the packed copy takes their place, its descriptors behind it)
+        const uint64_t desc_at = (pk + 255) & ~(uint64_t)255;
+        if (c->d_in.ensure((size_t)desc_at + desc.size() * sizeof(SmallDesc) + 256)) {
+            SmallDesc *d_desc = (SmallDesc *)((uint8_t *)c->d_in.p + desc_at);
+            HIP_TRY(hipMemcpyAsync(d_desc, desc.data(), desc.size() * sizeof(SmallDesc), hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(small_copy_kernel, dim3((uint32_t)desc.size()), dim3(256), 0, c->stream, (const uint8_t *)c->d_out.p,
+                               (uint8_t *)c->d_in.p, (const SmallDesc *)d_desc, (uint32_t)desc.size());
+            HIP_TRY(hipStreamSynchronize(c->stream));   // (`desc` is pageable memory of this scope)
+            d_from = (const uint8_t *)c->d_in.p;
+            at = packed;
+        }
+    }
+    // ---- granules again: every DMA is queued, and a granule is copied to its destinations as soon as it has arrived ----
+    jobs.clear(); pre.clear(); stage.clear();
+    uint64_t n_out = 0;
+    for (size_t i = 0; i < count; i++)
+        if (out_lens[i]) { jobs.push_back({dsts[i], (const uint8_t *)c->h_out.p + at[i], out_lens[i]}); pre.push_back(n_out); stage.push_back(at[i]); n_out += out_lens[i]; }
+    const size_t n_gran = (size_t)((n_out + HOST_GROUP - 1) / HOST_GROUP);
+    while (c->host_ev.size() < n_gran) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return LZFSE_MI_IO;
+        c->host_ev.push_back(e);
+    }
+    for (size_t g = 0; g < n_gran; g++) {
+        const uint64_t lo = g * HOST_GROUP, hi = std::min(n_out, lo + HOST_GROUP);
+        const uint64_t a = staged_at(jobs, pre, stage, lo), b = staged_at(jobs, pre, stage, hi - 1) + 1;
+        HIP_TRY(hipMemcpyAsync((uint8_t *)c->h_out.p + a, d_from + a, b - a, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipEventRecord(c->host_ev[g], c->stream));
+    }
+    for (size_t g = 0; g < n_gran; g++) {
+        HIP_TRY(hipEventSynchronize(c->host_ev[g]));
+        const uint64_t lo = g * HOST_GROUP;
+        par_copy(jobs, pre, lo, std::min(n_out, lo + HOST_GROUP));
     }
     return LZFSE_MI_OK;
 }
 
 int lzfse_mi_decode_batch(lzfse_mi_ctx *c, size_t count, const uint8_t *const *srcs, const size_t *lens,
                           uint8_t *const *dsts, const size_t *caps, size_t *out_lens, int *statuses) {
-    return host_batch(c, lzfse_mi_decode_batch_device, count, srcs, lens, dsts, caps, out_lens, statuses);
+    return host_batch(c, lzfse_mi_decode_batch_device, false, count, srcs, lens, dsts, caps, out_lens, statuses);
 }
 
 int lzfse_mi_encode_batch(lzfse_mi_ctx *c, size_t count, const uint8_t *const *srcs, const size_t *lens,
                           uint8_t *const *dsts, const size_t *caps, size_t *out_lens, int *statuses) {
-    return host_batch(c, lzfse_mi_encode_batch_device, count, srcs, lens, dsts, caps, out_lens, statuses);
+    return host_batch(c, lzfse_mi_encode_batch_device, true, count, srcs, lens, dsts, caps, out_lens, statuses);
 }
 
 int lzfse_mi_last_error_detail(lzfse_mi_ctx *c, size_t stream_index, uint32_t *detail) {
