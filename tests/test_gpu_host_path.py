@@ -1,0 +1,57 @@
+"""GPU tests of the host-pointer entry points (lzfse_mi_encode_batch / _decode_batch): inputs and outputs travel through pinned
+staging in 16 MiB granules copied by several threads, encoded streams are packed on the device first -- none of which may
+show in the results: empty and tiny streams, streams of several granules, failed streams in the middle of a batch."""
+import numpy as np
+import pytest
+
+from oracle_py import rng_gen_vec
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import lzfse_rust_amd as m
+    return m.Context(0)
+
+
+def test_host_batch_of_mixed_sizes(ctx, oracle, snappy_raw):
+    big = (snappy_raw["lcet10.txt"] * 100)[: 40 << 20]            # 2.5 granules in, 1 out
+    noise = rng_gen_vec(5, 20 << 20)                                # incompressible: 20 MiB out as well
+    raws = [b"", b"x", bytes(5000), big, snappy_raw["html"], noise, b"", snappy_raw["urls.10K"] * 3, bytes(range(256)) * 40]
+    encs, st = ctx.encode_batch(raws)
+    assert all(e == 0 for e in st)
+    for r, e in zip(raws, encs):
+        assert e.tobytes() == oracle.encode(r), len(r)
+    streams = [e.tobytes() for e in encs]
+    outs, st = ctx.decode_batch(streams)
+    assert all(e == 0 for e in st) and all(o.tobytes() == r for o, r in zip(outs, raws))
+
+
+def test_host_batch_with_failed_streams_in_the_middle(ctx, oracle, snappy_raw):
+    import lzfse_rust_amd as m
+    raws = [snappy_raw["alice29.txt"] * 20, snappy_raw["html"], snappy_raw["kppkn.gtb"] * 30, snappy_raw["geo.protodata"]]
+    encs = [oracle.encode(r) for r in raws]
+    cut = encs[1][: len(encs[1]) // 2]
+    srcs = [encs[0], cut, encs[2], b"bvxQ", encs[3], b""]
+    caps = [len(raws[0]), len(raws[1]), 1000, 10, len(raws[3]), 10]
+    want = [oracle.decode_status(s, c) for s, c in zip(srcs, caps)]
+    assert want[0] == 0 and want[1] != 0 and want[2] == 6 and want[3] != 0 and want[4] == 0 and want[5] != 0
+    outs, st = ctx.decode_batch(srcs, caps=caps)
+    assert list(st) == want
+    assert outs[0].tobytes() == raws[0] and outs[4].tobytes() == raws[3] and all(len(outs[i]) == 0 for i in (1, 2, 3, 5))
+    # encode: a destination that is too small for one stream of the batch (the packed copy has a hole there)
+    lib = ctx._lib
+    n = len(raws)
+    import ctypes as C
+    arrs = [np.frombuffer(r, dtype=np.uint8) for r in raws]
+    capsE = [lib.lzfse_mi_encode_bound(len(r)) for r in raws]
+    capsE[2] = 100
+    dst = [np.empty(c, dtype=np.uint8) for c in capsE]
+    sp = (C.c_void_p * n)(*[a.ctypes.data for a in arrs]); sl = (C.c_size_t * n)(*[a.size for a in arrs])
+    dp = (C.c_void_p * n)(*[d.ctypes.data for d in dst]); dc = (C.c_size_t * n)(*capsE)
+    ol = (C.c_size_t * n)(); stE = (C.c_int * n)()
+    assert lib.lzfse_mi_encode_batch(ctx._h, n, sp, sl, dp, dc, ol, stE) == 0
+    assert list(stE) == [0, 0, 6, 0] and ol[2] == 0
+    for i in (0, 1, 3):
+        assert dst[i][: ol[i]].tobytes() == encs[i]
