@@ -587,7 +587,7 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
         // (XCC id of every workgroup that touches a stream). If a launch ever says no, its streams are decoded again by
         // the one-workgroup kernel, and this context stops using the pipelined one.
         bool again = false;
-        for (uint32_t i : mlist) again |= h_state[(size_t)LZP_STATE_WORDS * i + 3] != 0;   // the word a misplaced workgroup sets
+        for (uint32_t i : mlist) again |= h_state[(size_t)LZP_STATE_WORDS * i + LZP_BAD] != 0;   // the word a misplaced workgroup sets
         if (again) {
             c->pipe_broken = true;
             for (uint32_t i : mlist) h_plan[i].pipe = 0;
@@ -613,7 +613,7 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
     }
     if ((c->diag_stats & 4) && !mlist.empty()) {
         for (size_t k = 0; k < mlist.size() && k < 4; k++) {
-            const uint64_t *q = (const uint64_t *)(h_state.data() + (size_t)LZP_STATE_WORDS * mlist[k] + 4);
+            const uint64_t *q = (const uint64_t *)(h_state.data() + (size_t)LZP_STATE_WORDS * mlist[k] + LZP_DIAG);
             fprintf(stderr, "lzp[%u] K=%u tickets=%llu cycles: setup=%llu ahead=%llu wait=%llu turn=%llu (copies from earlier output %llu, gather %llu, write-back and hand-over %llu)\n", mlist[k], pipe_k,
                     (unsigned long long)q[4], (unsigned long long)q[0], (unsigned long long)q[1], (unsigned long long)q[2],
                     (unsigned long long)q[3], (unsigned long long)q[5], (unsigned long long)q[6], (unsigned long long)q[7]);

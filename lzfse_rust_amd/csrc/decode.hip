@@ -1230,7 +1230,8 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
     const StreamPlan pl = plan[s];
     const StreamIn in = streams[s];
     uint8_t *dst = dst_all + in.dst_off;
-    uint32_t *next = state + LZP_STATE_WORDS * (size_t)s, *done = next + 1, *home = next + 2, *bad = next + 3;
+    uint32_t *sw = state + LZP_STATE_WORDS * (size_t)s;
+    uint32_t *next = sw + LZP_NEXT, *done = sw + LZP_DONE, *home = sw + LZP_HOME, *bad = sw + LZP_BAD;
     uint64_t cy_setup = 0, cy_ahead = 0, cy_wait = 0, cy_turn = 0, n_tk = 0, cy_far = 0, cy_gat = 0, cy_wb = 0;   // diagnostics: where a ticket's cycles go
     if (pl.n_blocks == 0) {
         if (wq % K == 0 && tid == 0) { StreamResult r = {}; sres[s] = r; }
@@ -1572,6 +1573,9 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
             __syncthreads();
             lit_run += s_cnt[2];
             g0 += cnt;
+            // (a group that did not fit one tile goes on: what was just written must have reached the L2 before the next
+            // part reads it past the L1)
+            if (g0 < g_end) __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
         }
         if (gone) break;
@@ -1582,7 +1586,7 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
         cy_ahead += t2 - t1; cy_wait += t3 - t2; cy_turn += t4 - t3; cy_wb += t4 - t3b;
     }
     if (tid == 0) {
-        unsigned long long *q = (unsigned long long *)(next + 4);
+        unsigned long long *q = (unsigned long long *)(sw + LZP_DIAG);
         atomicAdd(q, cy_setup); atomicAdd(q + 1, cy_ahead); atomicAdd(q + 2, cy_wait); atomicAdd(q + 3, cy_turn); atomicAdd(q + 4, n_tk);
         atomicAdd(q + 5, cy_far); atomicAdd(q + 6, cy_gat); atomicAdd(q + 7, cy_wb);
     }
