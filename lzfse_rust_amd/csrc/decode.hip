@@ -1004,7 +1004,10 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
                     if (dd >= m && p_match - dd + slen <= tile_base) {
                         if (m <= SHORT_COPY) {
                             const uint8_t *ms = dst + (p_match - dd);
-                            if (p_match - dd + 24 <= tile_base) {  // 24 readable bytes of finished output
+                            // (24 bytes are read wherever they lie inside the stream's output INCLUDING this tile's own place, which is
+                            // allocated and not yet written: only the first m are used. Byte by byte such a copy is a round trip per
+                            // byte, and a tile's first matches often start a few bytes before it.)
+                            if (p_match - dd + 24 <= tile_base + tile_len) {
                                 const uint64_t w0 = ld_u64(ms), w1 = m > 8 ? ld_u64(ms + 8) : 0, w2 = m > 16 ? ld_u64(ms + 16) : 0;
                                 lds_put24(t + ex_s + l, m, w0, w1, w2);
                             } else {
@@ -1057,11 +1060,22 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
                 __syncthreads();
                 if (dep) {
                     if (m <= SHORT_COPY) {
-                        for (uint32_t k = 0; k < m; k++) {
-                            const int64_t sp = so + k;
+                        // the part of the source that lies before the tile: finished output of earlier tiles (one wide read)
+                        uint32_t k0 = 0;
+                        if (so < 0) {
+                            k0 = (uint32_t)min((int64_t)m, -so);
+                            const uint8_t *ms = dst + ((int64_t)tile_base + so);
+                            if (so + 24 <= (int64_t)tile_len) {
+                                const uint64_t w0 = ld_u64(ms), w1 = k0 > 8 ? ld_u64(ms + 8) : 0, w2 = k0 > 16 ? ld_u64(ms + 16) : 0;
+                                lds_put24(t + mo, k0, w0, w1, w2);
+                            } else {
+                                for (uint32_t k = 0; k < k0; k++) t[mo + k] = ms[k];
+                            }
+                        }
+                        for (uint32_t k = k0; k < m; k++) {
+                            const uint32_t sp = (uint32_t)(so + k);
                             const uint32_t q = mo + k;
-                            if (sp >= 0) { s_org[q] = (uint16_t)sp; atomicOr(&s_dm[q & (NT - 1)], 1u << (q >> NTS)); }
-                            else t[q] = dst[(int64_t)tile_base + sp];   // finished output of earlier tiles
+                            s_org[q] = (uint16_t)sp; atomicOr(&s_dm[q & (NT - 1)], 1u << (q >> NTS));
                         }
                     } else {
                         s_long[atomicAdd(&s_cnt[3], 1u)] = tid;
