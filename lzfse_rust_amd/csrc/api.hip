@@ -556,9 +556,10 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
     }
     {
         StageTimer t(c, "dec_lz");
-        // one workgroup per stream: with few streams per CU the 1024-thread / 32 KiB-tile kernel finishes a stream
-        // soonest; with >= 4 streams per CU the 256-thread / 8 KiB-tile kernel (5 workgroups per CU) moves more bytes
-        int variant = ns >= 1024 ? 0 : 1;
+        // one workgroup per stream: the 1024-thread / 32 KiB-tile kernel (one workgroup per CU) finishes a stream 2.6 times
+        // sooner than the 256-thread / 8 KiB-tile kernel (five per CU), which moves more bytes once there are about seven
+        // streams per CU in flight (Snappy files x R, dec_lz ms: 1 080 streams 1.45 / 2.20, 1 536: 1.94 / 2.23, 2 040: 2.62 / 2.26)
+        int variant = (uint64_t)ns * (uint64_t)std::max(1, c->lane_share) >= 1792 ? 0 : 1;
         if (c->diag_lz_variant >= 0) variant = c->diag_lz_variant;
         launch_dec_lz(variant, (const uint8_t *)d_src, (const StreamIn *)c->d_streams.p,
                       (const StreamPlan *)c->d_plan.p, ns, (const BlockDesc *)c->d_blocks.p,
