@@ -1,6 +1,8 @@
 """One-off randomised parity campaign on a GPU box (not part of the test-suite: the suite's cases are fixed):
-    python scripts/fuzz_gpu.py [ROUNDS] [SEED] [walk|pipe]  (walk: the diagnostic build, every stream through the parallel header walk first;
-                                                              pipe: every stream of the tile kernel through the pipelined LZ kernel, K and tile size changing per round)
+    python scripts/fuzz_gpu.py [ROUNDS] [SEED] [walk|pipe|big]  (walk: the diagnostic build, every stream through the parallel header walk first;
+                                                              pipe: every stream of the tile kernel through the pipelined LZ kernel, K and tile size changing per round;
+                                                              big: 2 to 9 streams of 2 .. 24 MiB per round: pointer jumping, the parallel header walk and several
+                                                              workgroups per stream, as the cost model mixes them)
 Every round: ~120 streams of random structure and length (4 097 B .. 3 MiB, some at tile edges) are encoded by the device
 and compared with the CPU restatement's bytes, decoded back, and a damaged copy of every stream (one byte changed, or cut
 short) is decoded by both with the status codes and lengths compared."""
@@ -20,6 +22,7 @@ if len(sys.argv) > 3 and sys.argv[3] == "walk":
 else:
     ctx = lz.Context(0)
 PIPE = len(sys.argv) > 3 and sys.argv[3] == "pipe"
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
 rng = np.random.default_rng(seed)
 words = [bytes(rng.integers(97, 123, size=int(rng.integers(1, 12)), dtype=np.uint8)) for _ in range(800)]
 TILE = 65472
@@ -67,7 +70,10 @@ t0 = time.time(); total = 0
 for rd in range(rounds):
     if PIPE:
         ctx.set_option("decode_pipe", int(rng.integers(2, 12)) | (int(rng.integers(0, 2)) << 8))
-    raws = [gen(int(rng.integers(0, 7)), max(4097, length())) for _ in range(120)]
+    if BIG:
+        raws = [gen(int(rng.integers(0, 7)), int(rng.integers(2 << 20, 24 << 20))) for _ in range(int(rng.integers(2, 10)))]
+    else:
+        raws = [gen(int(rng.integers(0, 7)), max(4097, length())) for _ in range(120)]
     total += sum(map(len, raws))
     want = [O.encode(r) for r in raws]
     outs, st = ctx.encode_batch(raws)
