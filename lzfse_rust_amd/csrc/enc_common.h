@@ -130,8 +130,9 @@ void launch_enc_stitch(const uint8_t *src, const EncStream *streams, uint32_t ns
 void launch_enc_compact(const EncStream *streams, const uint32_t *slot_stream, uint32_t n_slots, uint32_t ns, const EncStreamOut *outs,
                         const RangeRec *ranges, const SpecEvent *logs, const MatchRec *gaps, MatchRec *matches, uint32_t *pc,
                         uint32_t *pl, uint2 *rsum, hipStream_t st);
-void launch_enc_segment(const EncStream *streams, uint32_t ns, const MatchRec *matches, const uint32_t *pc, const uint32_t *pl,
-                        uint2 *lmds, EncBlock *blocks, EncStreamOut *outs, hipStream_t st);
+void launch_enc_segment(const EncStream *streams, uint32_t ns, const uint32_t *slot_stream, uint32_t n_slots, bool try_parallel,
+                        const MatchRec *matches, const uint32_t *pc, const uint32_t *pl, uint2 *lmds, EncBlock *blocks, EncStreamOut *outs,
+                        uint32_t *flags, hipStream_t st);
 void launch_enc_lmd(const EncStream *streams, const uint32_t *slot_stream, uint32_t n_slots, const EncStreamOut *outs,
                     const EncBlock *blocks, const MatchRec *matches, const uint32_t *pc, uint2 *lmds, hipStream_t st);
 

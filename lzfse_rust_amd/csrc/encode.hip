@@ -698,7 +698,7 @@ __global__ __launch_bounds__(256) void enc_pack_kernel(const EncStream *__restri
 // ------------------------------------------------------------------------------------ host side
 
 enum { EB_STREAMS, EB_TILES, EB_PREV, EB_SUMMARY, EB_REC, EB_LMDS, EB_BLOCKS, EB_OUTS, EB_STAGE, EB_SLOTS,
-       EB_BITMAP, EB_SEGS, EB_LOGS, EB_HDRS, EB_RANGES, EB_GAPS, EB_MATCHES, EB_PC, EB_PL, EB_RSLOTS, EB_SYNC, EB_RSUM, EB_DBG, EB_N };
+       EB_BITMAP, EB_SEGS, EB_LOGS, EB_HDRS, EB_RANGES, EB_GAPS, EB_MATCHES, EB_PC, EB_PL, EB_RSLOTS, EB_SYNC, EB_RSUM, EB_DBG, EB_SEGFLAG, EB_N };
 static_assert(EB_N <= 32, "EncScratch slots");
 
 static bool eb_ensure(EncScratch &s, int i, size_t n) {
@@ -858,7 +858,10 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         }
         {
             StageTimer t(c, "enc_segment");
-            launch_enc_segment(d_streams, ns, d_matches, d_pc, d_pl, d_lmds, d_blocks, d_outs, stq);
+            if (!eb_ensure(S, EB_SEGFLAG, (size_t)ns * 4 + 64)) return LZFSE_MI_IO;
+            const bool big_stream = hs[0].n >= (1u << 20);   // (streams are sorted by size: enc_segpar_kernel only takes large ones)
+            launch_enc_segment(d_streams, ns, d_slots, blk_total, big_stream, d_matches, d_pc, d_pl, d_lmds, d_blocks, d_outs,
+                               (uint32_t *)S.bufs[EB_SEGFLAG], stq);
         }
         {
             StageTimer t(c, "enc_lmd");

@@ -714,9 +714,11 @@ __device__ bool em_buffer_push(Emit &w, uint32_t &n_lit, uint32_t &match_len, ui
 __global__ __launch_bounds__(SEGM_THREADS) void enc_segment_kernel(const EncStream *__restrict__ streams, uint32_t n_streams,
                                                                   const MatchRec *__restrict__ matches, const uint32_t *__restrict__ pc,
                                                                   const uint32_t *__restrict__ pl, uint2 *__restrict__ lmds,
-                                                                  EncBlock *__restrict__ blocks, EncStreamOut *__restrict__ outs) {
+                                                                  EncBlock *__restrict__ blocks, EncStreamOut *__restrict__ outs,
+                                                                  const uint32_t *__restrict__ flags) {
     const uint32_t si = blockIdx.x;
     if (si >= n_streams) return;
+    if (flags[si] == 2u) return;   // cut by enc_segpar_kernel / enc_segfin_kernel
     const int lane = e_lane();
     const EncStream &es = streams[si];
     EncStreamOut so = outs[si];
@@ -850,6 +852,177 @@ __global__ __launch_bounds__(SEGM_THREADS) void enc_segment_kernel(const EncStre
     if (lane == 0) outs[si] = so;
 }
 
+// ------------------------------------------------------------------------------------ block segmentation, all blocks at once
+//
+// The serial kernel above spends about a microsecond per block, which is a third of the encoder's time for ONE large stream
+// (860 blocks in 64 MiB of text). When the 10 000-LMD limit is what closes every block -- the 40 000-literal limit never binds
+// -- the cut is no chain at all: Buffer::push (fse/buffer.rs:45-97) hands out the LMDs of the events in order, so block k is
+// the LMDs [10 000 k, 10 000 k + 10 000) of the stream-wide LMD sequence, and everything the serial walk would leave in the
+// block record follows from the prefix sums by two binary searches: the event that holds the block's first LMD (its LMDs in
+// this block are the "head", written here, exactly as the serial emitter writes the remainder of a boundary event, or the
+// whole event when the boundary fell between two events), the complete events behind it (enc_lmd_kernel), and the leading
+// LMDs of the event that holds the block's last LMD when that event goes on into the next block. One wave per block slot
+// does this for every block of a large stream at once; a second kernel checks that no block came out with more than 40 000
+// literals (then no literal limit was ever met inside Buffer::push and the result is the serial one) and turns the per-block
+// sizes into offsets. Any stream for which that does not hold is left to the serial kernel, untouched.
+
+constexpr uint32_t SEGPAR_MIN_EVENTS = 200000;   // smaller streams: the serial cut is a few dozen microseconds
+
+// LMDs of one event (l literals, match m at distance d) in Buffer::push order: nL x (315, 0, 1), then nM match LMDs of which
+// the first carries the remaining literals
+struct EvShape {
+    uint32_t nL, l_rest, nM, m_last;
+};
+__device__ __forceinline__ EvShape ev_shape(uint32_t l, uint32_t m) {
+    EvShape s;
+    s.nL = l ? (l - 1) / MAX_L_VALUE : 0;
+    s.l_rest = l - s.nL * MAX_L_VALUE;
+    s.nM = m ? (m - 1) / MAX_M_VALUE + 1 : 1;
+    s.m_last = m - (s.nM - 1) * MAX_M_VALUE;
+    return s;
+}
+
+// LMDs [i0, i1) of event ev go to out[0 ..), the D of the first one against prev_d (0 at the start of a block); returns the
+// literals and match bytes they carry and the prev_d behind them. All lanes call with uniform arguments.
+__device__ void ev_emit(const MatchRec &ev, uint32_t i0, uint32_t i1, uint32_t prev_d, uint2 *out, uint32_t &lit, uint32_t &mat, uint32_t &prev_out) {
+    const EvShape s = ev_shape(ev.l, ev.m);
+    const int lane = e_lane();
+    uint32_t a_l = 0, a_m = 0;
+    for (uint32_t i = i0 + (uint32_t)lane; i < i1; i += 64) {
+        uint32_t L, M, D;
+        if (i < s.nL) { L = MAX_L_VALUE; M = 0; D = 1; }
+        else {
+            const uint32_t j = i - s.nL;
+            L = j == 0 ? s.l_rest : 0u;
+            M = j + 1 < s.nM ? MAX_M_VALUE : s.m_last;
+            const uint32_t pd = i == i0 ? prev_d : (i - 1 < s.nL ? 1u : ev.d);
+            D = pd == ev.d ? 0u : ev.d;
+        }
+        out[i - i0] = make_uint2(L | (M << 16), D);
+        a_l += L; a_m += M;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { a_l += __shfl_xor(a_l, d); a_m += __shfl_xor(a_m, d); }
+    lit = a_l; mat = a_m;
+    prev_out = i1 > i0 ? (i1 - 1 < s.nL ? 1u : ev.d) : prev_d;
+}
+
+// smallest e in [0, E) with PC[e] > x (PC inclusive, non-decreasing; x < PC[E - 1])
+__device__ __forceinline__ uint32_t first_above(const uint32_t *PC, uint32_t E, uint32_t x) {
+    uint32_t lo = 0, hi = E - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (PC[mid] > x) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(64) void enc_segpar_kernel(const EncStream *__restrict__ streams, const uint32_t *__restrict__ slot_stream,
+                                                        uint32_t n_slots, const EncStreamOut *__restrict__ outs,
+                                                        const MatchRec *__restrict__ matches, const uint32_t *__restrict__ pc,
+                                                        const uint32_t *__restrict__ pl, uint2 *__restrict__ lmds,
+                                                        EncBlock *__restrict__ blocks, uint32_t *__restrict__ flags) {
+    const uint32_t slot = blockIdx.x;
+    if (slot >= n_slots) return;
+    const uint32_t si = slot_stream[slot];
+    const EncStream &es = streams[si];
+    const uint32_t k = slot - es.blk_base;
+    const EncStreamOut so = outs[si];
+    const uint32_t E = so.n_matches;
+    if (so.status || E < SEGPAR_MIN_EVENTS) return;
+    const MatchRec *mt = matches + es.match_base;
+    const uint32_t *PC = pc + es.match_base, *PL = pl + es.match_base;
+    const uint32_t total = PC[E - 1];
+    const uint32_t nb = (total + LMDS_PER_BLOCK - 1) / LMDS_PER_BLOCK;
+    if (k >= nb) return;
+    const uint32_t B0 = k * LMDS_PER_BLOCK, B1 = total - B0 > LMDS_PER_BLOCK ? B0 + LMDS_PER_BLOCK : total;
+    const uint32_t n_lmd = B1 - B0;
+    uint2 *out = lmds + es.lmd_base + B0;
+    // the event of the block's first LMD, and the event of its last
+    const uint32_t e_first = first_above(PC, E, B0);
+    const uint32_t e_last = first_above(PC, E, B1 - 1);
+    const uint32_t before_first = e_first ? PC[e_first - 1] : 0, before_last = e_last ? PC[e_last - 1] : 0, pc_last = PC[e_last];
+    uint32_t n_lit = 0, n_match = 0;
+    uint32_t head_lmds = 0, head_prev_d = 0, ev_begin = 0;
+    if (k > 0) {
+        // head: what is left of event e_first (all of it when the block before ended between two events)
+        const MatchRec ev = mt[e_first];
+        const uint32_t off0 = B0 - before_first, c = PC[e_first] - before_first;
+        head_lmds = c - off0 < n_lmd ? c - off0 : n_lmd;
+        uint32_t hl, hm;
+        ev_emit(ev, off0, off0 + head_lmds, 0u, out, hl, hm, head_prev_d);
+        n_lit += hl; n_match += hm;
+        ev_begin = e_first + 1;
+    }
+    // complete events behind the head
+    uint32_t ev_end = pc_last == B1 ? e_last + 1 : e_last;
+    if (ev_end < ev_begin) ev_end = ev_begin;
+    if (ev_end > ev_begin) {
+        const MatchRec last = mt[ev_end - 1];
+        const uint32_t body_l = PL[ev_end - 1] - (ev_begin ? PL[ev_begin - 1] : 0);
+        const uint32_t body_raw = last.lit_pos + last.l + last.m - mt[ev_begin].lit_pos;
+        n_lit += body_l; n_match += body_raw - body_l;
+    }
+    // tail: the leading LMDs of an event that goes on into the next block (unless that event is this block's head)
+    if (pc_last > B1 && e_last >= ev_begin) {
+        const MatchRec ev = mt[e_last];
+        const uint32_t pd = e_last > ev_begin ? mt[e_last - 1].d : head_prev_d;
+        uint32_t tl, tm, unused;
+        ev_emit(ev, 0u, B1 - before_last, pd, out + (before_last - B0), tl, tm, unused);
+        n_lit += tl; n_match += tm;
+    }
+    if (n_lit > LITERALS_PER_BLOCK) atomicOr(&flags[si], 1u);   // the literal limit closes a block somewhere: not this kernel's case
+    if (e_lane() == 0) {
+        EncBlock b;
+        b.lmd_start = es.lmd_base + B0;
+        b.stage_off = stage_need(n_lit, n_lmd);   // (sizes; enc_segfin_kernel turns them into offsets)
+        b.src_start = n_lit + n_match;
+        b.n_lmd = n_lmd; b.n_lit = n_lit; b.n_match = n_match;
+        b.hdr_len = 0; b.lit_len = 0; b.lmd_len = 0; b.pad = 0;
+        b.ev_begin = ev_begin; b.ev_end = ev_end; b.head_lmds = head_lmds; b.head_prev_d = head_prev_d;
+        blocks[slot] = b;
+    }
+}
+
+// one wave per stream: the blocks' sizes become offsets; flags[si] = 2 tells the serial kernel that the stream is done
+__global__ __launch_bounds__(64) void enc_segfin_kernel(const EncStream *__restrict__ streams, uint32_t n_streams,
+                                                        const uint32_t *__restrict__ pc, EncBlock *__restrict__ blocks,
+                                                        EncStreamOut *__restrict__ outs, uint32_t *__restrict__ flags) {
+    const uint32_t si = blockIdx.x;
+    if (si >= n_streams) return;
+    const EncStream &es = streams[si];
+    EncStreamOut so = outs[si];
+    const uint32_t E = so.n_matches;
+    if (so.status || E < SEGPAR_MIN_EVENTS || flags[si]) return;
+    const uint32_t total = (pc + es.match_base)[E - 1];
+    const uint32_t nb = (total + LMDS_PER_BLOCK - 1) / LMDS_PER_BLOCK;
+    if (nb > es.blk_cap || total > es.lmd_cap) return;   // (the serial kernel reports it)
+    EncBlock *bk = blocks + es.blk_base;
+    const int lane = e_lane();
+    uint64_t stage_used = 0;
+    uint32_t raw_pos = 0;
+    for (uint32_t b0 = 0; b0 < nb; b0 += 64) {
+        const uint32_t b = b0 + (uint32_t)lane;
+        const bool in = b < nb;
+        const uint32_t need = in ? (uint32_t)bk[b].stage_off : 0u, raw = in ? bk[b].src_start : 0u;
+        uint32_t in_need = need, in_raw = raw;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t un = __shfl_up(in_need, d), ur = __shfl_up(in_raw, d);
+            if (lane >= d) { in_need += un; in_raw += ur; }
+        }
+        if (in) { bk[b].stage_off = es.stage_base + stage_used + (in_need - need); bk[b].src_start = raw_pos + (in_raw - raw); }
+        stage_used += e_readlane(in_need, 63);
+        raw_pos += e_readlane(in_raw, 63);
+    }
+    if (stage_used > es.stage_cap) return;   // (offsets are garbage then, and the serial kernel overwrites them)
+    if (lane == 0) {
+        so.n_blocks = nb; so.status = 0;
+        outs[si] = so;
+        flags[si] = 2u;
+    }
+}
+
 // ------------------------------------------------------------------------------------ LMD writing
 
 // One workgroup per block slot: the block's complete events write their LMDs
@@ -917,10 +1090,17 @@ void launch_enc_compact(const EncStream *streams, const uint32_t *slot_stream, u
     hipLaunchKernelGGL(enc_rscan_kernel, dim3(ns), dim3(RSCAN_THREADS), 0, st, streams, ns, outs, rsum);
     hipLaunchKernelGGL(enc_papply_kernel, dim3(n_slots), dim3(64), 0, st, streams, slot_stream, outs, ranges, rsum, pc, pl);
 }
-void launch_enc_segment(const EncStream *streams, uint32_t ns, const MatchRec *matches, const uint32_t *pc, const uint32_t *pl,
-                        uint2 *lmds, EncBlock *blocks, EncStreamOut *outs, hipStream_t st) {
+void launch_enc_segment(const EncStream *streams, uint32_t ns, const uint32_t *slot_stream, uint32_t n_slots, bool try_parallel,
+                        const MatchRec *matches, const uint32_t *pc, const uint32_t *pl, uint2 *lmds, EncBlock *blocks, EncStreamOut *outs,
+                        uint32_t *flags, hipStream_t st) {
+    (void)hipMemsetAsync(flags, 0, (size_t)ns * 4, st);
+    if (try_parallel && n_slots) {
+        hipLaunchKernelGGL(enc_segpar_kernel, dim3(n_slots), dim3(64), 0, st, streams, slot_stream, n_slots, outs, matches, pc, pl, lmds, blocks,
+                           flags);
+        hipLaunchKernelGGL(enc_segfin_kernel, dim3(ns), dim3(64), 0, st, streams, ns, pc, blocks, outs, flags);
+    }
     hipLaunchKernelGGL(enc_segment_kernel, dim3(ns), dim3(SEGM_THREADS), 0, st, streams, ns, matches,
-                       pc, pl, lmds, blocks, outs);
+                       pc, pl, lmds, blocks, outs, flags);
 }
 void launch_enc_lmd(const EncStream *streams, const uint32_t *slot_stream, uint32_t n_slots, const EncStreamOut *outs,
                     const EncBlock *blocks, const MatchRec *matches, const uint32_t *pc, uint2 *lmds, hipStream_t st) {

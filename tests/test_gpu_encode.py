@@ -266,3 +266,37 @@ def test_encode_block_boundaries_bit_exact(ctx, oracle):
     assert all(e == 0 for e in st)
     for r, o in zip(raws, outs):
         assert o.tobytes() == oracle.encode(r), len(r)
+
+
+def test_encode_blocks_cut_all_at_once_bit_exact(ctx, oracle, snappy_raw):
+    """Large streams have all their bvx2 blocks cut at once when only the 10 000-LMD limit closes blocks
+    (enc_segpar_kernel), and by the serial cut otherwise: text with long zero runs (matches of many LMDs that straddle block
+    ends), with runs of noise of some hundred bytes (literal runs split into several LMDs), and with runs of noise long
+    enough to close blocks by the 40 000-literal limit (the stream is left to the serial kernel) -- the oracle's bytes."""
+    rng = np.random.default_rng(41)
+    words = [bytes(rng.integers(97, 123, size=int(rng.integers(2, 10)), dtype=np.uint8)) for _ in range(3000)]
+
+    def text(n):
+        out = bytearray()
+        while len(out) < n:
+            out += words[int(rng.integers(0, len(words)))] + b" "
+        return bytes(out[:n])
+
+    def spliced(n, zero_runs, noise_runs, noise_len):
+        a = bytearray(text(n))
+        for _ in range(zero_runs):
+            p, m = int(rng.integers(0, n - 40000)), int(rng.integers(2400, 30000))
+            a[p:p + m] = bytes(m)
+        for _ in range(noise_runs):
+            p, m = int(rng.integers(0, n - 70000)), int(rng.integers(noise_len[0], noise_len[1]))
+            a[p:p + m] = rng.integers(0, 256, size=m, dtype=np.uint8).tobytes()
+        return bytes(a)
+
+    raws = [spliced(6 << 20, 150, 150, (320, 3000)),          # LMD-bound throughout
+            spliced(6 << 20, 40, 12, (30000, 65000)),           # some blocks closed by the literal limit
+            text(5 << 20) + bytes(3 << 20) + text(1 << 20),     # one match of 1 300 LMDs across a block end
+            (snappy_raw["lcet10.txt"] * 16)[: 6 << 20]]
+    encs, st = ctx.encode_batch(raws)
+    assert all(e == 0 for e in st)
+    for r, e in zip(raws, encs):
+        assert hashlib.sha256(e.tobytes()).digest() == hashlib.sha256(oracle.encode(r)).digest(), len(r)
