@@ -217,4 +217,25 @@ LZMI_HD inline int fse_load_v1(const uint8_t *p, FseHeader &h) {
 }
 
 
+
+#if defined(__HIPCC__)
+// Wave-wide (64 lanes) inclusive prefix sum by DPP moves: row_shr 1, 2, 4, 8 inside the rows of 16 lanes, then the last lane
+// of a row broadcast into the next row (row_bcast:15 for rows 1 and 3, row_bcast:31 for rows 2 and 3). Six dependent vector
+// instructions; the same scan by __shfl_up is six dependent trips through the LDS crossbar (ds_bpermute), ten times the
+// latency -- and a lone wave or a barrier-bound workgroup pays latency. All 64 lanes must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_take(uint32_t ident, uint32_t v) {   // v of the source lane, `ident` where there is none
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)ident, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v) {
+    v += dpp_take<0x111, 0xF>(0u, v);
+    v += dpp_take<0x112, 0xF>(0u, v);
+    v += dpp_take<0x114, 0xF>(0u, v);
+    v += dpp_take<0x118, 0xF>(0u, v);
+    v += dpp_take<0x142, 0xA>(0u, v);
+    v += dpp_take<0x143, 0xC>(0u, v);
+    return v;
+}
+#endif
+
 }  // namespace lzmi

@@ -37,16 +37,8 @@ __device__ __forceinline__ uint32_t read_lane(uint32_t v, int lane) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
 }
 
-// wave-level inclusive scan (shuffle based; used outside the hot loops)
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-    int l = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = __shfl_up(v, d);
-        if (l >= d) v += o;
-    }
-    return v;
-}
+// wave-level inclusive scan (DPP, common.h)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) { return wave_incl_sum(v); }
 
 // ------------------------------------------------------------------------------------ headers
 

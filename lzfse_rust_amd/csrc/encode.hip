@@ -280,12 +280,7 @@ __global__ __launch_bounds__(BLK_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
             r_next = idx + BLK_THREADS < blk.n_lmd ? bl[idx + BLK_THREADS] : make_uint2(0, 0);
             uint32_t l = r.x & 0xFFFF, m = r.x >> 16, d = r.y;
             // block exclusive scan of l and l + m
-            uint32_t il = l, is = l + m;
-#pragma unroll
-            for (int dd = 1; dd < 64; dd <<= 1) {
-                uint32_t a = __shfl_up(il, dd), b2 = __shfl_up(is, dd);
-                if (lane >= dd) { il += a; is += b2; }
-            }
+            uint32_t il = wave_incl_sum(l), is = wave_incl_sum(l + m);
             if (lane == 63) { scan_sh[wave] = il; scan_sh[BLK_THREADS / 64 + wave] = is; }
             lds_barrier();
             uint32_t ol = 0, os = 0, tl = 0, ts = 0;
@@ -384,8 +379,7 @@ __global__ __launch_bounds__(BLK_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
                 }
             }
             uint32_t inc = nb;
-#pragma unroll
-            for (int dd = 1; dd < 64; dd <<= 1) { uint32_t a = __shfl_up(inc, dd); if (lane >= dd) inc += a; }
+            inc = wave_incl_sum(inc);
             uint32_t bitpos = carry_bits + inc - nb;
             if (nb) {
                 uint64_t v64 = (uint64_t)code << (bitpos & 31);
@@ -401,8 +395,7 @@ __global__ __launch_bounds__(BLK_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         if (wave == 1) {
             uint32_t w0 = wts[104 + 4 * lane], w1 = wts[105 + 4 * lane], w2 = wts[106 + 4 * lane], w3 = wts[107 + 4 * lane];
             uint32_t s4 = w0 + w1 + w2 + w3, inc = s4;
-#pragma unroll
-            for (int dd = 1; dd < 64; dd <<= 1) { uint32_t a = __shfl_up(inc, dd); if (lane >= dd) inc += a; }
+            inc = wave_incl_sum(inc);
             uint32_t tot = inc - s4;
             uint32_t ws[4] = {w0, w1, w2, w3};
 #pragma unroll
@@ -416,8 +409,7 @@ __global__ __launch_bounds__(BLK_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
             }
         } else if (wave == 2) {
             uint32_t wv = wts[40 + lane], inc = wv;
-#pragma unroll
-            for (int dd = 1; dd < 64; dd <<= 1) { uint32_t a = __shfl_up(inc, dd); if (lane >= dd) inc += a; }
+            inc = wave_incl_sum(inc);
             uint32_t tot = inc - wv;
             int32_t tk, tw;
             if (wv == 0) { tk = -(int32_t)D_STATES; tw = 0; }
@@ -560,12 +552,7 @@ __global__ __launch_bounds__(BLK_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
             }
             // block exclusive scans: literal widths (per thread), LMD widths (per thread, per slice u)
             uint32_t a = lw, b2 = mw[0], c2 = CE / BLK_THREADS > 1 ? mw[CE / BLK_THREADS - 1] : 0;
-            uint32_t ia = a, ib = b2, ic = c2;
-#pragma unroll
-            for (int dd = 1; dd < 64; dd <<= 1) {
-                uint32_t x = __shfl_up(ia, dd), y = __shfl_up(ib, dd), z = __shfl_up(ic, dd);
-                if (lane >= dd) { ia += x; ib += y; ic += z; }
-            }
+            uint32_t ia = wave_incl_sum(a), ib = wave_incl_sum(b2), ic = wave_incl_sum(c2);
             if (lane == 63) { scan_sh[wave] = ia; scan_sh[4 + wave] = ib; scan_sh[8 + wave] = ic; }
             lds_barrier();
             uint32_t oa = 0, ob = 0, oc = 0, ta = 0, tb2 = 0, tc = 0;

@@ -422,21 +422,25 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
             if (nb > 0) {
                 const bool act = lane < nb;
                 const int32_t ii = (int32_t)sy_l.y, jj = (int32_t)sy_l.z;
-                int32_t A = act ? jj + 1 : INT32_MIN / 2, B = act ? jj - ii : 0;
-#pragma unroll
-                for (int dd = 1; dd < 64; dd <<= 1) {
-                    const int32_t Al = __shfl_up(A, dd), Bl = __shfl_up(B, dd);
-                    if (lane >= dd) { const int32_t t = Al + B; A = A > t ? A : t; B = Bl + B; }
+                // (identity of the composition: A = -inf, B = 0; the same six DPP steps as wave_incl_sum, earlier lanes on the left)
+                constexpr int32_t NEG = INT32_MIN / 2;
+                int32_t A = act ? jj + 1 : NEG, B = act ? jj - ii : 0;
+#define LZMI_MAXPLUS_STEP(CTRL, MASK)                                                                                   \
+                {                                                                                                        \
+                    const int32_t Al = (int32_t)dpp_take<CTRL, MASK>((uint32_t)NEG, (uint32_t)A), Bl = (int32_t)dpp_take<CTRL, MASK>(0u, (uint32_t)B); \
+                    const int32_t t = Al + B;                                                                            \
+                    A = A > t ? A : t; B = Bl + B;                                                                       \
                 }
+                LZMI_MAXPLUS_STEP(0x111, 0xF) LZMI_MAXPLUS_STEP(0x112, 0xF) LZMI_MAXPLUS_STEP(0x114, 0xF) LZMI_MAXPLUS_STEP(0x118, 0xF)
+                LZMI_MAXPLUS_STEP(0x142, 0xA) LZMI_MAXPLUS_STEP(0x143, 0xC)
+#undef LZMI_MAXPLUS_STEP
                 const int32_t a0 = (int32_t)a;
                 const int32_t a_out = A > a0 + B ? A : a0 + B;
                 const int32_t a_prev = __shfl_up(a_out, 1);
                 const int32_t a_in = lane ? a_prev : a0;
                 const int32_t i_eff = (a_in > 0 && ii + 1 < a_in) ? a_in - 1 : ii;
                 const uint32_t cnt = (act && i_eff >= a_in) ? (uint32_t)(i_eff - a_in + 1) : 0u;
-                uint32_t inc = cnt;
-#pragma unroll
-                for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t t = __shfl_up(inc, dd); if (lane >= dd) inc += t; }
+                const uint32_t inc = wave_incl_sum(cnt);
                 const uint64_t hm = __ballot(cnt != 0);
                 const uint32_t n_new = (uint32_t)__popcll(hm), total = e_readlane(inc, 63);
                 if (x.n_ranges + n_new > x.range_cap) x.status = LZFSE_MI_IO;
@@ -590,12 +594,7 @@ __global__ __launch_bounds__(64) void enc_compact_kernel(const EncStream *__rest
             out[q] = m;
             c = lmd_count_of(m.l, m.m);
         }
-        uint32_t ic = c, il = m.l;
-#pragma unroll
-        for (int d2 = 1; d2 < 64; d2 <<= 1) {
-            uint32_t xx = __shfl_up(ic, d2), yy = __shfl_up(il, d2);
-            if (lane >= d2) { ic += xx; il += yy; }
-        }
+        uint32_t ic = wave_incl_sum(c), il = wave_incl_sum(m.l);
         if (q < rg.count) { PC[q] = carry_c + ic; PL[q] = carry_l + il; }
         carry_c += e_readlane(ic, 63);
         carry_l += e_readlane(il, 63);
@@ -621,12 +620,7 @@ __global__ __launch_bounds__(RSCAN_THREADS) void enc_rscan_kernel(const EncStrea
     for (uint32_t g0 = 0; g0 < so.n_ranges; g0 += RSCAN_THREADS) {
         const uint32_t j = g0 + tid;
         const uint2 v = j < so.n_ranges ? rs[j] : make_uint2(0, 0);
-        uint32_t ic = v.x, il = v.y;
-#pragma unroll
-        for (int d2 = 1; d2 < 64; d2 <<= 1) {
-            uint32_t xx = __shfl_up(ic, d2), yy = __shfl_up(il, d2);
-            if (lane >= d2) { ic += xx; il += yy; }
-        }
+        uint32_t ic = wave_incl_sum(v.x), il = wave_incl_sum(v.y);
         if (lane == 63) { sh[wave] = ic; sh[NWV + wave] = il; }
         __syncthreads();
         uint32_t oc = 0, ol = 0, tc = 0, tl = 0;
