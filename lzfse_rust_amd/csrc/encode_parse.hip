@@ -436,7 +436,7 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
 #undef LZMI_MAXPLUS_STEP
                 const int32_t a0 = (int32_t)a;
                 const int32_t a_out = A > a0 + B ? A : a0 + B;
-                const int32_t a_prev = __shfl_up(a_out, 1);
+                const int32_t a_prev = (int32_t)dpp_take<0x138, 0xF>(0u, (uint32_t)a_out);   // wave_shr:1
                 const int32_t a_in = lane ? a_prev : a0;
                 const int32_t i_eff = (a_in > 0 && ii + 1 < a_in) ? a_in - 1 : ii;
                 const uint32_t cnt = (act && i_eff >= a_in) ? (uint32_t)(i_eff - a_in + 1) : 0u;
