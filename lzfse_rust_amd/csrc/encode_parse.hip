@@ -15,6 +15,7 @@
 //   enc_segment_kernel  prefix sums of LMD / literal counts; serial only per bvx2 block: binary
 //                       search of the last event that fits (10 000 LMDs / 40 000 literals,
 //                       fse/buffer.rs:45-97), exact simulation of the boundary event
+//   enc_segpar_kernel   the same cut for all blocks of a large stream at once when only the LMD limit closes blocks
 //   enc_lmd_kernel      per block: every event writes its LMDs (L > 315 and M > 2 359 splits,
 //                       D zeroing against the previous LMD, buffer.rs:99-117)
 #include "enc_common.h"
