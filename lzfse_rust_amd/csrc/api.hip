@@ -115,6 +115,7 @@ struct lzfse_mi_ctx {
     DevBuf d_in, d_out, d_small;
     HostBuf h_in, h_out, h_small;
     std::vector<hipEvent_t> host_ev;   // host_batch: one per output group in flight
+    std::vector<LaneWorker *> copy_workers;   // host_batch: helper threads of the staging copies
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
@@ -285,6 +286,8 @@ void lzfse_mi_destroy(lzfse_mi_ctx *c) {
                       &c->d_lmds, &c->d_lits, &c->d_origin, &c->d_jerr, &c->d_wcache, &c->d_fwalk, &c->d_ck, &c->d_lzp, &c->d_in, &c->d_out, &c->d_small})
         b->release();
     enc_scratch_release(c->enc);
+    for (LaneWorker *w : c->copy_workers) delete w;
+    c->copy_workers.clear();
     for (hipEvent_t e : c->host_ev) (void)hipEventDestroy(e);
     c->host_ev.clear();
     c->h_in.release();
@@ -881,7 +884,7 @@ struct CopyJob {
 };
 
 // bytes [lo, hi) of the concatenation of the jobs, shared by a few threads
-static void par_copy(const std::vector<CopyJob> &jobs, const std::vector<uint64_t> &pre, uint64_t lo, uint64_t hi) {
+static void par_copy(lzfse_mi_ctx *c, const std::vector<CopyJob> &jobs, const std::vector<uint64_t> &pre, uint64_t lo, uint64_t hi) {
     if (hi <= lo) return;
     const uint64_t total = hi - lo;
     unsigned T = 1;
@@ -899,14 +902,17 @@ static void par_copy(const std::vector<CopyJob> &jobs, const std::vector<uint64_
             if (x < y) memcpy(j.dst + (x - pre[k]), j.src + (x - pre[k]), (size_t)(y - x));
         }
     };
-    if (T <= 1) { work(0); return; }
-    std::vector<std::thread> th;
-    th.reserve(T - 1);
-    for (unsigned t = 1; t < T; t++) {
-        try { th.emplace_back(work, t); } catch (...) { work(t); }
+    // helper threads that live as long as the context (a thread per granule and call costs as much as the copy it does)
+    while (T > 1 && c->copy_workers.size() + 1 < T) {
+        LaneWorker *w = nullptr;
+        try { w = new (std::nothrow) LaneWorker(); } catch (...) { w = nullptr; }   // (no thread to be had: fewer helpers)
+        if (!w) { T = (unsigned)c->copy_workers.size() + 1; break; }
+        c->copy_workers.push_back(w);
     }
+    if (T <= 1) { T = 1; work(0); return; }
+    for (unsigned t = 1; t < T; t++) c->copy_workers[t - 1]->submit([&work, t] { work(t); });
     work(0);
-    for (auto &x : th) x.join();
+    for (unsigned t = 1; t < T; t++) c->copy_workers[t - 1]->wait();
 }
 
 static constexpr uint64_t HOST_GROUP = (uint64_t)16 << 20;   // staging granule: copied by the threads while the DMA moves the granule before / after
@@ -944,7 +950,7 @@ static int host_batch(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, size_
         if (lens[i]) { jobs.push_back({(uint8_t *)c->h_in.p + so[i], srcs[i], lens[i]}); pre.push_back(n_in); stage.push_back(so[i]); n_in += lens[i]; }
     for (uint64_t lo = 0; lo < n_in; lo += HOST_GROUP) {
         const uint64_t hi = std::min(n_in, lo + HOST_GROUP);
-        par_copy(jobs, pre, lo, hi);
+        par_copy(c, jobs, pre, lo, hi);
         const uint64_t a = staged_at(jobs, pre, stage, lo), b = staged_at(jobs, pre, stage, hi - 1) + 1;
         HIP_TRY(hipMemcpyAsync((uint8_t *)c->d_in.p + a, (uint8_t *)c->h_in.p + a, b - a, hipMemcpyHostToDevice, c->stream));
     }
@@ -1005,7 +1011,7 @@ static int host_batch(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, size_
     for (size_t g = 0; g < n_gran; g++) {
         HIP_TRY(hipEventSynchronize(c->host_ev[g]));
         const uint64_t lo = g * HOST_GROUP;
-        par_copy(jobs, pre, lo, std::min(n_out, lo + HOST_GROUP));
+        par_copy(c, jobs, pre, lo, std::min(n_out, lo + HOST_GROUP));
     }
     return LZFSE_MI_OK;
 }
