@@ -67,6 +67,27 @@ def test_encode_bound_and_decode_size(lib, oracle, snappy_raw):
     assert e.value.status == 2
 
 
+def test_decode_headroom_is_the_most_a_damaged_block_can_over_produce(lib, oracle, snappy_raw, golden_dir):
+    """lzfse_mi_decode_headroom (host code): 40 000 literals + 10 000 x 2 359 match bytes when the stream holds a bvx1 / bvx2
+    block, 136 bytes per payload byte of a bvxn block, nothing for raw blocks (fse/constants.rs, vn/vn_core.rs)."""
+    import ctypes as C
+    import numpy as np
+
+    def room(b):
+        a = np.frombuffer(b, dtype=np.uint8)
+        return lib.lzfse_mi_decode_headroom(a.ctypes.data if a.size else None, a.size)
+
+    fse = 40000 + 10000 * 2359
+    assert room(oracle.encode(snappy_raw["html"])) == fse
+    assert room(open(os.path.join(golden_dir, "mutate", "vx1.lzfse"), "rb").read()) == fse
+    assert room(open(os.path.join(golden_dir, "mutate", "raw.lzfse"), "rb").read()) == 0
+    vxn = open(os.path.join(golden_dir, "mutate", "vxn.lzfse"), "rb").read()
+    payload = int.from_bytes(vxn[8:12], "little")
+    assert room(vxn) == 136 * (12 + payload)
+    assert room(b"") == 0 and room(b"bvx$") == 0 and room(b"nope") == 0
+    assert room(vxn[:20]) == 136 * 20      # cut short: what is there
+
+
 def test_product_never_touches_oracle():
     """The product tree must not import, link or execute anything under oracle/."""
     for dirpath, _dirs, files in os.walk(os.path.join(ROOT, "lzfse_rust_amd")):
