@@ -420,6 +420,7 @@ def pcie_inclusive(ctx, lz, batch_raw):
     """The host-pointer entry points (what the Rust shim binds): pageable host buffers in, pinned staging, one H2D and one
     D2H per batch, results back in host memory. Never `value`."""
     import ctypes as C
+    ctx.enable_timing(False)   # (stage timings are per context: a large host call is not cut in two while they are collected)
     sample = batch_raw[:384]
     n = len(sample)
     raw = sum(len(r) for r in sample)

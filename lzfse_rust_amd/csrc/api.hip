@@ -116,6 +116,9 @@ struct lzfse_mi_ctx {
     HostBuf h_in, h_out, h_small;
     std::vector<hipEvent_t> host_ev;   // host_batch: one per output group in flight
     std::vector<LaneWorker *> copy_workers;   // host_batch: helper threads of the staging copies
+    lzfse_mi_ctx *host_peer = nullptr;        // host_batch: the context of the second half of a large call ...
+    LaneWorker *host_worker = nullptr;        // ... and the thread that drives it
+    bool is_peer = false;
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
@@ -286,6 +289,10 @@ void lzfse_mi_destroy(lzfse_mi_ctx *c) {
                       &c->d_lmds, &c->d_lits, &c->d_origin, &c->d_jerr, &c->d_wcache, &c->d_fwalk, &c->d_ck, &c->d_lzp, &c->d_in, &c->d_out, &c->d_small})
         b->release();
     enc_scratch_release(c->enc);
+    delete c->host_worker;
+    c->host_worker = nullptr;
+    if (c->host_peer) lzfse_mi_destroy(c->host_peer);
+    c->host_peer = nullptr;
     for (LaneWorker *w : c->copy_workers) delete w;
     c->copy_workers.clear();
     for (hipEvent_t e : c->host_ev) (void)hipEventDestroy(e);
@@ -924,11 +931,11 @@ static uint64_t staged_at(const std::vector<CopyJob> &jobs, const std::vector<ui
     return stage[k] + (pos - pre[k]);
 }
 
-static int host_batch(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, size_t count, const uint8_t *const *srcs,
-                      const size_t *lens, uint8_t *const *dsts, const size_t *caps, size_t *out_lens,
-                      int *statuses) {
+static int host_batch_one(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, size_t count, const uint8_t *const *srcs,
+                          const size_t *lens, uint8_t *const *dsts, const size_t *caps, size_t *out_lens,
+                          int *statuses, const std::function<void()> *on_staged) {
     if (!c || (count && (!srcs || !lens || !dsts || !caps || !out_lens || !statuses))) return LZFSE_MI_BAD_ARGUMENT;
-    if (count == 0) return LZFSE_MI_OK;
+    if (count == 0) { if (on_staged) (*on_staged)(); return LZFSE_MI_OK; }
     HIP_TRY(hipSetDevice(c->device));
     std::vector<uint64_t> so(count), sl(count), dof(count), dc(count), ol(count);
     uint64_t in_total = 0, out_total = 0;
@@ -954,6 +961,7 @@ static int host_batch(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, size_
         const uint64_t a = staged_at(jobs, pre, stage, lo), b = staged_at(jobs, pre, stage, hi - 1) + 1;
         HIP_TRY(hipMemcpyAsync((uint8_t *)c->d_in.p + a, (uint8_t *)c->h_in.p + a, b - a, hipMemcpyHostToDevice, c->stream));
     }
+    if (on_staged) (*on_staged)();   // (the inputs are on their way: the other half of a split call may start staging)
     int r = fn(c, count, c->d_in.p, so.data(), sl.data(), c->d_out.p, dof.data(), dc.data(), ol.data(), statuses);
     if (r) return r;
     // ---- out: where each stream's bytes are on the device (packed first when they fill little of their capacity) ----
@@ -1014,6 +1022,56 @@ static int host_batch(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, size_
         par_copy(c, jobs, pre, lo, std::min(n_out, lo + HOST_GROUP));
     }
     return LZFSE_MI_OK;
+}
+
+// A large call is cut in two halves that run on two contexts, the second one step behind the first: its inputs travel
+// while the first half's kernels run, its kernels run while the first half's outputs travel and are copied out. (Not while
+// stage timings are collected: they are per context.)
+static int host_batch(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, size_t count, const uint8_t *const *srcs,
+                      const size_t *lens, uint8_t *const *dsts, const size_t *caps, size_t *out_lens,
+                      int *statuses) {
+    if (!c || (count && (!srcs || !lens || !dsts || !caps || !out_lens || !statuses))) return LZFSE_MI_BAD_ARGUMENT;
+    uint64_t bytes = 0;
+    for (size_t i = 0; i < count; i++) bytes += (uint64_t)lens[i] + caps[i];
+    size_t nA = 0;
+    // (measured: 1 GiB of 4 MiB streams +18 % encode, +10 % decode; 94 MB in 384 streams -10 % / -25 %: the halves must be large)
+    if (count >= 2 && bytes >= ((uint64_t)512 << 20) && !c->timing && !c->is_peer) {
+        uint64_t acc = 0;
+        while (nA + 1 < count && acc + lens[nA] + caps[nA] <= bytes / 2) { acc += (uint64_t)lens[nA] + caps[nA]; nA++; }
+        if (nA == 0) nA = 1;
+        if (!c->host_peer) {
+            if (lzfse_mi_create(c->device, &c->host_peer) != LZFSE_MI_OK) c->host_peer = nullptr;
+            else c->host_peer->is_peer = true;
+        }
+        if (c->host_peer && !c->host_worker) {
+            try { c->host_worker = new (std::nothrow) LaneWorker(); } catch (...) { c->host_worker = nullptr; }
+        }
+        if (!c->host_peer || !c->host_worker) nA = 0;
+    }
+    if (nA == 0 || nA >= count) {
+        const int r = host_batch_one(c, fn, pack_outputs, count, srcs, lens, dsts, caps, out_lens, statuses, nullptr);
+        return r;
+    }
+    lzfse_mi_ctx *p = c->host_peer;
+    p->opt_lanes_enc = c->opt_lanes_enc; p->opt_lanes_dec = c->opt_lanes_dec; p->opt_stagger = c->opt_stagger; p->opt_pipe = c->opt_pipe;
+    p->diag_lz_jump = c->diag_lz_jump; p->diag_lz_variant = c->diag_lz_variant; p->diag_stats = c->diag_stats; p->diag_chain = c->diag_chain;
+    p->diag_walk = c->diag_walk; p->diag_pipe_scatter = c->diag_pipe_scatter;
+    int rB = 0;
+    bool started = false;
+    const size_t nB = count - nA;
+    const std::function<void()> kick = [&] {
+        started = true;
+        c->host_worker->submit([&] { rB = host_batch_one(p, fn, pack_outputs, nB, srcs + nA, lens + nA, dsts + nA, caps + nA, out_lens + nA, statuses + nA, nullptr); });
+    };
+    const int rA = host_batch_one(c, fn, pack_outputs, nA, srcs, lens, dsts, caps, out_lens, statuses, &kick);
+    if (!started) kick();   // (the first half failed before its inputs were staged: the second still has to give its answers)
+    c->host_worker->wait();
+    // the detail words of both halves, in the caller's order
+    std::vector<uint32_t> det(count, 0u);
+    for (size_t i = 0; i < nA && i < c->detail_out.size(); i++) det[i] = c->detail_out[i];
+    for (size_t i = 0; i < nB && i < p->detail_out.size(); i++) det[nA + i] = p->detail_out[i];
+    c->detail_out.swap(det);
+    return rA ? rA : rB;
 }
 
 int lzfse_mi_decode_batch(lzfse_mi_ctx *c, size_t count, const uint8_t *const *srcs, const size_t *lens,

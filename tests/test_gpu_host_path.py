@@ -55,3 +55,26 @@ def test_host_batch_with_failed_streams_in_the_middle(ctx, oracle, snappy_raw):
     assert list(stE) == [0, 0, 6, 0] and ol[2] == 0
     for i in (0, 1, 3):
         assert dst[i][: ol[i]].tobytes() == encs[i]
+
+
+def test_host_batch_cut_in_two_halves(ctx, oracle, snappy_raw):
+    """A call of 512 MiB and more (inputs + capacities) runs as two halves on two contexts, one step apart; the results
+    and the error details are those of one call, in the caller's order."""
+    import lzfse_rust_amd as m
+    big = (snappy_raw["lcet10.txt"] * 40)[: 12 << 20]
+    raws = [big[i:] + big[:i] for i in range(0, 24 * 997, 997)]       # 24 different streams of 12 MiB
+    encs, st = ctx.encode_batch(raws)                                   # 288 MiB in + 288 MiB of capacity
+    assert all(e == 0 for e in st)
+    want = [oracle.encode(r) for r in raws[:2]] + [None] * 21 + [oracle.encode(raws[-1])]
+    for e, w in zip(encs, want):
+        if w is not None:
+            assert e.tobytes() == w
+    streams = [e.tobytes() for e in encs]
+    streams[3] = b"bvxQ" + streams[3][4:]           # first half: BadBlock with its magic as the detail
+    streams[20] = streams[20][:-7]                   # second half: cut short
+    outs, st = ctx.decode_batch(streams, caps=[2 * len(r) for r in raws])      # 90 MiB in + 576 MiB of capacity
+    assert [i for i, e in enumerate(st) if e] == [3, 20] and st[3] == 2 and st[20] == oracle.decode_status(streams[20], 2 * len(raws[20]))
+    assert ctx.error_detail(3) == int.from_bytes(b"bvxQ", "little")
+    for i, (o, r) in enumerate(zip(outs, raws)):
+        if i not in (3, 20):
+            assert o.tobytes() == r, i
