@@ -420,6 +420,22 @@ __device__ __forceinline__ void bw_advance(BitWindow &w, uint32_t total) {
         __builtin_amdgcn_wave_barrier();
     }
 }
+// the same in two parts for loops that run their steps with most lanes switched off: bw_consume inside (no lane of the
+// wave is needed), bw_refill outside with all 64 lanes, often enough that `steps` steps of at most 64 bits stay inside
+__device__ __forceinline__ void bw_consume(BitWindow &w, uint32_t total) { w.rem -= (int32_t)total; }
+__device__ __forceinline__ void bw_refill(BitWindow &w, int32_t steps) {
+    const int32_t t = (w.rem - 64) >> 5;
+    if (t - w.cb < 2 * steps + 2) {
+        const int l = lane_id();
+        const uint32_t low = w.buf[l];
+        w.buf[64 + l] = low;
+        w.buf[l] = w.pend;
+        w.cb -= 64;
+        w.pend = bw_gload(w, w.cb - 64 + l);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
 
 // bit_reader.rs:64-71
 __device__ __forceinline__ int bw_finalize(const BitWindow &w) {
@@ -641,22 +657,33 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
         // the lookup of step g + 1 needs only the state, so it is issued before the window of step g + 1 is fetched: the
         // two LDS round trips of a step overlap instead of following each other
         uint32_t ent = u_tab[state];
-        for (uint32_t g = 0; g < n_groups; g++) {
-            const uint32_t k = ent & 0xFF;
-            const int32_t delta = (int32_t)(int16_t)(ent >> 16);
-            uint32_t pre = k;
-            pre += dpp_shr<1>(pre);
-            pre += dpp_shr<2>(pre);  // inclusive prefix over lanes 0..3
-            const uint32_t bits = (uint32_t)(win >> ((64 - pre) & 63)) & ((1u << k) - 1u);  // pre == 0 only with k == 0
-            state = (uint32_t)((int32_t)bits + delta) & 1023u;
-            const uint32_t sym = ent >> 8;
-            ent = u_tab[state];
-            stg_lit[sidx] = (uint8_t)sym;
-            sidx += s_inc;
-            bw_advance(w, read_lane(pre, 3));
-            win = bw_step_window(w);
-            if ((g & 63) == 63) {
-                ((uint32_t *)out)[(g & ~63u) + lane] = ((const uint32_t *)stg_lit)[lane];
+        // The steps run with the lanes of row 0 only (16 at a time between two refill checks, which need the whole wave):
+        // every LDS and vector instruction of a step then makes one pass instead of one per 32 lanes, and the LDS pipe is
+        // what a full chip of these waves runs out of.
+        constexpr uint32_t SUB = 16;
+        for (uint32_t g0 = 0; g0 < n_groups; g0 += SUB) {
+            bw_refill(w, (int32_t)SUB);
+            const uint32_t g1 = n_groups - g0 < SUB ? n_groups : g0 + SUB;
+            if (lane < 4) {
+                for (uint32_t g = g0; g < g1; g++) {
+                    const uint32_t k = ent & 0xFF;
+                    const int32_t delta = (int32_t)(int16_t)(ent >> 16);
+                    uint32_t pre = k;
+                    pre += dpp_shr<1>(pre);
+                    pre += dpp_shr<2>(pre);  // inclusive prefix over lanes 0..3
+                    const uint32_t bits = (uint32_t)(win >> ((64 - pre) & 63)) & ((1u << k) - 1u);  // pre == 0 only with k == 0
+                    state = (uint32_t)((int32_t)bits + delta) & 1023u;
+                    const uint32_t sym = ent >> 8;
+                    ent = u_tab[state];
+                    stg_lit[sidx] = (uint8_t)sym;
+                    sidx += s_inc;
+                    bw_consume(w, read_lane(pre, 3));
+                    win = bw_step_window(w);
+                }
+            }
+            w.rem = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)w.rem);   // (uniform again: the lanes that were off kept the old value)
+            if ((g1 & 63) == 0) {
+                ((uint32_t *)out)[(g1 - 64) + lane] = ((const uint32_t *)stg_lit)[lane];
                 sidx = s_home;
             }
         }
@@ -702,24 +729,32 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
         };
         uint64_t win = n ? bw_window(w) : 0;
         uint2 ent = v_tab[tbase + state];   // (looked up one step ahead of its window, see the literal loop)
-        for (uint32_t i = 0; i < n; i++) {
-            const uint32_t k = ent.x & 0xFF, vb = (ent.x >> 8) & 0xFF;
-            const int32_t delta = (int32_t)(int16_t)(ent.x >> 16);
-            uint32_t pre = k + vb;
-            pre += dpp_shr<1>(pre);
-            pre += dpp_shr<2>(pre);
-            // a lane's field (state bits above value bits) is at most 10 + 15 bits: one 64-bit shift, two 32-bit extracts
-            const uint32_t x = (uint32_t)(win >> ((64 - pre) & 63));  // pre == 0 only when k = vb = 0 below
-            const uint32_t extra = x & ((1u << vb) - 1u);
-            const uint32_t sb = (x >> vb) & ((1u << k) - 1u);
-            state = (uint32_t)((int32_t)sb + delta) & smask;
-            const uint32_t value = ent.y + extra;
-            ent = v_tab[tbase + state];
-            stg_lmd[sidx] = value;
-            sidx += s_inc;
-            bw_advance(w, read_lane(pre, 2));
-            win = bw_step_window(w);
-            if ((i & 63) == 63) { flush(i & ~63u, 64); sidx = s_home; }
+        constexpr uint32_t SUB = 16;   // (see the literal loop)
+        for (uint32_t i0 = 0; i0 < n; i0 += SUB) {
+            bw_refill(w, (int32_t)SUB);
+            const uint32_t i1 = n - i0 < SUB ? n : i0 + SUB;
+            if (lane < 3) {
+                for (uint32_t i = i0; i < i1; i++) {
+                    const uint32_t k = ent.x & 0xFF, vb = (ent.x >> 8) & 0xFF;
+                    const int32_t delta = (int32_t)(int16_t)(ent.x >> 16);
+                    uint32_t pre = k + vb;
+                    pre += dpp_shr<1>(pre);
+                    pre += dpp_shr<2>(pre);
+                    // a lane's field (state bits above value bits) is at most 10 + 15 bits: one 64-bit shift, two 32-bit extracts
+                    const uint32_t x = (uint32_t)(win >> ((64 - pre) & 63));  // pre == 0 only when k = vb = 0 below
+                    const uint32_t extra = x & ((1u << vb) - 1u);
+                    const uint32_t sb = (x >> vb) & ((1u << k) - 1u);
+                    state = (uint32_t)((int32_t)sb + delta) & smask;
+                    const uint32_t value = ent.y + extra;
+                    ent = v_tab[tbase + state];
+                    stg_lmd[sidx] = value;
+                    sidx += s_inc;
+                    bw_consume(w, read_lane(pre, 2));
+                    win = bw_step_window(w);
+                }
+            }
+            w.rem = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)w.rem);
+            if ((i1 & 63) == 0) { flush(i1 - 64, 64); sidx = s_home; }
         }
         if (n & 63) flush(n & ~63u, n & 63);
         uint32_t sum_m = acc_m;
