@@ -78,3 +78,33 @@ def test_host_batch_cut_in_two_halves(ctx, oracle, snappy_raw):
     for i, (o, r) in enumerate(zip(outs, raws)):
         if i not in (3, 20):
             assert o.tobytes() == r, i
+
+
+def test_two_contexts_in_two_threads(oracle, snappy_raw):
+    """Distinct contexts are independent: two host threads, each with its own context, encode and decode
+    different batches at the same time (ctypes releases the GIL during the calls)."""
+    import threading
+    import lzfse_rust_amd as m
+    names = sorted(snappy_raw)
+    batches = [[snappy_raw[n] for n in names[:6]] * 3, [snappy_raw[n] for n in names[6:]] * 3 + [bytes(3 << 20)]]
+    want = [[oracle.encode(r) for r in b] for b in batches]
+    errors = []
+
+    def work(k):
+        try:
+            c = m.Context(0)
+            for _ in range(6):
+                encs, st = c.encode_batch(batches[k])
+                assert all(e == 0 for e in st)
+                assert [e.tobytes() for e in encs] == want[k]
+                outs, st = c.decode_batch(want[k])
+                assert all(e == 0 for e in st) and [o.tobytes() for o in outs] == batches[k]
+        except Exception as e:      # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
