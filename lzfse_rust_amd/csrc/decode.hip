@@ -661,6 +661,7 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
         // every LDS and vector instruction of a step then makes one pass instead of one per 32 lanes, and the LDS pipe is
         // what a full chip of these waves runs out of.
         constexpr uint32_t SUB = 16;
+        static_assert(64 % SUB == 0 && 2 * SUB + 2 <= 62, "a sub-chunk ends where a 64-step flush does, and its refill margin stays in the lower half of the ring");
         for (uint32_t g0 = 0; g0 < n_groups; g0 += SUB) {
             bw_refill(w, (int32_t)SUB);
             const uint32_t g1 = n_groups - g0 < SUB ? n_groups : g0 + SUB;
