@@ -994,6 +994,470 @@ int lzo_table_rows(const uint8_t *src, size_t n, uint32_t *rows) {
     return LZO_OK;
 }
 
+/* ================================================================== ring frontend */
+/* Restatement of the ring/stream encoder: LzfseRingEncoder::encode (encode/ring_encoder.rs:55-67),
+ * LzfseWriter / LzfseWriterBytes (encode/writer.rs:39-75, writer_bytes.rs:44-78) over FrontendRing
+ * (encode/frontend_ring.rs:30-687). Its parse is NOT the slice parse: a 512 KiB ring fed in 16 KiB blocks
+ * (encode/constants.rs:23-33), matched in rounds (match_long) with a capped, "coarse" forward length, a backward
+ * length that stops at the ring head, literals that pass the head pushed as they are (pending discarded), and a final
+ * match_short over what is left. The ring itself is simulated byte for byte, shadow zones included, so the coarse
+ * compares read exactly what the reference reads (also beyond `tail`, where the ring holds older data or, for a
+ * fresh encoder, zeros: a RingBox starts zeroed, ring/ring_box.rs:9-17; a REUSED reference encoder would see the
+ * previous stream's bytes there -- this oracle is a fresh LzfseRingEncoder per stream).
+ * Parity pin: the KATs of frontend_ring.rs:768-993 (tests/test_oracle_ring.py). */
+
+#define OVERMATCH_LEN 40u                     /* ring/object.rs:15 (5 * size_of::<usize>(), 64-bit target) */
+#define OVERMATCH_SLACK (4u + OVERMATCH_LEN)  /* frontend_ring.rs:21 */
+#define RING_WIDE 32u                         /* kit/wide.rs:2 */
+#define Q1 0x40000000u
+
+enum { COMMIT_NONE = 0, COMMIT_FSE = 1, COMMIT_VN = 2 };
+
+struct lzo_ring {
+    uint32_t ring_size, ring_blk, ring_limit;
+    uint8_t *box;  /* ring/ring_type.rs:12: RING_SIZE + 2 * RING_LIMIT + WIDE, zeroed (ring_box.rs:9-17) */
+    uint8_t *ring; /* box + RING_LIMIT (ring/object.rs:241-250) */
+    history_t *table;
+    int commit;
+    match_t pending;
+    uint32_t head, literal_idx, idx, tail, mark, clamp; /* wrapping Idx values (types/idx.rs) */
+    uint64_t n_raw_bytes;
+    frontend be; /* backend plumbing shared with the slice path: fse buffer / vn backend / dst / err / vn type */
+    fse_buffer *fb;
+    vec_t dst;
+    uint8_t *lit_tmp;
+    int dummy; /* KAT mode: encode/dummy.rs backend (trace only) */
+};
+
+/* types/idx.rs:75-80: ordering by wrapping signed difference */
+static inline int idx_lt(uint32_t a, uint32_t b) { return (int32_t)(a - b) < 0; }
+static inline int idx_ge(uint32_t a, uint32_t b) { return (int32_t)(a - b) >= 0; }
+
+/* ring/object.rs:213-216 */
+static inline uint32_t rf_get_u32(const lzo_ring *f, uint32_t idx) { return ld32(f->ring + (idx % f->ring_size)); }
+
+/* ring/object.rs:147-155,181-189 via zone_copy_1 / zone_copy_2 (:252-261) */
+static void rf_head_copy_out(lzo_ring *f) { memcpy(f->ring + f->ring_size, f->ring, f->ring_limit); }
+static void rf_tail_copy_out(lzo_ring *f) {
+    memcpy(f->ring - f->ring_limit, f->ring - f->ring_limit + f->ring_size, f->ring_limit);
+}
+
+/* frontend_ring.rs:577-583 */
+static void rf_manage_ring_zones(lzo_ring *f) {
+    if (f->mark % f->ring_size == f->ring_blk)
+        rf_head_copy_out(f);
+    else if (f->mark % f->ring_size == 0)
+        rf_tail_copy_out(f);
+}
+
+/* ring/object.rs:39-84 with LEN = 4 */
+static size_t rf_match_inc_coarse4(const lzo_ring *f, uint32_t a, uint32_t b, size_t max) {
+    size_t i0 = a % f->ring_size, i1 = b % f->ring_size;
+    uint64_t x = ld64(f->ring + i0 + 4) ^ ld64(f->ring + i1 + 4);
+    if (x) return 4 + (size_t)(__builtin_ctzll(x) >> 3);
+    size_t len = 4 + 8;
+    for (;;) {
+        for (size_t i = 0; i < 4; i++) {
+            size_t off = 4 + 8 + i * 8;
+            x = ld64(f->ring + i0 + off) ^ ld64(f->ring + i1 + off);
+            if (x) return len + i * 8 + (size_t)(__builtin_ctzll(x) >> 3);
+        }
+        if (len >= max) break;
+        len += 32;
+        i0 = (i0 + 32) % f->ring_size;
+        i1 = (i1 + 32) % f->ring_size;
+    }
+    return max;
+}
+
+/* ring/object.rs:88-135 with LEN = 0 */
+static size_t rf_match_dec_coarse0(const lzo_ring *f, uint32_t a, uint32_t b, size_t max) {
+    size_t i0 = (uint32_t)(a - OVERMATCH_LEN) % f->ring_size, i1 = (uint32_t)(b - OVERMATCH_LEN) % f->ring_size;
+    uint64_t x = ld64(f->ring + i0 + 32) ^ ld64(f->ring + i1 + 32);
+    if (x) return (size_t)(__builtin_clzll(x) >> 3);
+    size_t len = 8;
+    for (;;) {
+        for (size_t i = 0; i < 4; i++) {
+            size_t off = (3 - i) * 8;
+            x = ld64(f->ring + i0 + off) ^ ld64(f->ring + i1 + off);
+            if (x) return len + i * 8 + (size_t)(__builtin_clzll(x) >> 3);
+        }
+        if (len >= max) break;
+        len += 32;
+        i0 = (i0 + f->ring_size - 32) % f->ring_size;
+        i1 = (i1 + f->ring_size - 32) % f->ring_size;
+    }
+    return max;
+}
+
+/* frontend_ring.rs:453-507; f_short = the const generic F */
+static match_t rf_find_match(const lzo_ring *f, const history_t *queue, uint32_t val, uint32_t idx, uint32_t max,
+                             int f_short) {
+    match_t m = {0, 0, 0};
+    for (int c = 0; c < HASH_WIDTH; c++) {
+        uint32_t distance = idx - queue->q[c].idx;
+        if (distance > f->be.max_dist) break;
+        uint32_t x = val ^ queue->q[c].val, len;
+        if (x == 0)
+            len = (uint32_t)rf_match_inc_coarse4(f, idx, queue->q[c].idx, max); /* :493-501 */
+        else if (f->be.vn && (x & 0x00FFFFFFu) == 0)
+            len = 3;
+        else
+            len = 0;
+        if (len > m.match_len) {
+            m.match_len = len;
+            m.match_idx = queue->q[c].idx;
+        }
+    }
+    if (m.match_len == 0) return m;
+    uint32_t literal_len = idx - f->literal_idx;
+    m.idx = idx;
+    if (f_short && m.match_len > max) m.match_len = max;
+    uint32_t room = m.match_idx - f->head;
+    uint32_t bmax = room < literal_len ? room : literal_len;
+    uint32_t dec = (uint32_t)rf_match_dec_coarse0(f, m.idx, m.match_idx, bmax);
+    if (dec > bmax) dec = bmax;
+    m.idx -= dec;
+    m.match_idx -= dec;
+    m.match_len += dec;
+    return m;
+}
+
+/* ring/ring_view.rs: the bytes [from, from + len) of the ring, wrap handled */
+static const uint8_t *rf_view(lzo_ring *f, uint32_t from, uint32_t len) {
+    size_t i = from % f->ring_size;
+    if (i + len <= f->ring_size) return f->ring + i;
+    size_t first = f->ring_size - i;
+    memcpy(f->lit_tmp, f->ring + i, first);
+    memcpy(f->lit_tmp + first, f->ring, len - first);
+    return f->lit_tmp;
+}
+
+static void rf_backend_push(lzo_ring *f, uint32_t lit_from, uint32_t n_lit, uint32_t match_len, uint32_t dist) {
+    if (f->be.trace && f->be.trace->match)
+        f->be.trace->match(f->be.trace->ctx, lit_from, lit_from + n_lit, match_len, dist);
+    if (f->dummy) return;
+    const uint8_t *lit = rf_view(f, lit_from, n_lit);
+    if (f->be.vn && match_len == 0) { /* vn/backend.rs:57-74 */
+        if (!f->be.err && !vn_push_literals(&f->be.vnb, f->be.dst, lit, n_lit)) f->be.err = LZO_IO;
+        return;
+    }
+    backend_push_match(&f->be, lit, n_lit, match_len, dist);
+}
+
+/* frontend_ring.rs:523-535 */
+static void rf_push_match(lzo_ring *f, match_t m) {
+    uint32_t from = f->literal_idx;
+    f->literal_idx = m.idx + m.match_len;
+    rf_backend_push(f, from, m.idx - from, m.match_len, m.idx - m.match_idx);
+}
+
+/* frontend_ring.rs:550-562: Backend::push_literals = push_match(literals, 0, 1) for Fse (fse/backend.rs:67-73) */
+static void rf_push_literals(lzo_ring *f, uint32_t len) {
+    uint32_t from = f->literal_idx;
+    f->literal_idx += len;
+    rf_backend_push(f, from, len, 0, 1);
+}
+
+/* frontend_ring.rs:359-397 */
+static void rf_match_long(lzo_ring *f) {
+    const uint32_t long_match_len = f->ring_size / 2 - f->ring_blk - OVERMATCH_SLACK; /* :110 */
+    uint32_t idx = f->idx;
+    f->idx = f->head + f->ring_size / 2 + f->ring_blk;
+    for (;;) {
+        uint32_t u = rf_get_u32(f, idx);
+        history_t queue = table_push(f->table, f->be.vn, u, idx);
+        match_t incoming = rf_find_match(f, &queue, u, idx, long_match_len, 0), sel;
+        if (match_select(&f->pending, incoming, &sel)) {
+            rf_push_match(f, sel);
+            if (f->be.err) return;
+            idx += 1;
+            for (int32_t k = (int32_t)(f->literal_idx - idx); k > 0; k--) {
+                table_push(f->table, f->be.vn, rf_get_u32(f, idx), idx);
+                idx += 1;
+            }
+            if (idx_ge(idx, f->idx)) {
+                f->idx = idx;
+                break;
+            }
+        } else {
+            idx += 1;
+            if (idx == f->idx) break;
+        }
+    }
+}
+
+/* frontend_ring.rs:401-450 */
+static void rf_match_short(lzo_ring *f) {
+    uint32_t len = f->tail - f->idx;
+    if (len < 4) return;
+    const uint32_t unit = f->be.vn ? 3 : 4; /* MATCH_UNIT: fse/object.rs:24, vn/object.rs:24, encode/dummy.rs:27 */
+    uint32_t idx = f->idx;
+    f->idx = f->tail - unit + 1;
+    for (;;) {
+        uint32_t u = rf_get_u32(f, idx);
+        history_t queue = table_push(f->table, f->be.vn, u, idx);
+        uint32_t max = f->tail - idx;
+        match_t incoming = rf_find_match(f, &queue, u, idx, max, 1), sel;
+        if (match_select(&f->pending, incoming, &sel)) {
+            rf_push_match(f, sel);
+            if (f->be.err) return;
+            if (idx_ge(f->literal_idx, f->idx)) {
+                f->idx = f->literal_idx;
+                break;
+            }
+            idx += 1;
+            for (int32_t k = (int32_t)(f->literal_idx - idx); k > 0; k--) {
+                table_push(f->table, f->be.vn, rf_get_u32(f, idx), idx);
+                idx += 1;
+            }
+            if (idx_ge(idx, f->idx)) {
+                f->idx = idx;
+                break;
+            }
+        } else {
+            idx += 1;
+            if (idx == f->idx) break;
+        }
+    }
+}
+
+/* history.rs:45-50,121-130 with delta = 0 */
+static void rf_table_clamp(history_t *t, uint32_t idx) {
+    for (size_t i = 0; i < ((size_t)1 << HASH_BITS); i++)
+        for (int k = 0; k < HASH_WIDTH; k++)
+            if ((uint32_t)(idx - t[i].q[k].idx) > Q1) t[i].q[k].idx = idx - Q1;
+}
+
+/* history.rs:76-83 */
+static void rf_table_reset_with_idx(history_t *t, uint32_t idx) {
+    for (size_t i = 0; i < ((size_t)1 << HASH_BITS); i++)
+        for (int k = 0; k < HASH_WIDTH; k++) {
+            t[i].q[k].val = 0;
+            t[i].q[k].idx = idx - Q1;
+        }
+}
+
+/* frontend_ring.rs:209-227 (+ :250-272, :585-595) */
+static void rf_match_block(lzo_ring *f) {
+    rf_manage_ring_zones(f);
+    if (f->mark != f->head + f->ring_size) {
+        f->mark += f->ring_blk;
+        return;
+    }
+    if (f->commit == COMMIT_NONE) { /* commit(Fse): fse/backend.rs:59-63 */
+        f->commit = COMMIT_FSE;
+        buffer_reset(f->fb);
+    }
+    rf_match_long(f);
+    if (f->be.err) return;
+    /* reposition_head :250-254 */
+    uint32_t delta = f->idx - f->head;
+    delta = (delta - f->ring_size / 2) / f->ring_blk * f->ring_blk;
+    f->head += delta;
+    /* push_literal_overflow :257-272 */
+    if (idx_lt(f->literal_idx, f->head)) {
+        f->pending.match_len = 0;
+        rf_push_literals(f, f->head - f->literal_idx);
+    }
+    /* clamp :585-595 */
+    if ((int32_t)(f->idx - f->clamp) >= 0) {
+        rf_table_clamp(f->table, f->idx);
+        f->clamp += Q1;
+    }
+    f->mark = f->tail + f->ring_blk;
+}
+
+/* frontend_ring.rs:564-575 */
+static void rf_init(lzo_ring *f) {
+    table_reset(f->table);
+    f->commit = COMMIT_NONE;
+    memset(&f->pending, 0, sizeof f->pending);
+    f->head = f->literal_idx = f->idx = f->tail = 0;
+    f->mark = f->ring_blk;
+    f->clamp = Q1;
+    f->n_raw_bytes = 0;
+}
+
+lzo_ring *lzo_ring_new(uint32_t ring_size, uint32_t ring_blk, uint32_t ring_limit, const lzo_trace *trace) {
+    init_tables();
+    if (!ring_size) { /* encode/constants.rs:23-33 (Input) */
+        ring_size = 0x80000u;
+        ring_blk = 0x4000u;
+        ring_limit = 0x140u;
+    }
+    lzo_ring *f = (lzo_ring *)calloc(1, sizeof *f);
+    if (!f) return NULL;
+    f->ring_size = ring_size;
+    f->ring_blk = ring_blk;
+    f->ring_limit = ring_limit;
+    f->box = (uint8_t *)calloc(1, (size_t)ring_size + 2 * (size_t)ring_limit + RING_WIDE + 64);
+    f->table = (history_t *)malloc(sizeof(history_t) << HASH_BITS);
+    f->fb = (fse_buffer *)malloc(sizeof(fse_buffer));
+    f->lit_tmp = (uint8_t *)malloc(ring_size);
+    if (!f->box || !f->table || !f->fb || !f->lit_tmp) {
+        lzo_ring_free(f);
+        return NULL;
+    }
+    f->ring = f->box + ring_limit;
+    buffer_reset(f->fb);
+    f->fb->trace = trace;
+    f->fb->literals[0] = 0;
+    f->be.vn = 0;
+    f->be.max_dist = MAX_D_VALUE;
+    f->be.fse = f->fb;
+    f->be.dst = &f->dst;
+    f->be.trace = trace;
+    rf_init(f);
+    return f;
+}
+
+void lzo_ring_free(lzo_ring *f) {
+    if (!f) return;
+    free(f->box);
+    free(f->table);
+    free(f->fb);
+    free(f->lit_tmp);
+    free(f->dst.p);
+    free(f);
+}
+
+/* frontend_ring.rs:167-206 (`write`); `copy` (:138-164) feeds the same blocks from a reader */
+int lzo_ring_write(lzo_ring *f, const uint8_t *src, size_t len) {
+    f->n_raw_bytes += len;
+    for (;;) {
+        size_t index = f->tail % f->ring_size;
+        size_t limit = (uint32_t)(f->mark - f->tail);
+        if (len < limit) {
+            memcpy(f->ring + index, src, len);
+            f->tail += (uint32_t)len;
+            return f->be.err;
+        }
+        memcpy(f->ring + index, src, limit);
+        f->tail += (uint32_t)limit;
+        src += limit;
+        len -= limit;
+        rf_match_block(f);
+        if (f->be.err) return f->be.err;
+    }
+}
+
+/* frontend_ring.rs:344-355 */
+static void rf_finalize(lzo_ring *f) {
+    rf_match_short(f);
+    if (f->be.err) return;
+    if (f->pending.match_len != 0) { /* flush_pending :510-520 */
+        rf_push_match(f, f->pending);
+        f->pending.match_len = 0;
+    }
+    uint32_t len = f->tail - f->literal_idx; /* flush_literals :538-548 */
+    if (len != 0) rf_push_literals(f, len);
+}
+
+/* frontend_ring.rs:275-342 (flush, flush_select, flush_backend, flush_raw); the stream is then dst[0..*out_len) */
+int lzo_ring_finish(lzo_ring *f, const uint8_t **out, size_t *out_len) {
+    vec_t *dst = &f->dst;
+    rf_manage_ring_zones(f);
+    if (f->commit == COMMIT_FSE) {
+        rf_finalize(f);
+        if (!f->be.err) f->be.err = emit_block_v2(f->fb, dst);
+    } else {
+        uint32_t len = f->tail - f->idx;
+        if (len > VN_CUTOFF) {
+            f->commit = COMMIT_FSE;
+            buffer_reset(f->fb);
+            rf_finalize(f);
+            if (!f->be.err) f->be.err = emit_block_v2(f->fb, dst);
+        } else if (len > RAW_CUTOFF) {
+            f->commit = COMMIT_VN;
+            f->be.vn = 1;
+            f->be.max_dist = VN_MAX_D;
+            size_t mark = dst->len;
+            memset(&f->be.vnb, 0, sizeof f->be.vnb); /* vn/backend.rs:42-55 */
+            uint8_t zero[VN_HEADER_SIZE] = {0};
+            if (!vec_put(dst, zero, VN_HEADER_SIZE)) f->be.err = LZO_IO;
+            if (!f->be.err) rf_finalize(f);
+            if (!f->be.err) { /* vn/backend.rs:127-135 */
+                uint64_t eos = 0x06;
+                if (!vec_put(dst, &eos, 8)) f->be.err = LZO_IO;
+            }
+            if (!f->be.err) {
+                st32(dst->p + mark, MAGIC_VXN);
+                st32(dst->p + mark + 4, f->be.vnb.n_literals + f->be.vnb.n_match_bytes);
+                st32(dst->p + mark + 8, (uint32_t)(dst->len - mark) - VN_HEADER_SIZE);
+                if (len < RAW_LIMIT && (size_t)len + 8 <= dst->len - mark) { /* :323-330 */
+                    dst->len = mark;
+                    if (!raw_compress(dst, rf_view(f, f->head, f->tail - f->head), f->tail - f->head)) f->be.err = LZO_IO;
+                    f->literal_idx = f->tail;
+                }
+            }
+        } else {
+            if (!raw_compress(dst, rf_view(f, f->head, f->tail - f->head), f->tail - f->head)) f->be.err = LZO_IO;
+            f->literal_idx = f->tail;
+        }
+    }
+    if (!f->be.err && !vec_put32(dst, MAGIC_EOS)) f->be.err = LZO_IO;
+    *out = dst->p;
+    *out_len = dst->len;
+    return f->be.err;
+}
+
+/* LzfseRingEncoder::encode over a whole buffer, fed in `piece`-byte writes (0 = all at once) */
+int lzo_ring_encode(const uint8_t *src, size_t n, size_t piece, uint8_t *out, size_t cap, size_t *out_len,
+                    const lzo_trace *trace) {
+    lzo_ring *f = lzo_ring_new(0, 0, 0, trace);
+    if (!f) return LZO_IO;
+    int status = LZO_OK;
+    if (!piece) piece = n ? n : 1;
+    for (size_t o = 0; o < n && !status; o += piece) status = lzo_ring_write(f, src + o, n - o < piece ? n - o : piece);
+    const uint8_t *p = NULL;
+    size_t len = 0;
+    if (!status) status = lzo_ring_finish(f, &p, &len);
+    if (!status) {
+        if (len > cap)
+            status = LZO_BUFFER_OVERFLOW;
+        else {
+            memcpy(out, p, len);
+            *out_len = len;
+        }
+    }
+    lzo_ring_free(f);
+    return status;
+}
+
+/* The set-ups of the reference's in-file KATs (frontend_ring.rs:861-992), which drive match_short / match_long on a
+ * hand-made state with the Dummy backend (encode/dummy.rs: 3-byte match unit, distance <= 0x3FFF_FFFF; every push is
+ * reported through trace->match as (literal_idx, match idx, match len, distance)). `ring_data` fills the ring from
+ * index 0. mode 0: match_short from idx = 0 with tail = n (:869-883,:899-911,:971-982); mode 1: match_long from
+ * idx = literal_idx = idx0 after table.reset_with_idx(idx0), head = 0, tail = mark = RING_SIZE (:929-941). Either
+ * way a pending match is pushed afterwards and, in mode 0, the remaining literals. */
+int lzo_ring_kat(int mode, uint32_t ring_size, uint32_t ring_blk, uint32_t ring_limit, const uint8_t *ring_data,
+                 size_t n_data, uint32_t idx0, uint32_t n, const lzo_trace *trace) {
+    lzo_ring *f = lzo_ring_new(ring_size, ring_blk, ring_limit, trace);
+    if (!f) return LZO_IO;
+    f->dummy = 1;
+    f->be.vn = 1;
+    f->be.max_dist = 0x3FFFFFFFu;
+    if (n_data > ring_size) n_data = ring_size;
+    memcpy(f->ring, ring_data, n_data);
+    rf_head_copy_out(f);
+    rf_tail_copy_out(f);
+    if (mode == 0) {
+        f->tail = n;
+        f->mark = (n + ring_blk - 1) / ring_blk * ring_blk;
+        rf_match_short(f);
+    } else {
+        rf_table_reset_with_idx(f->table, idx0);
+        f->literal_idx = f->idx = idx0;
+        f->tail = f->mark = ring_size;
+        rf_match_long(f);
+    }
+    if (f->pending.match_len != 0) rf_push_match(f, f->pending);
+    if (mode == 0 && f->tail != f->literal_idx) rf_push_literals(f, f->tail - f->literal_idx);
+    lzo_ring_free(f);
+    return LZO_OK;
+}
+
 /* ================================================================== decoder */
 
 /* fse/decoder.rs:205-238 */

@@ -99,6 +99,20 @@ int lzo_candidates(const uint8_t *src, size_t n, uint32_t *match_idx, uint32_t *
 /* candidate queue (4 positions, newest first, 0xFFFFFFFF = empty) of every position 0 .. n-4 */
 int lzo_table_rows(const uint8_t *src, size_t n, uint32_t *rows);
 
+/* ---- ring / stream encoder: LzfseRingEncoder::encode, LzfseWriter, LzfseWriterBytes (encode/ring_encoder.rs:55-97,
+ * encode/writer.rs:39-75, encode/frontend_ring.rs). Its bytes differ from lzo_encode's (another parse). A handle is a
+ * fresh encoder; ring_size = 0 takes the reference's Input ring (512 KiB, 16 KiB blocks, encode/constants.rs:23-33). */
+typedef struct lzo_ring lzo_ring;
+lzo_ring *lzo_ring_new(uint32_t ring_size, uint32_t ring_blk, uint32_t ring_limit, const lzo_trace *trace);
+int lzo_ring_write(lzo_ring *r, const uint8_t *src, size_t len);                  /* Write::write */
+int lzo_ring_finish(lzo_ring *r, const uint8_t **out, size_t *out_len);           /* finalize(); *out is owned by r */
+void lzo_ring_free(lzo_ring *r);
+int lzo_ring_encode(const uint8_t *src, size_t n, size_t piece, uint8_t *dst, size_t cap, size_t *out_len,
+                    const lzo_trace *trace);
+/* the hand-made states of the reference's in-file KATs (frontend_ring.rs:861-992), Dummy backend */
+int lzo_ring_kat(int mode, uint32_t ring_size, uint32_t ring_blk, uint32_t ring_limit, const uint8_t *ring_data,
+                 size_t n_data, uint32_t idx0, uint32_t n, const lzo_trace *trace);
+
 /* Low-level restatements exported for known-answer tests. */
 void lzo_normalize_m1(uint16_t *weights, uint32_t n_weights, uint32_t in_total, uint32_t out_total);
 uint32_t lzo_weights_store_v2(const uint16_t *weights360, uint8_t *dst630);

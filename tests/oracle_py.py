@@ -52,6 +52,20 @@ class Oracle:
         lib.lzo_weights_store_v2.argtypes = [C.c_void_p, C.c_void_p]
         lib.lzo_weights_load_v2.restype = C.c_int
         lib.lzo_weights_load_v2.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        lib.lzo_ring_new.restype = C.c_void_p
+        lib.lzo_ring_new.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        lib.lzo_ring_write.restype = C.c_int
+        lib.lzo_ring_write.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.lzo_ring_finish.restype = C.c_int
+        lib.lzo_ring_finish.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        lib.lzo_ring_free.restype = None
+        lib.lzo_ring_free.argtypes = [C.c_void_p]
+        lib.lzo_ring_encode.restype = C.c_int
+        lib.lzo_ring_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
+                                        C.POINTER(C.c_size_t), C.c_void_p]
+        lib.lzo_ring_kat.restype = C.c_int
+        lib.lzo_ring_kat.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t,
+                                     C.c_uint32, C.c_uint32, C.c_void_p]
 
     @staticmethod
     def _buf(data):
@@ -120,6 +134,58 @@ class Oracle:
                    PACK_CB(lambda _c, l, m, d: packs.append((l, m, d))))
         enc = self.encode(data, trace=tr)
         return enc, matches, blocks, packs
+
+    # ---- ring / stream encoder (LzfseRingEncoder::encode, LzfseWriter) ----
+
+    def ring_encode(self, data, piece=0, trace=None):
+        """The stream LzfseRingEncoder::encode / LzfseWriter produce for `data` (fed `piece` bytes at a time)."""
+        a, p = self._buf(data)
+        cap = self.encode_bound(a.size) + 65536
+        out = np.empty(cap, dtype=np.uint8)
+        n = C.c_size_t(0)
+        st = self.lib.lzo_ring_encode(p, a.size, piece, out.ctypes.data, cap, C.byref(n),
+                                      C.byref(trace) if trace is not None else None)
+        if st != 0:
+            raise OracleError(st)
+        return out[: n.value].tobytes()
+
+    def ring_encode_pieces(self, pieces):
+        """The same through the handle API, one write per element of `pieces`."""
+        h = self.lib.lzo_ring_new(0, 0, 0, None)
+        try:
+            for pc in pieces:
+                a, p = self._buf(pc)
+                st = self.lib.lzo_ring_write(h, p, a.size)
+                if st != 0:
+                    raise OracleError(st)
+            ptr, n = C.c_void_p(), C.c_size_t(0)
+            st = self.lib.lzo_ring_finish(h, C.byref(ptr), C.byref(n))
+            if st != 0:
+                raise OracleError(st)
+            return C.string_at(ptr, n.value)
+        finally:
+            self.lib.lzo_ring_free(h)
+
+    def ring_encode_trace(self, data, piece=0):
+        matches, blocks, packs = [], [], []
+        tr = Trace(None, LMD_CB(),
+                   MATCH_CB(lambda _c, li, idx, ln, d: matches.append((li, idx, ln, d))),
+                   BLOCK_CB(lambda _c, a, b, c: blocks.append((a, b, c))),
+                   PACK_CB(lambda _c, l, m, d: packs.append((l, m, d))))
+        enc = self.ring_encode(data, piece, trace=tr)
+        return enc, matches, blocks, packs
+
+    def ring_kat(self, mode, ring, ring_data, idx0, n):
+        """frontend_ring.rs:861-992 set-ups on the test ring `ring` = (size, block, limit); returns the Dummy backend's
+        pushes as (literal_len, match_len, distance) and the literal positions."""
+        out = []
+        tr = Trace(None, LMD_CB(), MATCH_CB(lambda _c, li, idx, ln, d: out.append((li, idx - li, ln, d))),
+                   BLOCK_CB(), PACK_CB())
+        a, p = self._buf(ring_data)
+        st = self.lib.lzo_ring_kat(mode, ring[0], ring[1], ring[2], p, a.size, idx0, n, C.byref(tr))
+        if st != 0:
+            raise OracleError(st)
+        return out
 
     def candidates(self, data):
         a, p = self._buf(data)
