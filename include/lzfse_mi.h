@@ -204,6 +204,34 @@ LZFSE_MI_API int lzfse_mi_dstream_feed(lzfse_mi_dstream *s, const uint8_t *src, 
 LZFSE_MI_API int lzfse_mi_dstream_totals(const lzfse_mi_dstream *s, uint64_t *bytes_in, uint64_t *bytes_out);
 LZFSE_MI_API void lzfse_mi_dstream_destroy(lzfse_mi_dstream *s);
 
+/* ---- Ring / stream encode (encode half): LzfseRingEncoder::encode(reader, writer)
+ * (encode/ring_encoder.rs:55-67), LzfseRingEncoder::writer / writer_bytes -> LzfseWriter / LzfseWriterBytes
+ * (ring_encoder.rs:79-97, encode/writer.rs:39-75, encode/writer_bytes.rs:44-78). The reference's ring front end
+ * (encode/frontend_ring.rs) is another parse than the slice encoder's -- a 512 KiB ring matched in rounds, forward
+ * lengths capped and measured coarsely, literals that pass the ring's head pushed as they are -- so its streams are
+ * other BYTES than lzfse_mi_encode's for the same input (both decode to it). These entry points produce the ring
+ * encoder's bytes (those of a fresh LzfseRingEncoder: where the reference's compares run past the end of the input a
+ * reused encoder would see its previous stream's bytes in the ring), whatever the sizes of the pieces fed. */
+LZFSE_MI_API int lzfse_mi_encode_ring(lzfse_mi_ctx *ctx, const uint8_t *src, size_t n, uint8_t *dst, size_t cap,
+                                      size_t *out_len);
+LZFSE_MI_API int lzfse_mi_encode_ring_batch(lzfse_mi_ctx *ctx, size_t count, const uint8_t *const *srcs,
+                                            const size_t *lens, uint8_t *const *dsts, const size_t *caps,
+                                            size_t *out_lens, int *statuses);
+LZFSE_MI_API int lzfse_mi_encode_ring_batch_device(lzfse_mi_ctx *ctx, size_t count, const void *d_src,
+                                                   const uint64_t *src_off, const uint64_t *src_len, void *d_dst,
+                                                   const uint64_t *dst_off, const uint64_t *dst_cap,
+                                                   uint64_t *out_lens, int *statuses);
+/* LzfseWriter: feed = Write::write (any piece sizes), finish = finalize(): the stream leaves through `write` (which
+ * returns 0 to go on; anything else ends the call with LZFSE_MI_IO), *bytes_in / *bytes_out are the (u64, u64)
+ * LzfseRingEncoder::encode returns. The parse needs the 256 KiB behind and ahead of a position, so the device does it
+ * when the input is complete: feed stores, finish encodes (memory: the input, once). A stream object is used once. */
+typedef struct lzfse_mi_estream lzfse_mi_estream;
+LZFSE_MI_API int lzfse_mi_estream_create(lzfse_mi_ctx *ctx, lzfse_mi_estream **out);
+LZFSE_MI_API int lzfse_mi_estream_feed(lzfse_mi_estream *s, const uint8_t *src, size_t n);
+LZFSE_MI_API int lzfse_mi_estream_finish(lzfse_mi_estream *s, lzfse_mi_write_fn write, void *user, uint64_t *bytes_in,
+                                         uint64_t *bytes_out);
+LZFSE_MI_API void lzfse_mi_estream_destroy(lzfse_mi_estream *s);
+
 #ifdef __cplusplus
 }
 #endif

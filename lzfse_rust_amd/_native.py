@@ -25,6 +25,8 @@ _SYMBOLS = [
     "lzfse_mi_last_error_detail", "lzfse_mi_set_option", "lzfse_mi_chunked_bound", "lzfse_mi_encode_chunked",
     "lzfse_mi_decode_chunked_size", "lzfse_mi_decode_chunked", "lzfse_mi_dstream_create", "lzfse_mi_dstream_feed",
     "lzfse_mi_dstream_totals", "lzfse_mi_dstream_destroy", "lzfse_mi_decode_headroom",
+    "lzfse_mi_encode_ring", "lzfse_mi_encode_ring_batch", "lzfse_mi_encode_ring_batch_device",
+    "lzfse_mi_estream_create", "lzfse_mi_estream_feed", "lzfse_mi_estream_finish", "lzfse_mi_estream_destroy",
 ]
 
 
@@ -59,7 +61,7 @@ def _load(path):
     L.lzfse_mi_set_stream.argtypes = [vp, vp]
     L.lzfse_mi_encode_bound.restype = sz
     L.lzfse_mi_encode_bound.argtypes = [sz]
-    for name in ("lzfse_mi_encode", "lzfse_mi_decode"):
+    for name in ("lzfse_mi_encode", "lzfse_mi_decode", "lzfse_mi_encode_ring"):
         f = getattr(L, name)
         f.restype = C.c_int
         f.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
@@ -67,11 +69,11 @@ def _load(path):
     L.lzfse_mi_encode_small.argtypes = [vp, sz, vp, sz, C.POINTER(sz)]
     L.lzfse_mi_decode_size.restype = C.c_int
     L.lzfse_mi_decode_size.argtypes = [vp, sz, u64p]
-    for name in ("lzfse_mi_encode_batch", "lzfse_mi_decode_batch"):
+    for name in ("lzfse_mi_encode_batch", "lzfse_mi_decode_batch", "lzfse_mi_encode_ring_batch"):
         f = getattr(L, name)
         f.restype = C.c_int
         f.argtypes = [vp, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), ip]
-    for name in ("lzfse_mi_encode_batch_device", "lzfse_mi_decode_batch_device"):
+    for name in ("lzfse_mi_encode_batch_device", "lzfse_mi_decode_batch_device", "lzfse_mi_encode_ring_batch_device"):
         f = getattr(L, name)
         f.restype = C.c_int
         f.argtypes = [vp, sz, vp, u64p, u64p, vp, u64p, u64p, u64p, ip]
@@ -99,6 +101,14 @@ def _load(path):
     L.lzfse_mi_dstream_totals.argtypes = [vp, u64p, u64p]
     L.lzfse_mi_dstream_destroy.restype = None
     L.lzfse_mi_dstream_destroy.argtypes = [vp]
+    L.lzfse_mi_estream_create.restype = C.c_int
+    L.lzfse_mi_estream_create.argtypes = [vp, C.POINTER(vp)]
+    L.lzfse_mi_estream_feed.restype = C.c_int
+    L.lzfse_mi_estream_feed.argtypes = [vp, vp, sz]
+    L.lzfse_mi_estream_finish.restype = C.c_int
+    L.lzfse_mi_estream_finish.argtypes = [vp, WRITE_FN, vp, u64p, u64p]
+    L.lzfse_mi_estream_destroy.restype = None
+    L.lzfse_mi_estream_destroy.argtypes = [vp]
     L.lzfse_mi_set_option.restype = C.c_int
     L.lzfse_mi_set_option.argtypes = [vp, C.c_int, C.c_int64]
     return L

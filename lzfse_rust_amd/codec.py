@@ -2,6 +2,8 @@
 
     LzfseEncoder.encode_bytes(src, dst) -> int     src/encode/encoder.rs:49-53
     LzfseDecoder.decode_bytes(src, dst) -> int     src/decode/decoder.rs:61-69
+    LzfseRingEncoder.encode(reader, writer) / .writer(inner) / .writer_bytes(vec)   src/encode/ring_encoder.rs:55-97
+    LzfseRingDecoder.decode(reader, writer) / .reader(inner) / .reader_bytes(bytes) src/decode/ring_decoder.rs:57-90
     encode_bytes / decode_bytes (free functions)   src/encode/mod.rs:58-60, src/decode/mod.rs:49-51
 
 Same names, argument meaning and error behaviour: `dst` (a bytearray, the Vec<u8>) is appended
@@ -94,9 +96,10 @@ class Context:
         _check(fn(self._h, n, sp, sl, dp, dc, ol, st))
         return [outs[i][: ol[i]] for i in range(n)], list(st)
 
-    def encode_batch(self, srcs):
+    def encode_batch(self, srcs, ring=False):
+        """ring=True: the streams LzfseRingEncoder::encode / LzfseWriter produce (encode/frontend_ring.rs: another parse)."""
         caps = [self._lib.lzfse_mi_encode_bound(len(s)) for s in srcs]
-        return self._host_batch(self._lib.lzfse_mi_encode_batch, srcs, caps)
+        return self._host_batch(self._lib.lzfse_mi_encode_ring_batch if ring else self._lib.lzfse_mi_encode_batch, srcs, caps)
 
     def decode_batch(self, srcs, caps=None):
         if caps is None:
@@ -122,9 +125,9 @@ class Context:
         return self._device_batch(self._lib.lzfse_mi_decode_batch_device, d_src, src_off, src_len, d_dst, dst_off,
                                   dst_cap)
 
-    def encode_batch_device(self, d_src, src_off, src_len, d_dst, dst_off, dst_cap):
-        return self._device_batch(self._lib.lzfse_mi_encode_batch_device, d_src, src_off, src_len, d_dst, dst_off,
-                                  dst_cap)
+    def encode_batch_device(self, d_src, src_off, src_len, d_dst, dst_off, dst_cap, ring=False):
+        fn = self._lib.lzfse_mi_encode_ring_batch_device if ring else self._lib.lzfse_mi_encode_batch_device
+        return self._device_batch(fn, d_src, src_off, src_len, d_dst, dst_off, dst_cap)
 
 
 def encode_small(src):
@@ -184,6 +187,103 @@ class LzfseDecoder:
             raise LzfseError(st[0], self._ctx.error_detail(0))
         dst += outs[0].tobytes()
         return len(outs[0])
+
+
+class LzfseRingEncoder:
+    """src/encode/ring_encoder.rs:17-97. encode(reader, writer) -> (bytes read, bytes written); encode_bytes is the slice
+    encoder's (ring_encoder.rs:71-73); writer(inner) / writer_bytes(vec) give the Write front ends. The streams are the
+    ring front end's (encode/frontend_ring.rs), not the slice encoder's bytes."""
+
+    def __init__(self, device=0, context=None, read_size=1 << 20):
+        self._ctx = context or Context(device)
+        self._read_size = read_size
+
+    def encode(self, reader, writer):
+        w = LzfseWriter(self._ctx, writer)
+        n_in = 0
+        while True:
+            piece = reader.read(self._read_size)
+            if not piece:
+                break
+            n_in += w.write(piece)
+        w.finalize()
+        return n_in, w.bytes_out
+
+    def encode_bytes(self, src, dst):
+        return LzfseEncoder(context=self._ctx).encode_bytes(src, dst)
+
+    def writer(self, inner):
+        """LzfseRingEncoder::writer (ring_encoder.rs:79-84)"""
+        return LzfseWriter(self._ctx, inner)
+
+    def writer_bytes(self, vec):
+        """LzfseRingEncoder::writer_bytes (ring_encoder.rs:91-96): `vec` (a bytearray) is appended to"""
+        return LzfseWriterBytes(self._ctx, vec)
+
+
+class LzfseWriter:
+    """encode/writer.rs:12-75: write(buf) takes all of buf, flush() does nothing, finalize() ends the stream (the
+    bytes reach `inner` then) and returns `inner`. Dropping a writer without finalize() loses the stream, as in the
+    reference (writer.rs:36-38)."""
+
+    def __init__(self, context, inner):
+        self._ctx, self._inner = context, inner
+        self._lib = context._lib
+        self._h = C.c_void_p()
+        _check(self._lib.lzfse_mi_estream_create(context._h, C.byref(self._h)))
+        self.bytes_out = 0
+
+    def write(self, buf):
+        a = np.frombuffer(bytes(buf), dtype=np.uint8)
+        _check(self._lib.lzfse_mi_estream_feed(self._h, a.ctypes.data if a.size else None, a.size))
+        return a.size
+
+    def flush(self):
+        pass
+
+    def _sink(self, piece):
+        self._inner.write(piece)
+
+    def finalize(self):
+        failure = []
+
+        def _write(_user, p, n):
+            try:
+                self._sink(C.string_at(p, n))
+                return 0
+            except Exception as e:   # the sink's error travels back through the C layer as LZFSE_MI_IO
+                failure.append(e)
+                return 1
+
+        cb = _native.WRITE_FN(_write)
+        u, v = C.c_uint64(0), C.c_uint64(0)
+        try:
+            st = self._lib.lzfse_mi_estream_finish(self._h, cb, None, C.byref(u), C.byref(v))
+        finally:
+            self.close()
+        if failure:
+            raise failure[0]
+        _check(st)
+        self.bytes_out = v.value
+        return self._inner
+
+    def close(self):
+        if self._h:
+            self._lib.lzfse_mi_estream_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class LzfseWriterBytes(LzfseWriter):
+    """encode/writer_bytes.rs:12-78: the same over a Vec<u8> (here a bytearray); finalize() returns it."""
+
+    def _sink(self, piece):
+        self._inner += piece
 
 
 class LzfseRingDecoder:

@@ -142,6 +142,7 @@ struct lzfse_mi_ctx {
     int opt_pipe = 0;      // LZFSE_MI_OPT_DECODE_PIPE
     bool pipe_broken = false;   // a launch found the workgroups of one stream on different XCDs: never again on this context
     int lane_share = 1;    // sub-batches running side by side with this one (split_batch)
+    bool parse_ring = false;   // set for the duration of a ring / stream encode call (lzfse_mi_encode_ring*, lzfse_mi_estream_*)
     int diag_lz_jump = -1, diag_lz_variant = -1, diag_stats = 0, diag_chain = 0, diag_walk = 0, diag_pipe_scatter = 0;  // diagnostic build only
 
     hipEvent_t get_event() {
@@ -172,6 +173,7 @@ EncScratch &ctx_enc(lzfse_mi_ctx *c) { return c->enc; }
 LaneGate *ctx_gate_in(lzfse_mi_ctx *c) { return c->gate_in; }
 LaneGate *ctx_gate_out(lzfse_mi_ctx *c) { return c->gate_out; }
 int ctx_diag_stats(lzfse_mi_ctx *c) { return c->diag_stats; }
+bool ctx_parse_ring(lzfse_mi_ctx *c) { return c->parse_ring; }
 int ctx_diag_chain(lzfse_mi_ctx *c) { return c->diag_chain; }
 }  // namespace lzmi
 
@@ -687,7 +689,7 @@ static int encode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
         for (size_t k = 0; k < ns; k++) {
             size_t n = 0;
             const size_t i = small[k];
-            small_status[k] = lzfse_mi_encode_small(h_in + k * SLOT, (size_t)src_len[i], h_out + k * SLOT, SLOT, &n);
+            small_status[k] = lzmi::encode_small(h_in + k * SLOT, (size_t)src_len[i], h_out + k * SLOT, SLOT, &n, c->parse_ring);
             if (small_status[k] == 0 && n > dst_cap[i]) small_status[k] = LZFSE_MI_BUFFER_OVERFLOW;
             small_len[k] = small_status[k] ? 0 : n;
             hd[k] = {(uint64_t)k * SLOT, dst_off[i], (uint32_t)small_len[k], 0u};
@@ -743,7 +745,8 @@ static int split_batch(lzfse_mi_ctx *c, batch_dev_fn one, int lanes, bool stagge
     for (int k = 0; k + 1 < lanes; k++)
         if (!c->shadow[k]) {
             if (lzfse_mi_create(c->device, &c->shadow[k]) != LZFSE_MI_OK) { c->shadow[k] = nullptr; lanes = k + 1; break; }
-            c->worker[k] = new (std::nothrow) LaneWorker();
+            // (std::thread's constructor throws when no thread can be started: nothrow only covers the allocation)
+            try { c->worker[k] = new (std::nothrow) LaneWorker(); } catch (...) { c->worker[k] = nullptr; }
             if (!c->worker[k]) { lzfse_mi_destroy(c->shadow[k]); c->shadow[k] = nullptr; lanes = k + 1; break; }
         }
     if (lanes < 2 || !c->split_ev) return unsplit();
@@ -771,6 +774,7 @@ static int split_batch(lzfse_mi_ctx *c, batch_dev_fn one, int lanes, bool stagge
         ok = hipStreamWaitEvent(c->shadow[k]->stream, c->split_ev, 0) == hipSuccess;
         c->shadow[k]->timing = c->timing;
         c->shadow[k]->opt_pipe = c->opt_pipe;
+        c->shadow[k]->parse_ring = c->parse_ring;
         c->shadow[k]->diag_lz_jump = c->diag_lz_jump; c->shadow[k]->diag_lz_variant = c->diag_lz_variant;
         c->shadow[k]->diag_stats = c->diag_stats; c->shadow[k]->diag_chain = c->diag_chain; c->shadow[k]->diag_walk = c->diag_walk;
         c->shadow[k]->diag_pipe_scatter = c->diag_pipe_scatter;
@@ -1056,6 +1060,7 @@ static int host_batch(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, size_
     p->opt_lanes_enc = c->opt_lanes_enc; p->opt_lanes_dec = c->opt_lanes_dec; p->opt_stagger = c->opt_stagger; p->opt_pipe = c->opt_pipe;
     p->diag_lz_jump = c->diag_lz_jump; p->diag_lz_variant = c->diag_lz_variant; p->diag_stats = c->diag_stats; p->diag_chain = c->diag_chain;
     p->diag_walk = c->diag_walk; p->diag_pipe_scatter = c->diag_pipe_scatter;
+    p->parse_ring = c->parse_ring;
     int rB = 0;
     bool started = false;
     const size_t nB = count - nA;
@@ -1102,6 +1107,33 @@ int lzfse_mi_encode(lzfse_mi_ctx *c, const uint8_t *src, size_t n, uint8_t *dst,
     int st = 0;
     int r = lzfse_mi_encode_batch(c, 1, &src, &n, &dst, &cap, out_len, &st);
     return r ? r : st;
+}
+
+// ---- the ring / stream encoder's parse (LzfseRingEncoder::encode, LzfseWriter: encode/frontend_ring.rs) ----
+namespace {
+struct RingScope {   // the encode entry points below run the ordinary pipeline with the context marked for the ring parse
+    lzfse_mi_ctx *c;
+    explicit RingScope(lzfse_mi_ctx *ctx) : c(ctx) { if (c) c->parse_ring = true; }
+    ~RingScope() { if (c) c->parse_ring = false; }
+};
+}  // namespace
+
+int lzfse_mi_encode_ring_batch_device(lzfse_mi_ctx *c, size_t count, const void *d_src, const uint64_t *src_off,
+                                      const uint64_t *src_len, void *d_dst, const uint64_t *dst_off,
+                                      const uint64_t *dst_cap, uint64_t *out_lens, int *statuses) {
+    RingScope ring(c);
+    return lzfse_mi_encode_batch_device(c, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap, out_lens, statuses);
+}
+
+int lzfse_mi_encode_ring_batch(lzfse_mi_ctx *c, size_t count, const uint8_t *const *srcs, const size_t *lens,
+                               uint8_t *const *dsts, const size_t *caps, size_t *out_lens, int *statuses) {
+    RingScope ring(c);
+    return lzfse_mi_encode_batch(c, count, srcs, lens, dsts, caps, out_lens, statuses);
+}
+
+int lzfse_mi_encode_ring(lzfse_mi_ctx *c, const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *out_len) {
+    RingScope ring(c);
+    return lzfse_mi_encode(c, src, n, dst, cap, out_len);
 }
 
 }  // extern "C"

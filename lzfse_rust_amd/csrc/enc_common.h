@@ -38,6 +38,40 @@ __device__ __forceinline__ uint32_t link_chk(uint32_t r) { return r >> 18; }
 // Entry of a chain tile's last-seen table and of its summary: (offset in tile + 1) | check bits << 16; 0 = none
 __device__ __forceinline__ uint32_t seen_make(uint32_t off1, uint32_t v) { return off1 | (chk_of(v) << 16); }
 
+// ---- geometry of the reference's ring encoder in flat positions (encode/frontend_ring.rs, encode/constants.rs:23-33) ----
+// The ring (512 KiB, filled in 16 KiB blocks) is matched in rounds: round 0 takes positions [0, RING/2 + BLK) with the ring
+// holding [0, RING); every later round starts at the position idx the one before stopped at, with
+// head = align_down(idx, BLK) - RING/2 (reposition_head :250-254), tail = head + RING, and runs to head + RING/2 + BLK
+// = align_down(idx, BLK) + BLK (match_long :359-397) -- as long as the input reaches tail (match_block :216-219). What is
+// left is matched by match_short (:401-450) with tail = n. A position that is VISITED at all therefore sees a head and a
+// tail that depend on the position and on n only: rounds end at multiples of BLK, and a round that a long match overshot
+// only moves the head further up, where it cannot bind (the match ends at literal_idx, and a backward extension never
+// passes literal_idx). T_last = first position of the short phase's block.
+constexpr uint32_t RING_SIZE = 0x80000u, RING_BLK = 0x4000u, RING_HALF = RING_SIZE / 2;
+constexpr uint32_t RING_FIRST_END = RING_HALF + RING_BLK;                    // end of round 0
+constexpr uint32_t RING_LONG_MATCH = RING_HALF - RING_BLK - 44u;             // LONG_MATCH_LEN (:110), OVERMATCH_SLACK = 4 + 40 (:21)
+struct RingGeo {
+    uint32_t head, tail;
+    bool is_short;     // matched by match_short: forward length limited by the end of the input, not by LONG_MATCH_LEN
+};
+__host__ __device__ __forceinline__ uint32_t ring_t_last(uint32_t n) { return ((n - RING_HALF) & ~(RING_BLK - 1)) + RING_BLK; }  // n >= RING_SIZE
+__host__ __device__ __forceinline__ RingGeo ring_geo(uint32_t n, uint32_t p) {
+    RingGeo g;
+    if (n < RING_SIZE) { g.head = 0; g.tail = n; g.is_short = true; return g; }
+    const uint32_t tl = ring_t_last(n);
+    if (p < tl) {
+        g.head = p < RING_FIRST_END ? 0u : (p & ~(RING_BLK - 1)) - RING_HALF;
+        g.tail = g.head + RING_SIZE; g.is_short = false;
+    } else { g.head = tl - RING_HALF; g.tail = n; g.is_short = true; }
+    return g;
+}
+// lowest position a backward extension of a match found at p may reach (find_match :482: match_idx - head); 0 for the slice parse
+__host__ __device__ __forceinline__ uint32_t parse_head(uint32_t ring, uint32_t n, uint32_t p) {
+    if (!ring || n < RING_SIZE || p < RING_FIRST_END) return 0u;
+    const uint32_t tl = ring_t_last(n);
+    return ((p < tl ? p : tl) & ~(RING_BLK - 1)) - RING_HALF;
+}
+
 struct EncStream {       // one input stream (n > VN_CUTOFF) of the batch
     uint64_t src_off;    // offset of the stream in d_src
     uint64_t pos_base;   // offset of the stream in the per-position arrays (prev, rec)
@@ -55,7 +89,8 @@ struct EncStream {       // one input stream (n > VN_CUTOFF) of the batch
     uint32_t seg_base, n_seg;      // segments of this stream in the segment arrays
     uint32_t range_base, range_cap;
     uint64_t match_base;           // offset into the match / gap / prefix-sum arrays
-    uint32_t match_cap, pad0;
+    uint32_t match_cap;
+    uint32_t ring;                 // 1: the ring / stream encoder's parse (encode/frontend_ring.rs), 0: the slice parse
 };
 
 struct SpecEvent {   // one emitted match of a segment walker + the walker state after it
@@ -79,7 +114,7 @@ struct EncTile {         // one chain tile; carries what its kernels need of the
     uint32_t stream;
     uint32_t n;          // stream length
     uint32_t start;      // first position of the tile (stream relative)
-    uint32_t pad;
+    uint32_t ring;       // EncStream::ring
     uint64_t src_off;    // offset of the stream in d_src
     uint64_t pos_base;   // offset of the stream in the per-position arrays (prev, rec)
 };

@@ -720,6 +720,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         ~GateRelease() { if (g) g->open(2); }
     } gate_release{ctx_gate_out(c)};
     std::vector<EncStream> hs;
+    const uint32_t ring = ctx_parse_ring(c) ? 1u : 0u;   // the ring / stream encoder's parse (encode/frontend_ring.rs) instead of the slice parse
     for (uint32_t i = 0; i < count; i++) {
         out_lens[i] = 0;
         statuses[i] = LZFSE_MI_OK;
@@ -728,7 +729,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         if (n > 0x7FFFFFFFull) { statuses[i] = LZFSE_MI_UNSUPPORTED; continue; }  // reposition path (:348-375) not built
         EncStream e{};
         e.src_off = src_off[i]; e.dst_off = dst_off[i]; e.dst_cap = dst_cap[i];
-        e.n = (uint32_t)n; e.user_index = i;
+        e.n = (uint32_t)n; e.user_index = i; e.ring = ring;
         hs.push_back(e);
     }
     const uint32_t ns = (uint32_t)hs.size();
@@ -745,9 +746,9 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         e.pos_base = pos_total;
         e.tile_base = (uint32_t)ht.size();
         const uint32_t n_pos = e.n - 3;
-        for (uint32_t p = 0; p < n_pos; p += TILE_POS) ht.push_back({si, e.n, p, 0u, e.src_off, e.pos_base});
+        for (uint32_t p = 0; p < n_pos; p += TILE_POS) ht.push_back({si, e.n, p, e.ring, e.src_off, e.pos_base});
         e.blk_base = blk_total;
-        e.blk_cap = e.n / 39000 + 2;
+        e.blk_cap = e.n / 39000 + 2 + ring;
         e.lmd_base = lmd_total;
         e.lmd_cap = e.n / 4 + e.n / 256 + 2 * e.blk_cap + 64;
         e.lmd_cap = (e.lmd_cap + 63) & ~63u;
@@ -758,9 +759,10 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         e.n_seg = (n_pos + SEG - 1) / SEG;
         for (uint32_t k = 0; k < e.n_seg; k++) hsegs.push_back(make_uint2(si, k));
         e.range_base = range_total;
-        e.range_cap = 2 * e.n_seg + 4;
+        // (ring parse: up to one more event and range per 16 KiB block, the literals a round pushes when they pass the head)
+        e.range_cap = 2 * e.n_seg + 4 + (ring ? e.n / RING_BLK + 4 : 0);
         e.match_base = match_total;
-        e.match_cap = e.n / 4 + 8;
+        e.match_cap = e.n / 4 + 8 + (ring ? e.n / RING_BLK + 4 : 0);
         for (uint32_t b = 0; b < e.blk_cap; b++) hslots.push_back(si);
         for (uint32_t b = 0; b < e.range_cap; b++) hrslots.push_back(si);
         blk_total += e.blk_cap;

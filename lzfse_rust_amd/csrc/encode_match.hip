@@ -516,7 +516,9 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
         }
         if (len) {
             if (len > cap_total) len = cap_total;
-            if (len == cap_total && cap_total < max_total) capped = true;
+            // (ring parse: a candidate that runs to the end of the input is compared past it by the reference's coarse compare,
+            // ring/object.rs:39-84, and which candidate wins depends on that: the walkers evaluate such a position exactly)
+            if (len == cap_total && (cap_total < max_total || tl.ring)) capped = true;
             if (len > best_len) { best_len = len; best_idx = c; }  // ties keep the newest (:226)
         }
     }

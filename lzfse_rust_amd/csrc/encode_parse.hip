@@ -138,6 +138,54 @@ __device__ uint32_t st_wave_lcs_bwd(const uint8_t *s, uint32_t a, uint32_t b, ui
     return max;
 }
 
+// Forward length of candidate c at position p as the reference's RING encoder measures it, by the whole wave (uniform
+// arguments): match_inc_coarse::<4> (ring/object.rs:39-84) looks at 8 bytes, then at 32 bytes per step, and gives up with
+// `max` once a step that began at or beyond `max` found nothing -- so it returns the true common length while that is
+// below thr = 12 + 32 (K + 1), K = ceil((max - 12) / 32), and `max` otherwise; and it reads the ring, not the input: from
+// `tail` on it sees what the ring still holds there, the byte one ring earlier (zeros while the ring has not wrapped: a
+// fresh RingBox is zeroed, ring/ring_box.rs:9-17). find_match picks the candidate by THESE lengths (:460-471) and only
+// match_short cuts the winner back to max (:479-481).
+__device__ uint32_t st_ring_fwd(const uint8_t *s, uint32_t p, uint32_t c, const RingGeo g, uint32_t max) {
+    const uint32_t K = max > 12 ? (max - 12 + 31) / 32 : 0;
+    const uint32_t thr = 12 + 32 * (K + 1);
+    const uint32_t real = g.tail - p;                 // bytes from p on that are the input's own
+    const uint32_t lim = thr < real ? thr : real;
+    uint32_t len = st_wave_lcp_fwd(s, p, c, 4, lim);
+    if (len == lim && lim < thr) {
+        // past the tail (thr - lim <= 63 bytes: one lane each)
+        const uint32_t q = lim + (uint32_t)e_lane();
+        bool bad = false;
+        if (q < thr) {
+            const uint32_t xa = p + q, xb = c + q;
+            const uint8_t va = xa < g.tail ? s[xa] : (xa >= RING_SIZE ? s[xa - RING_SIZE] : (uint8_t)0);
+            const uint8_t vb = xb < g.tail ? s[xb] : (xb >= RING_SIZE ? s[xb - RING_SIZE] : (uint8_t)0);
+            bad = va != vb;
+        }
+        const uint64_t bm = __ballot(bad);
+        len = bm ? lim + (uint32_t)__builtin_ctzll(bm) : thr;
+    }
+    return len < thr ? len : max;
+}
+
+// find_match's forward part for the ring parse (frontend_ring.rs:453-481) at position p, exact, by the whole wave
+__device__ void st_ring_find(const uint8_t *s, const uint32_t *pv, uint32_t n, uint32_t p, uint32_t &best_len, uint32_t &best_idx) {
+    const RingGeo g = ring_geo(n, p);
+    const uint32_t max = g.is_short ? n - p : RING_LONG_MATCH;
+    const uint32_t v = ld_u32(s + p);
+    uint32_t c = p, d = link_dist(pv[p]);
+    best_len = 0; best_idx = 0;
+    for (int q = 0; q < 4 && d != 0; q++) {
+        c -= d;
+        if (p - c > MAX_D_VALUE) break;
+        if (ld_u32(s + c) == v) {
+            const uint32_t len = st_ring_fwd(s, p, c, g, max);
+            if (len > best_len) { best_len = len; best_idx = c; }
+        }
+        d = link_dist(pv[c]);
+    }
+    if (g.is_short && best_len > max) best_len = max;
+}
+
 // All 64 lanes stay in the loop until every segment of the wave is finished, so that a lane whose
 // record is capped can have its exact lengths computed by the whole wave (one request at a time).
 template <bool STAGED>
@@ -151,6 +199,7 @@ __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict_
     const uint2 sg = exists ? segs[g] : make_uint2(0, 0);
     const EncStream &es = streams[sg.x];
     const uint32_t end = es.n - 3;
+    const uint32_t ring = exists ? es.ring : 0u, n_own = es.n;
     const uint32_t S = sg.y * SEG;
     const uint32_t stop = exists ? ((S + SEG + OVER < end) ? S + SEG + OVER : end) : 0;
     const uint32_t *r = rec + es.pos_base;
@@ -230,27 +279,32 @@ __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict_
                 if (q_p - c > MAX_D_VALUE) break;
                 if (ld_u32(s + c) == v) {
                     uint32_t len = st_wave_lcp_fwd(s, q_p, c, 4, lim);
-                    if (len == lim && lim < maxl) over = true;
+                    // (ring parse: a candidate that runs to the end of the input is measured past it, st_ring_fwd: the stitcher's)
+                    if (len == lim && (lim < maxl || qs.ring)) over = true;
                     if (len > best_len) { best_len = len; best_idx = c; }
                 }
                 d = link_dist(pv[c]);
             }
-            const uint32_t bl = st_wave_lcs_bwd(s, q_p, best_idx, best_idx < BCAP ? best_idx : BCAP);
+            const uint32_t q_hr = best_idx - parse_head(qs.ring, qs.n, q_p);
+            const uint32_t bl = st_wave_lcs_bwd(s, q_p, best_idx, q_hr < BCAP ? q_hr : BCAP);
             if (lane == L) {
                 if (over) { status = 1; running = false; have = false; }  // longer than XCAP: left to the stitcher
                 else { fwd = best_len; midx = best_idx; dist = q_p - best_idx; bw = bl; }
             }
         }
         // ---- exact backward length when the capped one may be too short (frontend_bytes.rs:259-268) ----
-        const uint32_t room = p - st.lit;
+        // backward room: the literals before p, and the bytes between the candidate and the start of the input -- or, for
+        // the ring parse, the ring's head (frontend_ring.rs:482)
+        const uint32_t hroom = midx - parse_head(ring, n_own, p);
+        const uint32_t room = (p - st.lit) < hroom ? p - st.lit : hroom;
         uint32_t b = bw < room ? bw : room;
-        uint64_t reqb = __ballot(have && bw == BCAP && room > BCAP && midx > BCAP);
+        uint64_t reqb = __ballot(have && bw == BCAP && room > BCAP);
         while (reqb) {
             const int L = __builtin_ctzll(reqb);
             reqb &= reqb - 1;
             const uint32_t q_stream = e_readlane(sg.x, L), q_p = e_readlane(p, L), q_m = e_readlane(midx, L), q_room = e_readlane(room, L);
             const uint8_t *s = src + streams[q_stream].src_off;
-            const uint32_t bl = st_wave_lcs_bwd(s, q_p, q_m, q_room < q_m ? q_room : q_m);
+            const uint32_t bl = st_wave_lcs_bwd(s, q_p, q_m, q_room);
             if (lane == L) b = bl;
         }
         if (have) {
@@ -394,6 +448,11 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
     const uint32_t *r = rec + es.pos_base;
     const uint64_t *bm = bitmap + (es.pos_base >> 6);
     const uint32_t n = es.n, end = n - 3, K = es.n_seg;
+    // ring parse: the rounds of match_long end at the multiples of RING_BLK in [RING_FIRST_END, t_last]; a round that ends
+    // with literals older than the new head pushes them as they are and drops the pending match (frontend_ring.rs:250-272)
+    const uint32_t ring = es.ring;
+    const bool rounds = ring && n >= RING_SIZE;
+    const uint32_t t_last = rounds ? ring_t_last(n) : 0u;
     const SpecEvent *L0 = logs + (uint64_t)es.seg_base * SEG_EV_CAP;
     const SpecHeader *H0 = hdrs + es.seg_base;
     Stitch x;
@@ -473,37 +532,74 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
         // ---- true walk (exact, scalar): frontend_bytes.rs:183-208 ----
         if (T.index >= end) { done = true; break; }
         uint32_t p = next_has_wave(bm, T.index, end);
+        if (rounds) {
+            // positions without a candidate are single steps of match_long: every round end B in (T.index, p] is reached
+            // with idx == B, the head moves to B - RING/2, and literals below it are pushed (pending dropped)
+            const uint32_t pe = p < end ? p : end;
+            uint32_t B = (T.index / RING_BLK + 1) * RING_BLK;
+            if (B < RING_FIRST_END) B = RING_FIRST_END;
+            for (; B <= pe && B <= t_last && !x.status; B += RING_BLK)
+                if (T.lit < B - RING_HALF) {
+                    T.p_len = 0;
+                    sx_gap_event(x, T.lit, B - RING_HALF, 0, 1);
+                    T.lit = B - RING_HALF;
+                }
+        }
         if (p >= end) { T.index = end; done = true; break; }
         st_iters++;
         T.index = p;
         const uint32_t rr = r[p];
         uint32_t dist = rec_dist(rr), bw = rec_bwd(rr), fwd = rec_fwd(rr);
         uint32_t midx = p - dist;
+        const uint32_t head = parse_head(ring, n, p);
         if (fwd == FCAP) {
-            // exact forward part of find_match (frontend_bytes.rs:214-231) by the whole wave
-            uint32_t v = ld_u32(s + p), best_len = 0, best_idx = 0, c = p, d = link_dist(pv[p]);
-            for (int q = 0; q < 4 && d != 0; q++) {
-                c -= d;
-                if (p - c > MAX_D_VALUE) break;
-                if (ld_u32(s + c) == v) {
-                    uint32_t len = st_wave_lcp_fwd(s, p, c, 4, n - p);
-                    if (len > best_len) { best_len = len; best_idx = c; }
+            // exact forward part of find_match (frontend_bytes.rs:214-231; ring parse: frontend_ring.rs:453-481) by the whole wave
+            uint32_t best_len = 0, best_idx = 0;
+            if (ring) st_ring_find(s, pv, n, p, best_len, best_idx);
+            else {
+                uint32_t v = ld_u32(s + p), c = p, d = link_dist(pv[p]);
+                for (int q = 0; q < 4 && d != 0; q++) {
+                    c -= d;
+                    if (p - c > MAX_D_VALUE) break;
+                    if (ld_u32(s + c) == v) {
+                        uint32_t len = st_wave_lcp_fwd(s, p, c, 4, n - p);
+                        if (len > best_len) { best_len = len; best_idx = c; }
+                    }
+                    d = link_dist(pv[c]);
                 }
-                d = link_dist(pv[c]);
             }
             fwd = best_len; midx = best_idx; dist = p - midx;
-            bw = st_wave_lcs_bwd(s, p, midx, midx < BCAP ? midx : BCAP);
+            bw = st_wave_lcs_bwd(s, p, midx, midx - head < BCAP ? midx - head : BCAP);
         }
-        const uint32_t room = p - T.lit;
+        const uint32_t hroom = midx - head;
+        const uint32_t room = (p - T.lit) < hroom ? p - T.lit : hroom;
         uint32_t b = bw < room ? bw : room;
-        if (bw == BCAP && room > BCAP && midx > BCAP) b = st_wave_lcs_bwd(s, p, midx, room < midx ? room : midx);
+        if (bw == BCAP && room > BCAP) b = st_wave_lcs_bwd(s, p, midx, room);
         uint32_t e_idx = 0, e_midx = 0, e_len = 0;
         const uint32_t lit_before = T.lit;
-        if (select40(T, p - b, midx - b, fwd + b, e_idx, e_midx, e_len)) {
+        const bool emitted = select40(T, p - b, midx - b, fwd + b, e_idx, e_midx, e_len);
+        if (emitted) {
             sx_gap_event(x, lit_before, e_idx, e_len, e_idx - e_midx);
             T.lit = e_idx + e_len;
             if (T.lit >= end) { T.index = end; done = true; break; }
             T.index = (p + 1 > T.lit) ? p + 1 : T.lit;
+        } else {
+            T.index = p + 1;
+        }
+        if (rounds) {
+            // a step (or a match's skip) that carried idx over a round end: the round ends with this idx (:382-392)
+            uint32_t B = (p / RING_BLK + 1) * RING_BLK;
+            if (B < RING_FIRST_END) B = RING_FIRST_END;
+            if (B <= T.index && B <= t_last) {
+                const uint32_t nh = (T.index & ~(RING_BLK - 1)) - RING_HALF;
+                if (T.lit < nh) {
+                    T.p_len = 0;
+                    sx_gap_event(x, T.lit, nh, 0, 1);
+                    T.lit = nh;
+                }
+            }
+        }
+        if (emitted) {
             // does the log of the segment we are in agree with this state?
             uint32_t kk = T.index / SEG;
             if (kk >= K) kk = K - 1;
@@ -523,8 +619,6 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
                     }
                 }
             }
-        } else {
-            T.index = p + 1;
         }
     }
     if (!x.status) {

@@ -7,6 +7,13 @@
 // LZVN emission follows vn/backend.rs:37-136 and vn/opc.rs; the parse is the same lazy matcher as
 // the bvx2 path (frontend_bytes.rs:160-344, match_object.rs:12-33) instantiated for the Vn match
 // unit: 3-byte hash, 3- or 4+-byte matches, distances <= 65 535 (vn/object.rs:9-60).
+//
+// The ring / stream encoder (LzfseRingEncoder::encode, LzfseWriter: encode/frontend_ring.rs) makes the same choice of
+// block kinds below one ring (flush_select :297-312) but runs its own loop over them, match_short (:401-450), which is
+// not the slice loop for the Vn unit: it visits one more position (idx < tail - MATCH_UNIT + 1 = n - 2, so the last
+// 4-byte load reads one byte past the input) and it measures candidates with the ring's coarse compare, which runs past
+// the end of the input (st. ring/object.rs:39-84: what lies there in a fresh ring is zeros) before the winner is cut
+// back to the input's end. `ring` selects that loop; 16 % of random inputs of 21..4096 bytes come out differently.
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -84,14 +91,27 @@ void raw_block(std::vector<uint8_t> &o, const uint8_t *src, uint32_t n) {  // ra
     put32(o, 0x2D787662u); put32(o, n); o.insert(o.end(), src, src + n);
 }
 
-void vn_block(std::vector<uint8_t> &o, const uint8_t *src, uint32_t n) {
+// match_inc_coarse::<4> (ring/object.rs:39-84) on a flat, zero-padded copy of the input: the true common length while
+// it is below 12 + 32 (K + 1), K = ceil((max - 12) / 32), else max
+uint32_t coarse_inc4(const uint8_t *b, uint32_t i, uint32_t c, uint32_t max) {
+    const uint32_t K = max > 12 ? (max - 12 + 31) / 32 : 0, thr = 12 + 32 * (K + 1);
+    uint32_t len = 4;
+    while (len < thr && b[i + len] == b[c + len]) len++;
+    return len < thr ? len : max;
+}
+
+void vn_block(std::vector<uint8_t> &o, const uint8_t *input, uint32_t n, bool ring) {
+    // (ring: the loads and compares past the end of the input see zeros, as in a fresh RingBox, ring/ring_box.rs:9-17)
+    std::vector<uint8_t> padded;
+    const uint8_t *src = input;
+    if (ring) { padded.assign(size_t(n) + 128, 0); std::memcpy(padded.data(), input, n); src = padded.data(); }
     const size_t mark = o.size();
     o.insert(o.end(), 12, 0);
     VnWriter w(o);
     VnHistory hist;
     Candidate pending;
     uint32_t lit = 0;
-    const uint32_t end = n - 3;
+    const uint32_t end = ring ? n - 2 : n - 3;   // frontend_ring.rs:412 (tail - MATCH_UNIT + 1) / frontend_bytes.rs:172
     auto emit = [&](const Candidate &c) { w.match(src + lit, c.idx - lit, c.len, c.idx - c.midx); lit = c.idx + c.len; };
     for (uint32_t i = 0;;) {
         const uint32_t v = load32(src + i);
@@ -101,10 +121,14 @@ void vn_block(std::vector<uint8_t> &o, const uint8_t *src, uint32_t n) {
         for (int k = 0; k < 4; k++) {
             if (i - qp[k] > kVnMaxDist) break;
             uint32_t x = v ^ qv[k], len = 0;
-            if (x == 0) { len = 4; while (len < n - i && src[i + len] == src[qp[k] + len]) len++; }
+            if (x == 0) {
+                if (ring) len = coarse_inc4(src, i, qp[k], n - i);   // frontend_ring.rs:493-501
+                else { len = 4; while (len < n - i && src[i + len] == src[qp[k] + len]) len++; }
+            }
             else if ((x & 0x00FFFFFFu) == 0) len = 3;
             if (len > in.len) { in.len = len; in.midx = qp[k]; }
         }
+        if (ring && in.len > n - i) in.len = n - i;   // frontend_ring.rs:479-481
         bool emitted = false;
         if (in.len) {
             in.idx = i;
@@ -137,19 +161,27 @@ void vn_block(std::vector<uint8_t> &o, const uint8_t *src, uint32_t n) {
     const uint32_t magic = 0x6E787662u, raw = w.n_raw();
     std::memcpy(hdr, &magic, 4); std::memcpy(hdr + 4, &raw, 4); std::memcpy(hdr + 8, &payload, 4);
     std::memcpy(o.data() + mark, hdr, 12);
-    if (size_t(n) + 8 <= o.size() - mark) {  // not smaller than a raw block (frontend_bytes.rs:92-99)
+    if (size_t(n) + 8 <= o.size() - mark) {  // not smaller than a raw block (frontend_bytes.rs:92-99, frontend_ring.rs:323-330)
         o.resize(mark);
-        raw_block(o, src, n);
+        raw_block(o, input, n);
     }
 }
 
 }  // namespace
 
+namespace lzmi {
+int encode_small(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *out_len, bool ring);
+}
+
 extern "C" int lzfse_mi_encode_small(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *out_len) {
+    return lzmi::encode_small(src, n, dst, cap, out_len, false);
+}
+
+int lzmi::encode_small(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *out_len, bool ring) {
     if (!out_len || (!src && n) || n > kVnCutoff) return LZFSE_MI_BAD_ARGUMENT;
     std::vector<uint8_t> o;
     o.reserve(n + n / 4 + 64);
-    if (n > kRawCutoff) vn_block(o, src, uint32_t(n));
+    if (n > kRawCutoff) vn_block(o, src, uint32_t(n), ring);
     else raw_block(o, src, uint32_t(n));
     put32(o, 0x24787662u);
     if (o.size() > cap) return LZFSE_MI_BUFFER_OVERFLOW;

@@ -38,6 +38,7 @@ struct LaneGate {
 LaneGate *ctx_gate_in(lzfse_mi_ctx *c);
 LaneGate *ctx_gate_out(lzfse_mi_ctx *c);
 int ctx_diag_stats(lzfse_mi_ctx *c);  // LZFSE_MI_OPT_DIAG_STATS bits: 1 block encode, 2 parse, 4 LZ decode
+bool ctx_parse_ring(lzfse_mi_ctx *c);  // this call encodes with the ring / stream encoder's parse (lzfse_mi_encode_ring*, lzfse_mi_estream_*)
 int ctx_diag_chain(lzfse_mi_ctx *c);  // LZFSE_MI_OPT_DIAG_CHAIN: 1 = every chain tile through the ballot kernel
 
 // ---- decode.hip ----
@@ -78,5 +79,8 @@ void enc_scratch_release(EncScratch &s);
 int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, const uint64_t *src_off,
                      const uint64_t *src_len, uint8_t *d_dst, const uint64_t *dst_off, const uint64_t *dst_cap,
                      uint64_t *out_lens, int *statuses);
+
+// host_small.cpp: the host-side size classes (<= 4096 bytes); ring = as LzfseRingEncoder::encode / LzfseWriter emit them
+int encode_small(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *out_len, bool ring);
 
 }  // namespace lzmi

@@ -7,8 +7,9 @@
 // first error in stream order is reported with the slice path's code: the windows before it decoded cleanly, and the
 // window that holds it is decoded by the same kernels.
 //
-// (The encode half of the rank -- the ring front ends, frontend_ring.rs -- produces other bytes than the slice encoder
-// and would need a CPU restatement of its own to be checked against; not built.)
+// The encode half of the rank is at the end of this file (lzfse_mi_estream_*): the ring front end's parse
+// (encode/frontend_ring.rs) is done by the device kernels (encode_parse.hip, st_ring_find and the round ends of the
+// stitcher) once the input is complete; this file only collects the pieces and hands the stream out.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -210,6 +211,59 @@ LZFSE_MI_API int lzfse_mi_dstream_feed(lzfse_mi_dstream *s, const uint8_t *src, 
             return s->status = st ? st : LZFSE_MI_PAYLOAD_UNDERFLOW;   // (no bvx$: cannot have decoded cleanly)
         }
     }
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------ streaming encode (LzfseWriter)
+
+struct lzfse_mi_estream {
+    lzfse_mi_ctx *ctx = nullptr;
+    std::vector<uint8_t> in;   // everything written so far (frontend_ring.rs:167-206 copies it into the ring; here it waits for finish)
+    int status = 0;            // sticky
+    bool finished = false;
+};
+
+extern "C" {
+
+int lzfse_mi_estream_create(lzfse_mi_ctx *ctx, lzfse_mi_estream **out) {
+    if (!ctx || !out) return LZFSE_MI_BAD_ARGUMENT;
+    lzfse_mi_estream *s = new (std::nothrow) lzfse_mi_estream();
+    if (!s) return LZFSE_MI_IO;
+    s->ctx = ctx;
+    *out = s;
+    return LZFSE_MI_OK;
+}
+
+void lzfse_mi_estream_destroy(lzfse_mi_estream *s) { delete s; }
+
+// Write::write of LzfseWriter (encode/writer.rs:59-63): takes all of buf
+int lzfse_mi_estream_feed(lzfse_mi_estream *s, const uint8_t *src, size_t n) {
+    if (!s || (!src && n) || s->finished) return LZFSE_MI_BAD_ARGUMENT;
+    if (s->status) return s->status;
+    if (s->in.size() + n > (size_t)0x7FFFFFFFu) return s->status = LZFSE_MI_UNSUPPORTED;   // as the slice path: positions are 31 bits on the device
+    try { s->in.insert(s->in.end(), src, src + n); } catch (...) { return s->status = LZFSE_MI_IO; }
+    return LZFSE_MI_OK;
+}
+
+// LzfseWriter::finalize (encode/writer.rs:50-53) = FrontendRing::flush (frontend_ring.rs:275-295) + the writer's flush
+int lzfse_mi_estream_finish(lzfse_mi_estream *s, lzfse_mi_write_fn write, void *user, uint64_t *bytes_in, uint64_t *bytes_out) {
+    if (!s || !write || s->finished) return LZFSE_MI_BAD_ARGUMENT;
+    s->finished = true;
+    if (s->status) return s->status;
+    const size_t n = s->in.size(), cap = lzfse_mi_encode_bound(n);
+    uint8_t *out = (uint8_t *)std::malloc(cap ? cap : 1);
+    if (!out) return s->status = LZFSE_MI_IO;
+    size_t len = 0;
+    int st = lzfse_mi_encode_ring(s->ctx, s->in.data(), n, out, cap, &len);
+    // the sink takes the stream in pieces, as the reference's 8 KiB output ring does (encode/constants.rs:36-48); larger here
+    for (size_t o = 0; !st && o < len; o += (size_t)1 << 20)
+        if (write(user, out + o, len - o < ((size_t)1 << 20) ? len - o : (size_t)1 << 20)) st = LZFSE_MI_IO;
+    std::free(out);
+    if (bytes_in) *bytes_in = n;
+    if (bytes_out) *bytes_out = st ? 0 : len;
+    std::vector<uint8_t>().swap(s->in);
+    return s->status = st;
 }
 
 }  // extern "C"

@@ -1,0 +1,268 @@
+"""GPU parity tests (ring / stream encode): LzfseRingEncoder::encode, LzfseWriter, LzfseWriterBytes over the HIP path give,
+byte for byte, the streams the reference's ring front end gives (encode/frontend_ring.rs, restated in the oracle's
+"ring frontend" and pinned by the reference's in-file KATs: tests/test_oracle_ring.py) -- another parse than the slice
+encoder's: rounds over a 512 KiB ring, capped and coarse forward lengths, the ring head as the backward limit, literals
+that pass the head pushed in pieces."""
+import io
+
+import numpy as np
+import pytest
+
+import test_kit as tk
+from oracle_py import rng_gen_vec
+from test_oracle import EOS, ZERO_4097, raw_block
+
+pytestmark = pytest.mark.gpu
+
+RING, BLK = 0x80000, 0x4000
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import lzfse_rust_amd as m
+    return m.Context(0)
+
+
+def _ring(ctx, data):
+    outs, st = ctx.encode_batch([data], ring=True)
+    assert st == [0]
+    return outs[0].tobytes()
+
+
+def _text(n, seed=7):
+    rng = np.random.default_rng(seed)
+    words = [bytes(rng.integers(97, 123, size=int(k), dtype=np.uint8)) for k in rng.integers(2, 9, size=500)]
+    out = b" ".join(words[int(i)] for i in rng.integers(0, 500, size=n // 4 + 16))
+    return out[:n]
+
+
+# ---- the reference's byte-exact vectors through the device library: frontend_ring.rs:768-859 ----
+
+def test_ring_kats(ctx):
+    for n in (0, 1, 20):
+        assert _ring(ctx, bytes(n)) == raw_block(bytes(n))
+    assert _ring(ctx, bytes(21)) == bytes([0x62, 0x76, 0x78, 0x6E, 0x15, 0, 0, 0, 0x0C, 0, 0, 0, 0x68, 0x01, 0x00, 0xFC,
+                                            0x06, 0, 0, 0, 0, 0, 0, 0]) + EOS
+    assert _ring(ctx, bytes(4096)) == (bytes([0x62, 0x76, 0x78, 0x6E, 0x00, 0x10, 0, 0, 0x2B, 0, 0, 0, 0x68, 0x01, 0x00])
+                                       + bytes([0xF0, 0xFF]) * 15 + bytes([0xF0, 0x06, 0x06, 0, 0, 0, 0, 0, 0, 0]) + EOS)
+    assert _ring(ctx, bytes(4097)) == ZERO_4097
+    assert _ring(ctx, rng_gen_vec(0, 4096))[:4] == b"bvx-"
+    assert _ring(ctx, rng_gen_vec(0, 4097))[:4] == b"bvx2"
+
+
+# ---- every Snappy file: bytes == ring oracle ----
+
+def test_ring_snappy_files_match_the_oracle(ctx, oracle, snappy_raw):
+    names = sorted(snappy_raw)
+    outs, st = ctx.encode_batch([snappy_raw[k] for k in names], ring=True)
+    assert st == [0] * len(names)
+    for k, o in zip(names, outs):
+        assert o.tobytes() == oracle.ring_encode(snappy_raw[k]), k
+
+
+def _cases():
+    text = _text(2_400_000)
+    yield "text_2_4M", text
+    yield "text_ring_exact", text[:RING]
+    yield "text_ring_minus_1", text[:RING - 1]
+    yield "text_ring_plus_1", text[:RING + 1]
+    yield "text_ring_plus_blk", text[:RING + BLK]
+    yield "text_ring_plus_blk_minus_1", text[:RING + BLK - 1]
+    yield "noise_1_2M", tk.seq(1_200_000, seed=3)                       # a literal desert: push_literal_overflow every round
+    yield "low_entropy_1M", tk.seq(1_000_000, seed=5, mask=0x01010101)   # many candidates that run to the end of the input
+    yield "low_entropy_bits", tk.seq(700_000, seed=6, mask=0x00010001)
+    yield "zeros_1_5M", bytes(1_500_000)                                 # LONG_MATCH_LEN caps every round's match
+    yield "zeros_then_text", bytes(700_000) + text[:300_000] + bytes(400_000)
+    yield "noise_sandwich", text[:40_000] + tk.seq(900_000, seed=9) + text[:40_000]
+    per = bytes(np.random.default_rng(2).integers(0, 256, size=300_000, dtype=np.uint8))
+    yield "period_300k", per * 4                                         # matches longer than LONG_MATCH_LEN at distance 300 000? no: beyond the window
+    per2 = bytes(np.random.default_rng(3).integers(0, 256, size=250_000, dtype=np.uint8))
+    yield "period_250k", per2 * 5                                        # distance 250 000 < 262 139: every round's match hits the cap
+    yield "far_match_long_literals", _far_match_case()
+
+
+def _far_match_case():
+    """A match at nearly the maximum distance behind a long run of literals: its backward extension stops at the ring
+    head (frontend_ring.rs:482), not at the start of the input."""
+    rng = np.random.default_rng(17)
+    a = bytes(rng.integers(0, 256, size=20_000, dtype=np.uint8))
+    pad1 = tk.seq(560_000, seed=21)
+    pad2 = tk.seq(262_000 - 20_000, seed=22)
+    return pad1 + a + pad2 + a + tk.seq(300_000, seed=23)
+
+
+@pytest.mark.parametrize("name,data", list(_cases()), ids=[n for n, _ in _cases()])
+def test_ring_cases_match_the_oracle(ctx, oracle, name, data):
+    got = _ring(ctx, data)
+    exp = oracle.ring_encode(data)
+    assert got == exp
+    assert oracle.decode(got) == data
+
+
+def test_ring_every_small_size_class(ctx, oracle):
+    """The host-side size classes as the ring front end cuts them (flush_select, frontend_ring.rs:297-342): Vn's
+    match_short visits one more position than the slice loop and compares past the end of the input."""
+    rng = np.random.default_rng(23)
+    datas = []
+    for n in list(range(0, 300)) + list(range(300, 4097, 61)) + [4095, 4096]:
+        k = int(rng.choice([2, 4, 16, 256]))
+        datas.append(bytes(rng.integers(0, k, size=n, dtype=np.uint8)))
+    outs, st = ctx.encode_batch(datas, ring=True)
+    assert not any(st)
+    n_other = 0
+    for d, o in zip(datas, outs):
+        exp = oracle.ring_encode(d)
+        assert o.tobytes() == exp, len(d)
+        n_other += exp != oracle.encode(d)
+    assert n_other > 10
+
+
+def test_ring_low_entropy_sweep(ctx, oracle):
+    """Sizes around 4097 .. 300 000 over tiny alphabets: where the ring's candidate choice differs from the slice parse
+    (candidates that run to the end of the input are measured past it)."""
+    rng = np.random.default_rng(29)
+    datas = []
+    for _ in range(160):
+        n = int(rng.integers(4097, 300_000))
+        k = int(rng.choice([2, 3, 4, 16]))
+        datas.append(bytes(rng.integers(0, k, size=n, dtype=np.uint8)))
+    outs, st = ctx.encode_batch(datas, ring=True)
+    assert not any(st)
+    n_other = 0
+    for d, o in zip(datas, outs):
+        exp = oracle.ring_encode(d)
+        assert o.tobytes() == exp, len(d)
+        n_other += exp != oracle.encode(d)
+    assert n_other >= 1
+
+
+def test_ring_reference_patterns(ctx, oracle):
+    """The generators of the reference's integration suite (test/src/pattern_*.rs, patchwork_*.rs, random_*.rs run
+    `encode_writer_bytes` too: test/src/ops.rs:73-84), a sample of each, against the ring oracle."""
+    datas = [tk.patchwork(seed, 0x40, 20) for seed in range(0, 24, 3)]
+    datas += [tk.patchwork(seed, 0x200, 24) for seed in range(4)]
+    datas += [tk.seq(n, seed=n) for n in (5000, 70_000, 600_000)]
+    datas += [tk.seq(n, seed=n, mask=0x03030303) for n in (5000, 70_000, 600_000)]
+    datas += [tk.cycle(n) for n in (4097, 100_000, RING + 5)]
+    datas += [tk.useq(200_000)]
+    datas += [tk.build_match_inc(9000, 5000, 4990, 3000), tk.build_match_dec(9000, 5000, 4990, 3000)]
+    outs, st = ctx.encode_batch(datas, ring=True)
+    assert not any(st)
+    for i, (d, o) in enumerate(zip(datas, outs)):
+        assert o.tobytes() == oracle.ring_encode(d), i
+
+
+# ---- LzfseWriter / LzfseRingEncoder::encode: any piece sizes, test/src/fuzz_write.rs:8-33 ----
+
+def test_fuzz_write(ctx, oracle):
+    """fuzz_write.rs: 2 MiB of Seq written in random-length pieces ((gen % 0x20) * multiplier) must give the stream of
+    one encode() call -- and here that stream is the ring oracle's. Multipliers 0x100 / 0x1000 / 0x10000 over a few seeds
+    (1 and 0x10 are two million ctypes calls a seed; the piece size never reaches the device: feed only stores)."""
+    import lzfse_rust_amd as m
+    data = tk.seq(0x0020_0000)
+    enc = m.LzfseRingEncoder(context=ctx)
+    base = io.BytesIO()
+    u, v = enc.encode(io.BytesIO(data), base)
+    assert (u, v) == (len(data), len(base.getvalue()))
+    assert base.getvalue() == oracle.ring_encode(data)
+    for mult, seeds in ((0x100, 2), (0x1000, 3), (0x10000, 4)):
+        for seed in range(seeds):
+            out = bytearray()
+            w = enc.writer_bytes(out)
+            rng = tk.Rng(seed)
+            pos = 0
+            while pos < len(data):
+                n = min((rng.gen() % 0x20) * mult, len(data) - pos)
+                w.write(data[pos:pos + n])
+                pos += n
+            assert w.finalize() is out
+            assert bytes(out) == base.getvalue(), (mult, seed)
+
+
+def test_writer_small_pieces_and_sink_errors(ctx, oracle):
+    import lzfse_rust_amd as m
+    data = _text(70_000, seed=3)
+    enc = m.LzfseRingEncoder(context=ctx)
+    out = io.BytesIO()
+    w = enc.writer(out)
+    for i in range(0, len(data), 7):
+        assert w.write(data[i:i + 7]) == len(data[i:i + 7])
+    w.flush()
+    assert w.finalize() is out
+    assert out.getvalue() == oracle.ring_encode(data)
+    # an empty stream
+    out = bytearray(b"head")
+    assert enc.writer_bytes(out).finalize() == bytearray(b"head") + raw_block(b"")
+    # the sink's failure comes back as the sink's exception (io::Error of the inner writer, ring_short_writer.rs)
+
+    class Bad:
+        def write(self, b):
+            raise OSError("disk full")
+
+    w = enc.writer(Bad())
+    w.write(data)
+    with pytest.raises(OSError):
+        w.finalize()
+    # ... and the encoder object is still good
+    dst = bytearray()
+    assert enc.encode_bytes(data, dst) == len(dst) and bytes(dst) == oracle.encode(data)
+
+
+class _Hip:
+    """hipMalloc / hipMemcpy of the runtime the library itself is linked against (torch ships another copy of it)."""
+
+    def __init__(self):
+        import ctypes as C
+        self.C = C
+        self.rt = C.CDLL("libamdhip64.so")
+        self.rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.rt.hipFree.argtypes = [C.c_void_p]
+
+    def alloc(self, n):
+        p = self.C.c_void_p()
+        assert self.rt.hipMalloc(self.C.byref(p), n) == 0
+        return p.value
+
+    def upload(self, arr):
+        p = self.alloc(arr.size)
+        assert self.rt.hipMemcpy(p, arr.ctypes.data, arr.size, 1) == 0
+        return p
+
+    def download(self, p, n):
+        out = np.empty(n, dtype=np.uint8)
+        assert self.rt.hipMemcpy(out.ctypes.data, p, n, 2) == 0
+        return out
+
+    def free(self, p):
+        self.rt.hipFree(p)
+
+
+def test_ring_batch_device_resident(ctx, oracle, snappy_raw):
+    """The device-resident form (what the bench times), ring and slice parses side by side on the same inputs."""
+    hip = _Hip()
+    names = sorted(snappy_raw)[:6]
+    raws = [snappy_raw[k] for k in names] + [_text(1_300_000, seed=5)]
+    offs, pos = [], 0
+    for r in raws:
+        offs.append(pos)
+        pos += (len(r) + 255) & ~255
+    src = np.zeros(pos, dtype=np.uint8)
+    for o, r in zip(offs, raws):
+        src[o:o + len(r)] = np.frombuffer(r, dtype=np.uint8)
+    d_src = hip.upload(src)
+    caps = [ctx._lib.lzfse_mi_encode_bound(len(r)) for r in raws]
+    doffs = np.concatenate([[0], np.cumsum([(c + 255) & ~255 for c in caps])[:-1]]).astype(np.uint64)
+    total = int(doffs[-1]) + caps[-1] + 256
+    d_dst = hip.alloc(total)
+    try:
+        for ring in (True, False, True):
+            ol, st = ctx.encode_batch_device(d_src, offs, [len(r) for r in raws], d_dst, doffs, caps, ring=ring)
+            assert not st.any()
+            host = hip.download(d_dst, total)
+            for i, r in enumerate(raws):
+                got = host[int(doffs[i]):int(doffs[i]) + int(ol[i])].tobytes()
+                assert got == (oracle.ring_encode(r) if ring else oracle.encode(r)), (ring, i)
+    finally:
+        hip.free(d_src)
+        hip.free(d_dst)
