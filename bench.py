@@ -135,6 +135,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--replicas", type=int, default=256, help="copies of the 12-file corpus per GPU (256: 3072 streams, 752 MB)")
     ap.add_argument("--workload", default="snappy", choices=["snappy", "text64m", "chunks4m", "chunks1g"])
+    ap.add_argument("--emulate-world", type=int, default=0, metavar="N",
+                    help="chunks1g only: run rank 0's shard of an N-way split on ONE GPU (what one rank of an N-GPU strong-scaling run does)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the exclusive pass, PCIe-inclusive and copy-peak measurements")
     ap.add_argument("--lanes", type=int, default=0, help="sub-batches run side by side per call (0: library default, 1: unsplit)")
@@ -198,10 +200,13 @@ def main():
         scaling = "strong"
         data = corpus_1g(seed=1)
         bounds = sharding.chunk_bounds(data.size, sharding.CHUNK_BYTES)
-        mine = sharding.shard(len(bounds), rank, world)
+        emu = args.emulate_world if (args.emulate_world > 1 and world == 1) else 0
+        mine = sharding.shard(len(bounds), rank, emu or world)
         batch_raw = [data[o:o + n].tobytes() for o, n in (bounds[c] for c in mine)]
         workload = (f"ONE 1 GiB input (16 perturbed copies of 64 MiB synthetic text) cut into {len(bounds)} independent 4 MiB "
-                    f"streams, chunk c -> rank c mod {world}, encode+decode")
+                    f"streams, chunk c -> rank c mod {emu or world}, encode+decode")
+        if emu:
+            workload += f"; EMULATED: only rank 0's shard of a {emu}-way split ({len(mine)} streams) on one GPU"
         # untimed: the sharded result equals what ONE encoder makes of the same chunks (per-chunk SHA-256)
         report = sharding.process_shard(data, sharding.CHUNK_BYTES, rank, world, GpuCodec(ctx))
         reports = sharding.gather_reports(report, world, dist)
@@ -298,12 +303,16 @@ def main():
         alg_bytes = int((comp_total + raw_total) * args.steps / max(kern_n[dom], 1))
         achieved = alg_bytes / (dom_avg_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": pmc_traffic(dom, args),
+                "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_avg_ms, 4),
                 "direction": "decode" if is_dec else "encode",
                 # the launches of one step overlap on the device (sub-batches side by side): a per-launch duration under
                 # co-scheduling is not an exclusive kernel time; see exclusive_* below for one unsplit pass
                 "launches_per_step": round(kern_n[dom] / args.steps, 2)}
+        roof["traffic"], enc_traffic = pmc_traffic(dom, args, comp_total + raw_total)
+        roof["traffic_is"] = "2 x FETCH_SIZE + WRITE_SIZE per launch (gfx950 read-counter correction of MI355X_MICROARCH.md applied)"
+        if enc_traffic:
+            roof["encoder_traffic"] = enc_traffic
         out = {
             "metric": "encode+decode MB/s on Snappy corpus",
             "value": round(value, 2),
@@ -333,9 +342,15 @@ def main():
             out["exclusive_kernel_ms"] = {k: round(v[0], 4) for k, v in sorted(kx.items())}
             out["copy_peak"] = copy_peak(torch, dev)
             out["pcie_inclusive"] = pcie_inclusive(ctx, lz, batch_raw)
+            if args.workload == "snappy":
+                ctx.enable_timing(False)
+                out["html"] = html_rows(ctx, torch, dev, lz, raws[names.index("html")])
         if not args.no_cpu_baseline:
             sample = batch_raw[:12] if args.workload == "snappy" else [batch_raw[0][:8 << 20]]
             out["cpu_baseline"] = cpu_baseline(sample)
+        # the pipelined LZ stage of decode was never given up (a context that does so silently decodes 2-3 x slower)
+        out["pipe_refusals"] = ctx.pipe_refusals()
+        assert out["pipe_refusals"] == 0, "the pipelined LZ kernel was switched off on this device"
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -380,23 +395,41 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(dom, args):
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+
+
+def pmc_traffic(dom, args, b_enc=None):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE runs of this same default command, profiles/r02_pmc_traffic.json). Only reported when that file was taken
-    on exactly the kernel sources of this build (source_sha) and for the default workload; otherwise null."""
+    WRITE_SIZE runs of this same default command, profiles/r03_pmc_traffic.json), CORRECTED as MI355X_MICROARCH.md's HBM
+    section prescribes for gfx950: 2 x FETCH_SIZE + WRITE_SIZE (the read counter tallies 128-byte requests at 64 bytes;
+    checked on this build's own mandatory coalesced reads). Only reported when that file was taken
+    on exactly the kernel sources of this build (source_sha) and for the default workload; otherwise null. Returns
+    (bytes per launch of `dom`, {whole-encoder figures}) ."""
     try:
         if args.workload != "snappy" or args.replicas != 256 or args.lanes:
-            return None
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+            return None, None
+        pm = json.load(open(PMC_FILE))
         if pm.get("source_sha") != kernel_source_sha():
-            return None
-        key = [k for k in pm["kernels"] if k.startswith(dom + "_kernel")]
-        if not key:
-            return None
-        return int(sum(pm["kernels"][k]["hbm_bytes_raw"] * pm["kernels"][k]["launches"] for k in key) /
-                   sum(pm["kernels"][k]["launches"] for k in key))
+            return None, None
+        ks = pm["kernels"]
+
+        def per_launch(prefix):
+            key = [k for k in ks if k.startswith(prefix + "_kernel")]
+            if not key:
+                return None
+            return int(sum((2 * ks[k]["fetch_bytes_raw"] + ks[k]["write_bytes"]) * ks[k]["launches"] for k in key) /
+                       sum(ks[k]["launches"] for k in key))
+        enc = None
+        if b_enc:
+            # every encode kernel, bytes per STEP (launches per step come from the file's own launch counts: the profiled
+            # command makes pm["steps"] encode calls)
+            steps = pm.get("encode_calls", 0)
+            if steps:
+                tot = sum((2 * v["fetch_bytes_raw"] + v["write_bytes"]) * v["launches"] for k, v in ks.items() if k.startswith("enc_")) / steps
+                enc = {"hbm_bytes_per_step": int(tot), "over_algorithmic": round(tot / b_enc, 2)}
+        return per_launch(dom), enc
     except Exception:
-        return None
+        return None, None
 
 
 def copy_peak(torch, dev):
@@ -450,46 +483,47 @@ def pcie_inclusive(ctx, lz, batch_raw):
 
 def cpu_baseline(sample):
     """The oracle (C restatement of lzfse_rust's CPU path; the reference itself cannot be built: no Rust toolchain)
-    timed on this box's host cores: one thread (comparable with the reference README's `rust` column), then one
+    timed on this box's host cores by oracle/lzo_bench.c: pthreads that loop over their own streams for the whole
+    budget, no interpreter in the loop -- one thread (comparable with the reference README's `rust` column), then one
     thread per core over independent streams. About 20 s in all."""
-    from concurrent.futures import ThreadPoolExecutor
+    import ctypes as C
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_py import Oracle
     o = Oracle("liblzfse_oracle_native.so")
-    encs = [o.encode(r) for r in sample]
+    encs = [o.encode(r) for r in sample]   # (also initialises the oracle's tables before any thread runs)
     nbytes = sum(len(r) for r in sample)
+    n = len(sample)
+    ra = [np.frombuffer(r, dtype=np.uint8) for r in sample]
+    ea = [np.frombuffer(e, dtype=np.uint8) for e in encs]
+    rp = (C.c_void_p * n)(*[a.ctypes.data for a in ra])
+    rl = (C.c_size_t * n)(*[a.size for a in ra])
+    ep = (C.c_void_p * n)(*[a.ctypes.data for a in ea])
+    el = (C.c_size_t * n)(*[a.size for a in ea])
+    fn = o.lib.lzo_bench_threads
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_int,
+                   C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
 
     def run(threads, budget):
-        work = list(zip(sample, encs))
-        if threads > 1:
-            work = work * (threads // max(len(sample), 1) + 1)
-        wbytes = sum(len(r) for r, _ in work)
-        pool = ThreadPoolExecutor(threads) if threads > 1 else None
-        mp = pool.map if pool else map
-        t0 = time.perf_counter()
-        n = 0
-        te = td = 0.0
-        while time.perf_counter() - t0 < budget:
-            a = time.perf_counter()
-            list(mp(lambda w: o.encode(w[0]), work))          # ctypes releases the GIL inside the C call
-            b = time.perf_counter()
-            list(mp(lambda w: o.decode(w[1], cap=len(w[0]), as_array=True), work))
-            c = time.perf_counter()
-            te += b - a
-            td += c - b
-            n += 1
-        if pool:
-            pool.shutdown()
-        return wbytes * n / (te + td) / 1e6, wbytes * n / te / 1e6, wbytes * n / td / 1e6, n
+        rates = []
+        for decode in (0, 1):
+            mbps, tot = C.c_double(0), C.c_uint64(0)
+            st = fn(rp, rl, ep, el, n, threads, budget, decode, C.byref(mbps), C.byref(tot))
+            assert st == 0, st
+            rates.append(mbps.value)
+        e, d = rates
+        return 1.0 / (1.0 / e + 1.0 / d), e, d     # encode + decode of the same bytes, one after the other
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    v1, e1, d1, n1 = run(1, 8.0)
-    vn, en, dn, nn = run(cores, 10.0) if cores > 1 else (v1, e1, d1, n1)
+    v1, e1, d1 = run(1, 4.0)
+    vn, en, dn = run(cores, 5.0) if cores > 1 else (v1, e1, d1)
     return {"value": round(vn, 2), "unit": "MB/s", "cores": cores, "kind": "port",
             "encode_MBps": round(en, 2), "decode_MBps": round(dn, 2),
             "single_thread": {"value": round(v1, 2), "encode_MBps": round(e1, 2), "decode_MBps": round(d1, 2)},
-            "sample": f"{len(sample)} stream(s), {nbytes} raw bytes, encode+decode repeated for ~8 s on 1 thread and ~10 s on "
-                      f"{cores} threads (independent streams per thread); gcc -O3 -march=native C restatement of "
-                      "lzfse_rust's slice path (oracle/)"}
+            "threads_over_single": {"encode": round(en / e1, 1), "decode": round(dn / d1, 1)},
+            "sample": f"{n} stream(s), {nbytes} raw bytes; per direction ~4 s on 1 thread and ~5 s on {cores} pthreads, every "
+                      "thread looping over its own streams for the whole budget (oracle/lzo_bench.c, no Python in the "
+                      "loop); value = 1 / (1/encode + 1/decode); gcc -O3 -march=native C restatement of lzfse_rust's slice "
+                      "path (oracle/)"}
 
 
 # README.md:155-176 of the reference: Criterion, i5-2500K, single thread, MiB/s of raw bytes, column `rust` (decode, encode)
@@ -498,6 +532,42 @@ README_I5_2500K = {
     "html_x_4": (3174.4, 457.2), "alice29.txt": (344.7, 55.1), "asyoulik.txt": (319.7, 51.2), "lcet10.txt": (371.0, 58.5),
     "plrabn12.txt": (304.0, 49.7), "geo.protodata": (1254.1, 140.9), "kppkn.gtb": (425.4, 74.8),
 }
+
+
+def file_rates(ctx, torch, dev, lz, raw, R, samples=5):
+    """One file alone as a batch of R independent copies resident in HBM: wall time of the encode and of the decode call,
+    2 warm-up + `samples` samples (the protocol of per_file_table). Returns (B, enc_len, te[], td[])."""
+    B = DeviceBatch(torch, dev, lz, [raw] * R)
+    enc_len, est = ctx.encode_batch_device(B.d_raw.data_ptr(), B.raw_off, B.raw_len, B.d_enc.data_ptr(), B.enc_off, B.enc_cap)
+    assert (est == 0).all()
+    te, td = [], []
+    for _ in range(samples + 2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.encode_batch_device(B.d_raw.data_ptr(), B.raw_off, B.raw_len, B.d_enc.data_ptr(), B.enc_off, B.enc_cap)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        _, dst_ = ctx.decode_batch_device(B.d_enc.data_ptr(), B.enc_off, enc_len, B.d_dec.data_ptr(), B.raw_off, B.raw_len)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        assert (dst_ == 0).all()
+        te.append(t1 - t0)
+        td.append(t2 - t1)
+    assert torch.equal(B.d_dec[:B.raw_padded], B.d_raw[:B.raw_padded])
+    return B, enc_len, np.array(te[2:]), np.array(td[2:])
+
+
+def html_rows(ctx, torch, dev, lz, raw):
+    """The file the north-star target is phrased on (README.md:155,166 of the reference, bench/src/bench.rs:181-193), by
+    itself: R = 256 and R = 16 copies per call, so that a driver record carries it."""
+    rows = {}
+    for R in (256, 16):
+        _, enc_len, te, td = file_rates(ctx, torch, dev, lz, raw, R)
+        rows[f"x{R}"] = {"encode_GBps": round(len(raw) * R / te.mean() / 1e9, 2), "decode_GBps": round(len(raw) * R / td.mean() / 1e9, 2),
+                         "encode_sd_pct": round(100 * te.std() / te.mean(), 1), "decode_sd_pct": round(100 * td.std() / td.mean(), 1)}
+    rows["what"] = (f"data/snappy/html ({len(raw)} B) alone as a batch of R independent copies resident in HBM, wall time of the "
+                    "batch call, 2 warm-up + 5 samples")
+    return rows
 
 
 def per_file_table(ctx, torch, dev, names, fixture_streams, R):
@@ -512,27 +582,10 @@ def per_file_table(ctx, torch, dev, names, fixture_streams, R):
     rows = []
     for name, r in zip(names, raws_np):
         raw = r.tobytes()
-        B = DeviceBatch(torch, dev, lz, [raw] * R)
-        enc_len, est = ctx.encode_batch_device(B.d_raw.data_ptr(), B.raw_off, B.raw_len, B.d_enc.data_ptr(), B.enc_off, B.enc_cap)
-        assert (est == 0).all()
+        B, enc_len, te, td = file_rates(ctx, torch, dev, lz, raw, R)
         want = o.encode(raw)
         got = B.d_enc[int(B.enc_off[0]):int(B.enc_off[0]) + int(enc_len[0])].cpu().numpy().tobytes()
         assert got == want, name   # bit-exact vs the CPU port
-        te, td = [], []
-        for _ in range(7):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            ctx.encode_batch_device(B.d_raw.data_ptr(), B.raw_off, B.raw_len, B.d_enc.data_ptr(), B.enc_off, B.enc_cap)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            _, dst_ = ctx.decode_batch_device(B.d_enc.data_ptr(), B.enc_off, enc_len, B.d_dec.data_ptr(), B.raw_off, B.raw_len)
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            assert (dst_ == 0).all()
-            te.append(t1 - t0)
-            td.append(t2 - t1)
-        assert torch.equal(B.d_dec[:B.raw_padded], B.d_raw[:B.raw_padded]), name
-        te, td = np.array(te[2:]), np.array(td[2:])   # two warm-up samples dropped
         # CPU port, one thread, ~0.5 s per direction
         t0 = time.perf_counter()
         k = 0

@@ -100,6 +100,13 @@ enum {
 };
 LZFSE_MI_API int lzfse_mi_set_option(lzfse_mi_ctx *ctx, int option, int64_t value);
 
+/* Read-only facts about a context. LZFSE_MI_INFO_PIPE_REFUSALS: how often the pipelined LZ stage of decode (several
+ * workgroups per stream handing output over through one XCD's L2) was given up on this context and its helpers -- its
+ * start-up self-test failed, or a launch found a stream's workgroups on different XCDs -- after which the context decodes
+ * such batches with one workgroup per stream (correct, slower). 0 on the hardware this was written on. */
+enum { LZFSE_MI_INFO_PIPE_REFUSALS = 1 };
+LZFSE_MI_API int lzfse_mi_get_info(lzfse_mi_ctx *ctx, int what, int64_t *value);
+
 /* Upper bound of the encoded size of an n-byte input (fse/constants.rs:54-69: every full
  * bvx2 block carries >= 39 996 raw bytes and costs <= 54 bits per LMD + 10 bits per literal). */
 LZFSE_MI_API size_t lzfse_mi_encode_bound(size_t n);

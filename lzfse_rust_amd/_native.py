@@ -26,7 +26,7 @@ _SYMBOLS = [
     "lzfse_mi_decode_chunked_size", "lzfse_mi_decode_chunked", "lzfse_mi_dstream_create", "lzfse_mi_dstream_feed",
     "lzfse_mi_dstream_totals", "lzfse_mi_dstream_destroy", "lzfse_mi_decode_headroom",
     "lzfse_mi_encode_ring", "lzfse_mi_encode_ring_batch", "lzfse_mi_encode_ring_batch_device",
-    "lzfse_mi_estream_create", "lzfse_mi_estream_feed", "lzfse_mi_estream_finish", "lzfse_mi_estream_destroy",
+    "lzfse_mi_get_info", "lzfse_mi_estream_create", "lzfse_mi_estream_feed", "lzfse_mi_estream_finish", "lzfse_mi_estream_destroy",
 ]
 
 
@@ -109,6 +109,8 @@ def _load(path):
     L.lzfse_mi_estream_finish.argtypes = [vp, WRITE_FN, vp, u64p, u64p]
     L.lzfse_mi_estream_destroy.restype = None
     L.lzfse_mi_estream_destroy.argtypes = [vp]
+    L.lzfse_mi_get_info.restype = C.c_int
+    L.lzfse_mi_get_info.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
     L.lzfse_mi_set_option.restype = C.c_int
     L.lzfse_mi_set_option.argtypes = [vp, C.c_int, C.c_int64]
     return L

@@ -64,6 +64,12 @@ class Context:
         """lzfse_mi_set_option; the diag_* options need Context(diag=True)."""
         _check(self._lib.lzfse_mi_set_option(self._h, self.OPTIONS[name], int(value)))
 
+    def pipe_refusals(self):
+        """lzfse_mi_get_info(LZFSE_MI_INFO_PIPE_REFUSALS): times the pipelined LZ stage of decode was given up (0 = in use)."""
+        v = C.c_int64(0)
+        _check(self._lib.lzfse_mi_get_info(self._h, 1, C.byref(v)))
+        return v.value
+
     # -- stream / timing plumbing --
     def set_stream(self, hip_stream_ptr):
         _check(self._lib.lzfse_mi_set_stream(self._h, C.c_void_p(hip_stream_ptr)))

@@ -141,6 +141,8 @@ struct lzfse_mi_ctx {
     int opt_stagger = 0;
     int opt_pipe = 0;      // LZFSE_MI_OPT_DECODE_PIPE
     bool pipe_broken = false;   // a launch found the workgroups of one stream on different XCDs: never again on this context
+    bool pipe_tested = false;   // the hand-over self-test (dec_lzp_selftest_kernel) has run on this context
+    uint32_t pipe_refusals = 0; // times the pipelined LZ kernel was given up (self-test failed / a launch refused): lzfse_mi_get_info
     int lane_share = 1;    // sub-batches running side by side with this one (split_batch)
     bool parse_ring = false;   // set for the duration of a ring / stream encode call (lzfse_mi_encode_ring*, lzfse_mi_estream_*)
     int diag_lz_jump = -1, diag_lz_variant = -1, diag_stats = 0, diag_chain = 0, diag_walk = 0, diag_pipe_scatter = 0;  // diagnostic build only
@@ -393,7 +395,9 @@ int lzfse_mi_decode_size(const uint8_t *src, size_t n, uint64_t *raw_len) {
             break;
         }
         pos += (size_t)skip;
-        total += n_raw;
+        // (a sound bvxn block never yields more than 136 bytes per payload byte: a header that promises more -- 4 GiB over a
+        // few bytes -- fails in the LZVN decoder with the reference's code, and must not size anybody's buffers meanwhile)
+        total += magic == MAGIC_VXN ? std::min<uint64_t>(n_raw, 136ull * (skip - 12)) : n_raw;
     }
     *raw_len = total;
     return rc;
@@ -503,6 +507,19 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
     std::vector<uint32_t> mlist;
     int pipe_variant = 1;
     uint32_t pipe_k = 0;
+    if (c->opt_pipe != 1 && !c->pipe_broken && !c->pipe_tested) {
+        // before the pipelined LZ kernel is used for the first time on this context: its hand-over, on this device
+        c->pipe_tested = true;
+        if (c->d_lzp.ensure((1088 + 2) * 4)) {
+            uint32_t *tb = (uint32_t *)c->d_lzp.p, res[2] = {1, 0};
+            if (hipMemsetAsync(tb, 0, (1088 + 2) * 4, c->stream) == hipSuccess) {
+                launch_dec_lzp_selftest(tb, tb + 1088, c->stream);
+                if (hipMemcpyAsync(res, tb + 1088, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) res[0] = 1;
+            }
+            const bool same_xcd = (res[1] & 0xFF) == ((res[1] >> 8) & 0xFF);
+            if (res[0] != 0 || (res[1] & 0x10000u) || !same_xcd) { c->pipe_broken = true; c->pipe_refusals++; }
+        }
+    }
     if (c->opt_pipe != 1 && !c->pipe_broken) {
         const bool forced = c->opt_pipe > 1;
         size_t n_tile = 0;   // streams of the tile kernel: one workgroup each fills the chip when they are many
@@ -603,6 +620,7 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
         for (uint32_t i : mlist) again |= h_state[(size_t)LZP_STATE_WORDS * i + LZP_BAD] != 0;   // the word a misplaced workgroup sets
         if (again) {
             c->pipe_broken = true;
+            c->pipe_refusals++;
             for (uint32_t i : mlist) h_plan[i].pipe = 0;
             HIP_TRY(hipMemcpyAsync(c->d_plan.p, h_plan.data(), ns * sizeof(StreamPlan), hipMemcpyHostToDevice, st));
             {
@@ -848,6 +866,24 @@ int lzfse_mi_encode_batch_device(lzfse_mi_ctx *c, size_t count, const void *d_sr
     }
     return split_batch(c, encode_batch_device_one, lanes, c->opt_stagger != 0, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap,
                        out_lens, statuses);
+}
+
+int lzfse_mi_get_info(lzfse_mi_ctx *c, int what, int64_t *value) {
+    if (!c || !value) return LZFSE_MI_BAD_ARGUMENT;
+    switch (what) {
+    case LZFSE_MI_INFO_PIPE_REFUSALS: {
+        // this context, the helper contexts of its split calls and of its large host calls
+        int64_t n = c->pipe_refusals;
+        for (lzfse_mi_ctx *sh : c->shadow) if (sh) n += sh->pipe_refusals;
+        if (c->host_peer) {
+            n += c->host_peer->pipe_refusals;
+            for (lzfse_mi_ctx *sh : c->host_peer->shadow) if (sh) n += sh->pipe_refusals;
+        }
+        *value = n;
+        return LZFSE_MI_OK;
+    }
+    default: return LZFSE_MI_BAD_ARGUMENT;
+    }
 }
 
 int lzfse_mi_set_option(lzfse_mi_ctx *c, int option, int64_t value) {

@@ -138,8 +138,8 @@ __global__ void dec_walk_kernel(const uint8_t *__restrict__ src, const StreamIn 
         w.n_blocks++;
         w.n_lmds += d.n_lmd; lmd_i += d.n_lmd;
         w.n_lits += d.n_lit; lit_i += d.n_lit;
-        // (a cut bvxn block produces at most 136 bytes per payload byte present; its header's count is not to be trusted)
-        w.raw_total += (truncated && d.kind == KIND_VXN && 136ull * avail < d.n_raw) ? 136ull * avail : d.n_raw;
+        // (bvxn: at most 136 output bytes per payload byte -- of what is there, when the block is cut; lzfse_mi_decode_size)
+        w.raw_total += d.kind == KIND_VXN ? min((uint64_t)d.n_raw, 136ull * (truncated ? avail : (uint64_t)d.payload)) : (uint64_t)d.n_raw;
         if (truncated) { w.status = LZFSE_MI_PAYLOAD_UNDERFLOW; w.err_block = w.n_blocks; break; }
         pos += skip;
     }
@@ -1211,6 +1211,59 @@ __device__ __forceinline__ uint32_t xcc_id() {
     return x & 15u;
 }
 
+
+// Self-test of the hand-over dec_lzp_kernel relies on (run once per context before its first use): two workgroups that
+// the round-robin placement puts on ONE XCD pass a 1 KiB tile back and forth exactly as the pipelined kernel does --
+// producer: plain payload stores, s_waitcnt 0, workgroup barrier, plain flag store; consumer: poll the flag and read the
+// payload with sc0 sc1 loads (ld_u32_l2) after having pulled the OLD lines into its L1 with plain loads. The form is
+// measured, not architectural (MI355X_MICROARCH.md's hand-over table asks for sc1 stores or an agent-scope release on
+// the producer): a single stale word, a flag that never arrives or two different XCC ids switch the pipelined kernel off
+// for the context. out[0] = stale words, out[1] = XCC id of A | XCC id of B << 8 | 0x10000 when a wait timed out.
+__global__ __launch_bounds__(256) void dec_lzp_selftest_kernel(uint32_t *buf, uint32_t *out, uint32_t rounds) {
+    const bool is_a = blockIdx.x == 0, is_b = blockIdx.x == 8;   // (workgroup b runs on XCC b mod 8)
+    if (!is_a && !is_b) return;
+    uint32_t *tile = buf, *flag_a = buf + 1024, *flag_b = buf + 1056;   // separate 128-byte lines
+    const uint32_t tid = threadIdx.x;
+    __shared__ uint32_t sh_ok;
+    if (tid == 0) { sh_ok = 1; atomicOr(&out[1], is_a ? xcc_id() : (xcc_id() << 8)); }
+    uint32_t bad = 0;
+    for (uint32_t r = 1; r <= rounds; r++) {
+        if (is_a) {
+            // the consumer: old tile into L1 first, then wait for the producer's flag, then read past the L1
+            const uint32_t old = tile[tid];
+            if (old == 0xFFFFFFFFu) bad += 1u << 16;   // (keeps the load)
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_store(flag_a, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                uint32_t spins = 0;
+                while (ld_u32_l2(flag_b) != r && ++spins < (1u << 20)) __builtin_amdgcn_s_sleep(1);
+                if (spins >= (1u << 20)) sh_ok = 0;
+            }
+            __syncthreads();
+            if (!sh_ok) break;
+            if (ld_u32_l2(tile + tid) != (r << 8 | (tid & 255))) bad++;
+        } else {
+            if (tid == 0) {
+                uint32_t spins = 0;
+                while (ld_u32_l2(flag_a) != r && ++spins < (1u << 20)) __builtin_amdgcn_s_sleep(1);
+                if (spins >= (1u << 20)) sh_ok = 0;
+            }
+            __syncthreads();
+            if (!sh_ok) break;
+            tile[tid] = r << 8 | (tid & 255);
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(flag_b, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    if (bad) atomicAdd(&out[0], bad);
+    if (tid == 0 && !sh_ok) atomicOr(&out[1], 0x10000u);
+}
+
+void launch_dec_lzp_selftest(uint32_t *buf, uint32_t *out, hipStream_t st) {
+    hipLaunchKernelGGL(dec_lzp_selftest_kernel, dim3(9), dim3(256), 0, st, buf, out, 48u);
+}
 
 constexpr uint32_t LZP_ERR = 0x80000000u;       // done[s]: the stream has failed, its result is written
 constexpr uint32_t LZP_SPIN_MAX = 1u << 22;     // polls of done[s] before a workgroup gives up (never reached: a seized launch must still drain)

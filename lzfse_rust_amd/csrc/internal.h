@@ -64,6 +64,7 @@ void launch_dec_lzp(int variant, uint32_t K, const uint8_t *src, const StreamIn 
                     const uint32_t *mlist, uint32_t n_multi, const BlockDesc *blocks, uint32_t n_blocks, const BlockResult *bres,
                     const LmdRec *lmds, const uint8_t *lits, uint2 *ck, uint8_t *dst, StreamResult *sres, uint32_t *state,
                     bool scatter, hipStream_t st);
+void launch_dec_lzp_selftest(uint32_t *buf, uint32_t *out, hipStream_t st);   // buf: 1088 zeroed dwords, out: 2 zeroed dwords
 void launch_dec_jump(const uint8_t *src, const StreamIn *streams, const StreamPlan *plan, const StreamWalk *walk, uint32_t n_streams,
                      const BlockDesc *blocks, uint32_t n_blocks, const BlockResult *bres, const LmdRec *lmds, const uint8_t *lits,
                      uint8_t *dst, uint32_t *origin, uint64_t total, uint32_t *jerr, uint32_t *flags, StreamResult *sres,

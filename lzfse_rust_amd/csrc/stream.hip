@@ -63,6 +63,7 @@ int block_extent(const uint8_t *p, size_t avail, uint64_t &len, uint64_t &n_raw,
     if (magic == MAGIC_VXN) {
         if (avail < 12) return 1;
         n_raw = ld_u32(p + 4); len = 12ull + ld_u32(p + 8);
+        if (n_raw > 136ull * (len - 12)) n_raw = 136ull * (len - 12);   // (as lzfse_mi_decode_size: what a sound block can yield at most)
         return avail < len ? 1 : 0;
     }
     if (magic == MAGIC_RAW) {
@@ -206,8 +207,12 @@ LZFSE_MI_API int lzfse_mi_dstream_feed(lzfse_mi_dstream *s, const uint8_t *src, 
         }
         // the input ends inside a block, or a block cannot be delimited: the rest goes to the device as it is, which
         // reports what the slice path reports for it (PayloadUnderflow, BadBlock, a header error ...)
+        // The sound blocks in front of it go first, as a window of their own: what the sink holds and what the totals say
+        // when the error comes must not depend on how the input was cut into feeds (the reference has written those
+        // blocks by then: decoder.rs:76-99 decodes block by block).
+        if (span) { const int st = decode_span(s, span, raw, true, write, user); if (st) return s->status = st; }
         {
-            const int st = decode_span(s, s->in.size() - s->in_pos, raw, false, write, user);
+            const int st = decode_span(s, s->in.size() - s->in_pos, 0, false, write, user);
             return s->status = st ? st : LZFSE_MI_PAYLOAD_UNDERFLOW;   // (no bvx$: cannot have decoded cleanly)
         }
     }

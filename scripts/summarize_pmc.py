@@ -22,12 +22,15 @@ res = {}
 for k in sorted(set(fetch) | set(write)):
     f = fetch.get(k, (0, 0)); w = write.get(k, (0, 0))
     res[k] = {"launches": max(f[1], w[1]), "fetch_bytes_raw": f[0] * 1024, "fetch_bytes_x2": f[0] * 2048,
-              "write_bytes": w[0] * 1024, "hbm_bytes_raw": (f[0] + w[0]) * 1024}
+              "write_bytes": w[0] * 1024, "hbm_bytes_raw": (f[0] + w[0]) * 1024, "hbm_bytes": (2 * f[0] + w[0]) * 1024}
 import bench
 # stamped with the identity of the kernel sources it was taken on: bench.py reports roofline.traffic only for these
+calls = int(sys.argv[4]) if len(sys.argv) > 4 else 0   # encode (= decode) batch calls of the profiled command: verify + warm-up + steps
 json.dump({"source_sha": bench.kernel_source_sha(), "command": "python bench.py --steps 2 --warmup 1 (default workload: snappy x 256)",
-           "units": "bytes per launch, averaged over the launches of the run; FETCH_SIZE / WRITE_SIZE KiB -> bytes, raw",
+           "encode_calls": calls,
+           "units": "bytes per launch, averaged over the launches of the run; FETCH_SIZE / WRITE_SIZE KiB -> bytes; hbm_bytes = "
+                    "2 x fetch + write (gfx950: FETCH_SIZE tallies 128-byte read requests at 64 bytes, MI355X_MICROARCH.md HBM section)",
            "kernels": res}, open(sys.argv[3], 'w'), indent=1)
 for k, v in res.items():
     if k.startswith(('enc_', 'dec_')):
-        print(f"{k:28s} launches {v['launches']:4d} fetch {v['fetch_bytes_raw']/1e6:9.1f} MB write {v['write_bytes']/1e6:9.1f} MB")
+        print(f"{k:28s} launches {v['launches']:4d} fetch(raw) {v['fetch_bytes_raw']/1e6:9.1f} MB write {v['write_bytes']/1e6:9.1f} MB  hbm = 2 x fetch + write {v['hbm_bytes']/1e6:9.1f} MB")

@@ -11,8 +11,8 @@ _ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
 
 def _load(name="liblzfse_oracle.so"):
     path = os.path.join(_ORACLE_DIR, name)
-    src = os.path.join(_ORACLE_DIR, "lzfse_oracle.c")
-    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+    srcs = [os.path.join(_ORACLE_DIR, f) for f in ("lzfse_oracle.c", "lzfse_oracle.h", "lzo_bench.c")]
+    if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in srcs if os.path.exists(f)):
         subprocess.check_call(["make", "-C", _ORACLE_DIR, name], stdout=subprocess.DEVNULL)
     return C.CDLL(path)
 

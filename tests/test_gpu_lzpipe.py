@@ -91,6 +91,8 @@ def test_pipe_is_chosen_for_few_mid_size_streams(ctx, oracle, snappy_raw):
     ctx.set_option("decode_pipe", 0)
     outs, st = ctx.decode_batch([enc] * 64)
     assert all(e == 0 for e in st) and all(o.tobytes() == raw for o in outs)
+    # the hand-over's start-up self-test (dec_lzp_selftest_kernel) passed on this device, and no launch has refused since
+    assert ctx.pipe_refusals() == 0
 
 
 def test_pipe_refuses_streams_spread_over_xcds(oracle, snappy_raw):
@@ -110,9 +112,11 @@ def test_pipe_refuses_streams_spread_over_xcds(oracle, snappy_raw):
         outs, st = diag_ctx.decode_batch(encs, caps=[1 << 22] * len(encs))
         assert "dec_lz_again" not in diag_ctx.timings()
         assert list(st) == want and all(o.tobytes() == r for o, r in zip(outs, raws))
+        assert diag_ctx.pipe_refusals() == 0
         diag_ctx.set_option("diag_pipe_scatter", 1)
         outs, st = diag_ctx.decode_batch(encs, caps=[1 << 22] * len(encs))
         assert diag_ctx.timings()["dec_lz_again"][1] == 1
+        assert diag_ctx.pipe_refusals() == 1      # ... and the caller can see that it was given up
         assert list(st) == want and all(o.tobytes() == r for o, r in zip(outs, raws))
         outs, st = diag_ctx.decode_batch(encs, caps=[1 << 22] * len(encs))      # given up: the plain kernel from the start
         assert "dec_lz_again" not in diag_ctx.timings()

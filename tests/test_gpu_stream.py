@@ -195,3 +195,60 @@ def test_reader_pulls_the_decoded_bytes(ctx, oracle, golden_dir, snappy_raw):
     with pytest.raises(m.LzfseError) as e:
         r.read()
     assert e.value.status == oracle.decode_status(bytes(bad), 1 << 23) != 0
+
+
+def test_cut_stream_same_sink_whatever_the_feeds(ctx, oracle):
+    """A multi-block stream that ends inside a block: the sound blocks in front of the cut reach the sink, and the
+    totals say so, whether the stream is fed whole, in pieces or byte by byte (the reference decodes block by block,
+    decode/decoder.rs:76-99: it has written them when the error comes)."""
+    import lzfse_rust_amd as m
+    rng = np.random.default_rng(41)
+    words = [bytes(rng.integers(97, 123, size=int(k), dtype=np.uint8)) for k in rng.integers(2, 9, size=300)]
+    raw = b" ".join(words[int(i)] for i in rng.integers(0, 300, size=90_000))[:400_000]
+    enc = oracle.encode(raw)
+    # block boundaries from the headers (bvx2: header size | payload sizes, fse/block.rs:108-136)
+    cuts, pos = [], 0
+    while enc[pos:pos + 4] == b"bvx2":
+        p1, p2, p3 = (int.from_bytes(enc[pos + 8 + 8 * k:pos + 16 + 8 * k], "little") for k in range(3))
+        cuts.append(pos)
+        pos += (p3 & 0xFFFFFFFF) + ((p1 >> 20) & 0xFFFFF) + ((p2 >> 40) & 0xFFFFF)
+    assert len(cuts) >= 4 and enc[pos:pos + 4] == b"bvx$"
+    cut = cuts[3] + 100          # inside the fourth block
+    damaged = enc[:cut]
+    whole_blocks_raw = sum(int.from_bytes(enc[c + 4:c + 8], "little") for c in cuts[:3])
+    results = []
+    for sizes in ([len(damaged)], [4096], [1], [cuts[1] + 5, 7, 100_000]):
+        out = io.BytesIO()
+        dec = m.LzfseRingDecoder(context=ctx)
+        with pytest.raises(m.LzfseError) as e:
+            dec.decode(PieceReader(damaged, sizes), out)
+        results.append((e.value.status, out.getvalue()))
+    assert all(r == results[0] for r in results)
+    assert results[0][0] == oracle.decode_status(damaged, len(raw)) == 8   # PayloadUnderflow
+    assert results[0][1] == raw[:whole_blocks_raw]
+
+
+def test_bvxn_header_that_promises_gigabytes(ctx, oracle):
+    """A bvxn block whose header says 4 GiB over a payload of a few bytes: the reference grows a Vec as it produces and
+    fails in the LZVN decoder at once; nothing here may size a buffer by the header (136 output bytes per payload byte
+    is what a sound block can yield)."""
+    import resource
+    import lzfse_rust_amd as m
+    payload = bytes([0xE3, 1, 2, 3, 0x06, 0, 0, 0, 0, 0, 0, 0])            # SmlL 3 literals, then end of stream
+    good = b"bvxn" + (3).to_bytes(4, "little") + len(payload).to_bytes(4, "little") + payload + b"bvx$"
+    assert oracle.decode(good) == bytes([1, 2, 3])
+    liar = b"bvxn" + (0xFFFFFFFF).to_bytes(4, "little") + len(payload).to_bytes(4, "little") + payload + b"bvx$"
+    liars = liar[:-4] * 40 + b"bvx$"
+    for stream in (liar, liars):
+        assert m.decode_size(stream, partial=True) <= 136 * len(stream)
+        want = oracle.decode_status(stream, 1 << 16)
+        assert want != 0
+        before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+        with pytest.raises(m.LzfseError) as e:
+            m.LzfseDecoder(context=ctx).decode_bytes(stream, bytearray())
+        assert e.value.status == want
+        for sizes in ([len(stream)], [5]):
+            with pytest.raises(m.LzfseError) as e:
+                m.LzfseRingDecoder(context=ctx).decode(PieceReader(stream, sizes), io.BytesIO())
+            assert e.value.status == want
+        assert resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - before < (256 << 10)   # KiB: no gigabyte was allocated
