@@ -18,6 +18,8 @@
 // resolves near matches there and writes the tile back with coalesced 16-byte stores.
 #include <algorithm>
 
+#include <type_traits>
+
 #include "internal.h"
 
 namespace lzmi {
@@ -660,29 +662,48 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
         // The steps run with the lanes of row 0 only (16 at a time between two refill checks, which need the whole wave):
         // every LDS and vector instruction of a step then makes one pass instead of one per 32 lanes, and the LDS pipe is
         // what a full chip of these waves runs out of.
+        // One step is about 25 instructions and a wave issues one every four cycles: a full chip of these waves is bound by
+        // instruction ISSUE (16 blocks x 2 waves per CU), a lone block by its own instruction count plus one LDS round trip
+        // per step -- either way the time is the number of instructions in a step. So: a chunk of SUB steps is unrolled
+        // (no loop counter, the staging stores at constant offsets), the cursor is ONE scalar (r2 = rem - 64 - 32 cb: its
+        // dword index and its bit offset are what the ring is read with), and the rule for a stream that has run out of
+        // bits (bw_step_window) is only evaluated in chunks that can get there (the tail of a sound stream, damaged ones).
         constexpr uint32_t SUB = 16;
         static_assert(64 % SUB == 0 && 2 * SUB + 2 <= 62, "a sub-chunk ends where a 64-step flush does, and its refill margin stays in the lower half of the ring");
+        const uint32_t *const ringw = w.buf;
         for (uint32_t g0 = 0; g0 < n_groups; g0 += SUB) {
             bw_refill(w, (int32_t)SUB);
             const uint32_t g1 = n_groups - g0 < SUB ? n_groups : g0 + SUB;
+            const int32_t r2_bias = 64 + 32 * w.cb;
+            int32_t r2 = w.rem - r2_bias;   // uniform: bits below the window's lowest bit, counted from the ring's first dword
+            const int32_t low57 = w.base_bit + 57 - r2_bias;   // the window is forced to zero once r2 < low57 - 64 + 64 ... (rem - base_bit < 57)
+            auto lit_step = [&](auto safe_tag, uint32_t slot_off) {
+                constexpr bool SAFE = decltype(safe_tag)::value;
+                const uint32_t k = ent & 0xFF;
+                uint32_t pre = k + dpp_shr<1>(k);
+                pre += dpp_shr<2>(pre);  // inclusive prefix over lanes 0..3
+                const uint32_t x = (uint32_t)(win >> ((0u - pre) & 63));   // pre == 0 only with k == 0
+                const uint32_t bits = __builtin_amdgcn_ubfe(x, 0u, k);
+                state = (bits + (ent >> 16)) & 1023u;       // (delta is a 16-bit two's complement: the mask takes the carry away)
+                stg_lit[sidx + slot_off] = (uint8_t)(ent >> 8);
+                ent = u_tab[state];
+                r2 -= (int32_t)read_lane(pre, 3);
+                const int32_t di = r2 >> 5;
+                const uint32_t d0 = ringw[di], d1 = ringw[di + 1], d2 = ringw[di + 2];
+                const uint32_t x0 = __builtin_amdgcn_alignbit(d1, d0, (uint32_t)r2), x1 = __builtin_amdgcn_alignbit(d2, d1, (uint32_t)r2);
+                win = (uint64_t)x0 | ((uint64_t)x1 << 32);
+                if (SAFE && r2 + 64 < low57) win = 0;
+            };
             if (lane < 4) {
-                for (uint32_t g = g0; g < g1; g++) {
-                    const uint32_t k = ent & 0xFF;
-                    const int32_t delta = (int32_t)(int16_t)(ent >> 16);
-                    uint32_t pre = k;
-                    pre += dpp_shr<1>(pre);
-                    pre += dpp_shr<2>(pre);  // inclusive prefix over lanes 0..3
-                    const uint32_t bits = (uint32_t)(win >> ((64 - pre) & 63)) & ((1u << k) - 1u);  // pre == 0 only with k == 0
-                    state = (uint32_t)((int32_t)bits + delta) & 1023u;
-                    const uint32_t sym = ent >> 8;
-                    ent = u_tab[state];
-                    stg_lit[sidx] = (uint8_t)sym;
-                    sidx += s_inc;
-                    bw_consume(w, read_lane(pre, 3));
-                    win = bw_step_window(w);
+                if (g1 - g0 == SUB && r2 + 64 - 64 * (int32_t)SUB >= low57) {
+#pragma unroll
+                    for (uint32_t j = 0; j < SUB; j++) lit_step(std::false_type{}, 4u * j);
+                    sidx += s_inc * SUB;
+                } else {
+                    for (uint32_t g = g0; g < g1; g++) { lit_step(std::true_type{}, 0u); sidx += s_inc; }
                 }
             }
-            w.rem = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)w.rem);   // (uniform again: the lanes that were off kept the old value)
+            w.rem = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)r2) + r2_bias;   // (uniform again: the lanes that were off kept the old value)
             if ((g1 & 63) == 0) {
                 ((uint32_t *)out)[(g1 - 64) + lane] = ((const uint32_t *)stg_lit)[lane];
                 sidx = s_home;
@@ -731,30 +752,44 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
         uint64_t win = n ? bw_window(w) : 0;
         uint2 ent = v_tab[tbase + state];   // (looked up one step ahead of its window, see the literal loop)
         constexpr uint32_t SUB = 16;   // (see the literal loop)
+        const uint32_t *const ringw = w.buf;
+        const uint2 *const vt = v_tab + tbase;
         for (uint32_t i0 = 0; i0 < n; i0 += SUB) {
             bw_refill(w, (int32_t)SUB);
             const uint32_t i1 = n - i0 < SUB ? n : i0 + SUB;
+            const int32_t r2_bias = 64 + 32 * w.cb;
+            int32_t r2 = w.rem - r2_bias;
+            const int32_t low57 = w.base_bit + 57 - r2_bias;
+            auto lmd_step = [&](auto safe_tag, uint32_t slot_off) {
+                constexpr bool SAFE = decltype(safe_tag)::value;
+                const uint32_t k = ent.x & 0xFF, vb = __builtin_amdgcn_ubfe(ent.x, 8u, 8u);
+                const uint32_t tot = k + vb;
+                uint32_t pre = tot + dpp_shr<1>(tot);
+                pre += dpp_shr<2>(tot);   // (both moves read `tot`: no wait between them)
+                // a lane's field (state bits above value bits) is at most 10 + 15 bits: one 64-bit shift, two bit-field extracts
+                const uint32_t x = (uint32_t)(win >> ((0u - pre) & 63));  // pre == 0 only when k = vb = 0 below
+                const uint32_t extra = __builtin_amdgcn_ubfe(x, 0u, vb);
+                const uint32_t sb = __builtin_amdgcn_ubfe(x, vb, k);
+                state = (sb + (ent.x >> 16)) & smask;
+                stg_lmd[sidx + slot_off] = ent.y + extra;
+                ent = vt[state];
+                r2 -= (int32_t)read_lane(pre, 2);
+                const int32_t di = r2 >> 5;
+                const uint32_t d0 = ringw[di], d1 = ringw[di + 1], d2 = ringw[di + 2];
+                const uint32_t x0 = __builtin_amdgcn_alignbit(d1, d0, (uint32_t)r2), x1 = __builtin_amdgcn_alignbit(d2, d1, (uint32_t)r2);
+                win = (uint64_t)x0 | ((uint64_t)x1 << 32);
+                if (SAFE && r2 + 64 < low57) win = 0;
+            };
             if (lane < 3) {
-                for (uint32_t i = i0; i < i1; i++) {
-                    const uint32_t k = ent.x & 0xFF, vb = (ent.x >> 8) & 0xFF;
-                    const int32_t delta = (int32_t)(int16_t)(ent.x >> 16);
-                    uint32_t pre = k + vb;
-                    pre += dpp_shr<1>(pre);
-                    pre += dpp_shr<2>(pre);
-                    // a lane's field (state bits above value bits) is at most 10 + 15 bits: one 64-bit shift, two 32-bit extracts
-                    const uint32_t x = (uint32_t)(win >> ((64 - pre) & 63));  // pre == 0 only when k = vb = 0 below
-                    const uint32_t extra = x & ((1u << vb) - 1u);
-                    const uint32_t sb = (x >> vb) & ((1u << k) - 1u);
-                    state = (uint32_t)((int32_t)sb + delta) & smask;
-                    const uint32_t value = ent.y + extra;
-                    ent = v_tab[tbase + state];
-                    stg_lmd[sidx] = value;
-                    sidx += s_inc;
-                    bw_consume(w, read_lane(pre, 2));
-                    win = bw_step_window(w);
+                if (i1 - i0 == SUB && r2 + 64 - 64 * (int32_t)SUB >= low57) {
+#pragma unroll
+                    for (uint32_t j = 0; j < SUB; j++) lmd_step(std::false_type{}, 3u * j);
+                    sidx += s_inc * SUB;
+                } else {
+                    for (uint32_t i = i0; i < i1; i++) { lmd_step(std::true_type{}, 0u); sidx += s_inc; }
                 }
             }
-            w.rem = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)w.rem);
+            w.rem = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)r2) + r2_bias;
             if ((i1 & 63) == 0) { flush(i1 - 64, 64); sidx = s_home; }
         }
         if (n & 63) flush(n & ~63u, n & 63);
