@@ -470,18 +470,31 @@ __global__ void dec_order_place_kernel(const BlockDesc *__restrict__ blocks, uin
 }
 
 // LDS table entry formats
-//   U: k | symbol << 8 | (delta & 0xFFFF) << 16                       (decoder.rs:222-238)
+//   U: (delta & 0xFFFF) | symbol << 16 | k << 24                      (decoder.rs:222-238; the symbol in byte 2 is what a
+//      d16_hi byte store takes without a shift, the delta in the low word what an SDWA add takes)
 //   V: .x = k | v_bits << 8 | (delta & 0xFFFF) << 16, .y = v_base     (decoder.rs:205-220)
 __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
     const uint8_t *__restrict__ src, uint64_t src_total, const BlockDesc *__restrict__ blocks,
     uint32_t n_blocks, uint8_t *__restrict__ lit_out, LmdRec *__restrict__ lmd_out,
     BlockResult *__restrict__ results, const uint32_t *__restrict__ order) {
-    __shared__ uint32_t u_tab[U_STATES];
-    __shared__ uint2 v_tab[L_STATES + M_STATES + D_STATES];
-    // The buffers of the table set-up (weight payload, weights, cumulative weights) and those of the two bit streams share
-    // one pool: the set-up is over (a workgroup barrier) before the first payload word is staged. 9.3 KB of LDS per block
-    // instead of 11.4: the 32 wave slots of a CU, not its LDS, bound the number of resident blocks (16 instead of 14).
-    __shared__ uint32_t pool[168 + N_WEIGHTS];
+    // One LDS block, the pool FIRST: the payload rings then sit at LDS addresses 0 and 512, inside the offset fields of
+    // ds_read2_b32 / ds_read_b32, and a window fetch is one address register + two reads (no base add, no second move).
+    struct FseLds {
+        // The buffers of the table set-up (weight payload, weights, cumulative weights) and those of the two bit streams share
+        // one pool: the set-up is over (a workgroup barrier) before the first payload word is staged. 9.3 KB of LDS per block
+        // instead of 11.4: the 32 wave slots of a CU, not its LDS, bound the number of resident blocks (16 instead of 14).
+        uint32_t pool[168 + N_WEIGHTS];
+        uint32_t u_tab[U_STATES];
+        uint2 v_tab[L_STATES + M_STATES + D_STATES];
+        int status[2];
+        uint32_t sums[3];
+    };
+    __shared__ __attribute__((aligned(16))) FseLds lds;
+    uint32_t *const pool = lds.pool;
+    uint32_t *const u_tab = lds.u_tab;
+    uint2 *const v_tab = lds.v_tab;
+    int *const sh_status = lds.status;
+    uint32_t *const sh_sums = lds.sums;
     uint32_t *const stage = pool;                                               // up to 662 header+weight bytes (v2), dword aligned
     uint16_t *const wts = reinterpret_cast<uint16_t *>(pool + 168);            // N_WEIGHTS
     uint16_t *const cum = reinterpret_cast<uint16_t *>(pool + 168 + N_WEIGHTS / 2);
@@ -489,8 +502,6 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
     uint32_t *const stg_lmd = pool + 256;          // 64 steps of (L, M, D) values, + one dump slot for the idle lanes (193)
     uint8_t *const stg_lit = reinterpret_cast<uint8_t *>(pool + 256 + 194);    // 64 groups of four literals, + dump slot (260 B)
     static_assert(256 + 194 + 65 <= 168 + N_WEIGHTS, "dec_fse LDS pool");
-    __shared__ int sh_status[2];
-    __shared__ uint32_t sh_sums[3];
 
     if (blockIdx.x >= n_blocks) return;
     const uint32_t b = order[blockIdx.x];   // longest blocks first (dec_order_*)
@@ -600,9 +611,9 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
             int32_t delta; uint32_t kk;
             if (j < x) { kk = k; delta = (int32_t)((w + j) << k) - 1024; }
             else { kk = k - 1; delta = (int32_t)((j - x) << (k - 1)); }
-            e = kk | (lo << 8) | ((uint32_t)(delta & 0xFFFF) << 16);
+            e = (uint32_t)(delta & 0xFFFF) | (lo << 16) | (kk << 24);
         } else {
-            e = 0u | (0u << 8) | (t << 16);  // latch: k = 0, symbol 0, delta = own index
+            e = t;  // latch: k = 0, symbol 0, delta = own index
         }
         u_tab[t] = e;
     }
@@ -679,15 +690,15 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
             const int32_t low57 = w.base_bit + 57 - r2_bias;   // the window is forced to zero once r2 < low57 - 64 + 64 ... (rem - base_bit < 57)
             auto lit_step = [&](auto safe_tag, uint32_t slot_off) {
                 constexpr bool SAFE = decltype(safe_tag)::value;
-                const uint32_t k = ent & 0xFF;
+                const uint32_t k = ent >> 24;
                 uint32_t pre = k + dpp_shr<1>(k);
                 pre += dpp_shr<2>(pre);  // inclusive prefix over lanes 0..3
                 const uint32_t x = (uint32_t)(win >> ((0u - pre) & 63));   // pre == 0 only with k == 0
                 const uint32_t bits = __builtin_amdgcn_ubfe(x, 0u, k);
-                state = (bits + (ent >> 16)) & 1023u;       // (delta is a 16-bit two's complement: the mask takes the carry away)
-                stg_lit[sidx + slot_off] = (uint8_t)(ent >> 8);
+                state = (bits + (ent & 0xFFFFu)) & 1023u;   // (delta is a 16-bit two's complement: the mask takes the carry away)
+                stg_lit[sidx + slot_off] = (uint8_t)(ent >> 16);
                 ent = u_tab[state];
-                r2 -= (int32_t)read_lane(pre, 3);
+                r2 = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)(r2 - (int32_t)read_lane(pre, 3)));   // (scalar: the address arithmetic below stays off the vector pipe)
                 const int32_t di = r2 >> 5;
                 const uint32_t d0 = ringw[di], d1 = ringw[di + 1], d2 = ringw[di + 2];
                 const uint32_t x0 = __builtin_amdgcn_alignbit(d1, d0, (uint32_t)r2), x1 = __builtin_amdgcn_alignbit(d2, d1, (uint32_t)r2);
@@ -773,7 +784,7 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
                 state = (sb + (ent.x >> 16)) & smask;
                 stg_lmd[sidx + slot_off] = ent.y + extra;
                 ent = vt[state];
-                r2 -= (int32_t)read_lane(pre, 2);
+                r2 = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)(r2 - (int32_t)read_lane(pre, 2)));
                 const int32_t di = r2 >> 5;
                 const uint32_t d0 = ringw[di], d1 = ringw[di + 1], d2 = ringw[di + 2];
                 const uint32_t x0 = __builtin_amdgcn_alignbit(d1, d0, (uint32_t)r2), x1 = __builtin_amdgcn_alignbit(d2, d1, (uint32_t)r2);
