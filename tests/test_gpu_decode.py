@@ -218,3 +218,46 @@ def test_decode_many_tiny_blocks_rewalk(ctx, oracle, snappy_raw):
     for s, o in zip(srcs, outs):
         assert o.tobytes() == oracle.decode(s)
     assert len(outs[1]) == 3000 and len(outs[3]) == 1500
+
+
+def test_entropy_stage_one_and_four_blocks_per_workgroup(diag_ctx, oracle, golden_dir, snappy_raw):
+    """dec_fse_kernel (one block per workgroup) and dec_fse4_kernel (four blocks per workgroup, one per row of 16 lanes) are
+    chosen by the size of the batch; the diagnostic build forces either. Both must give the oracle's bytes and status
+    codes: every fixture, multi-block streams whose blocks differ in length, blocks cut short, damaged payloads (the
+    run-out rule of the bit reader, literals past the block limit, bad final states), counts that are not multiples of 4."""
+    import glob
+    import os
+    rng = np.random.default_rng(77)
+    srcs = []
+    for sub in ("snappy", "special", "mutate"):
+        srcs += [open(f, "rb").read() for f in sorted(glob.glob(os.path.join(golden_dir, sub, "*.lzfse")))]
+    big = oracle.encode(snappy_raw["lcet10.txt"] + snappy_raw["html"] * 2 + snappy_raw["kppkn.gtb"][:70000])
+    srcs += [big, oracle.encode(snappy_raw["urls.10K"]), oracle.encode(bytes(300000)), oracle.encode(snappy_raw["fireworks.jpeg"])]
+    for base in (open(os.path.join(golden_dir, "mutate", "vx2.lzfse"), "rb").read(), open(os.path.join(golden_dir, "mutate", "vx1.lzfse"), "rb").read()):
+        for bit in range(0, 8 * len(base), 7):
+            m = bytearray(base)
+            m[bit >> 3] ^= 1 << (bit & 7)
+            srcs.append(bytes(m))
+    for _ in range(150):
+        m = bytearray(big)
+        if rng.random() < 0.3:
+            m = m[: int(rng.integers(40, len(m)))]
+        else:
+            for _k in range(int(rng.integers(1, 3))):
+                m[int(rng.integers(0, len(m)))] ^= 1 << int(rng.integers(0, 8))
+        srcs.append(bytes(m))
+    cap = 1 << 21
+    want = []
+    for s in srcs:
+        st = oracle.decode_status(s, cap)
+        want.append((st, oracle.decode(s, cap=cap) if st == 0 else None))
+    try:
+        for mode in (1, 2):
+            diag_ctx.set_option("diag_fse", mode)
+            outs, st = diag_ctx.decode_batch(srcs, caps=[cap] * len(srcs))
+            for i, (o, e) in enumerate(zip(outs, st)):
+                assert e == want[i][0], (mode, i, e, want[i][0])
+                if e == 0:
+                    assert o.tobytes() == want[i][1], (mode, i)
+    finally:
+        diag_ctx.set_option("diag_fse", 0)
