@@ -95,9 +95,8 @@ enum {
     LZFSE_MI_OPT_DIAG_STATS = 102,   /* bit mask: per-stage statistics on stderr */
     LZFSE_MI_OPT_DIAG_CHAIN = 103,   /* 1: every chain tile through the ballot kernel (the fallback of the LDS-exchange one) */
     LZFSE_MI_OPT_DIAG_WALK = 104,    /* decode header walk: 0 by size, 1: every stream tries the parallel walk first, 2: serial only */
-    LZFSE_MI_OPT_DIAG_PIPE_SCATTER = 105, /* 1: the pipelined LZ kernel is told that the workgroups of a stream sit on different XCDs
+    LZFSE_MI_OPT_DIAG_PIPE_SCATTER = 105  /* 1: the pipelined LZ kernel is told that the workgroups of a stream sit on different XCDs
                                              (it must refuse, and the streams are decoded again by the one-workgroup kernel) */
-    LZFSE_MI_OPT_DIAG_FSE = 106           /* entropy stage of decode: 0 by the batch, 1 one block per workgroup, 2 four blocks per workgroup */
 };
 LZFSE_MI_API int lzfse_mi_set_option(lzfse_mi_ctx *ctx, int option, int64_t value);
 

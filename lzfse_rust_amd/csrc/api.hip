@@ -145,7 +145,7 @@ struct lzfse_mi_ctx {
     uint32_t pipe_refusals = 0; // times the pipelined LZ kernel was given up (self-test failed / a launch refused): lzfse_mi_get_info
     int lane_share = 1;    // sub-batches running side by side with this one (split_batch)
     bool parse_ring = false;   // set for the duration of a ring / stream encode call (lzfse_mi_encode_ring*, lzfse_mi_estream_*)
-    int diag_lz_jump = -1, diag_lz_variant = -1, diag_stats = 0, diag_chain = 0, diag_walk = 0, diag_pipe_scatter = 0, diag_fse = 0;  // diagnostic build only
+    int diag_lz_jump = -1, diag_lz_variant = -1, diag_stats = 0, diag_chain = 0, diag_walk = 0, diag_pipe_scatter = 0;  // diagnostic build only
 
     hipEvent_t get_event() {
         if (ev_used == ev_pool.size()) {
@@ -581,7 +581,7 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
     {
         StageTimer t(c, "dec_fse");
         launch_dec_fse((const uint8_t *)d_src, src_total, (const BlockDesc *)c->d_blocks.p, (uint32_t)nb,
-                       (uint8_t *)c->d_lits.p, (LmdRec *)c->d_lmds.p, (BlockResult *)c->d_bres.p, d_ohist, d_order, c->diag_fse, st);
+                       (uint8_t *)c->d_lits.p, (LmdRec *)c->d_lmds.p, (BlockResult *)c->d_bres.p, d_ohist, d_order, st);
     }
     {
         StageTimer t(c, "dec_lz");
@@ -795,7 +795,7 @@ static int split_batch(lzfse_mi_ctx *c, batch_dev_fn one, int lanes, bool stagge
         c->shadow[k]->parse_ring = c->parse_ring;
         c->shadow[k]->diag_lz_jump = c->diag_lz_jump; c->shadow[k]->diag_lz_variant = c->diag_lz_variant;
         c->shadow[k]->diag_stats = c->diag_stats; c->shadow[k]->diag_chain = c->diag_chain; c->shadow[k]->diag_walk = c->diag_walk;
-        c->shadow[k]->diag_pipe_scatter = c->diag_pipe_scatter; c->shadow[k]->diag_fse = c->diag_fse;
+        c->shadow[k]->diag_pipe_scatter = c->diag_pipe_scatter;
     }
     if (!ok) return unsplit();
     // staggered start (encode): lane k + 1 begins when lane k has queued its candidate kernel
@@ -841,14 +841,11 @@ int lzfse_mi_decode_batch_device(lzfse_mi_ctx *c, size_t count, const void *d_sr
                                  const uint64_t *src_len, void *d_dst, const uint64_t *dst_off,
                                  const uint64_t *dst_cap, uint64_t *out_lens, int *statuses) {
     if (!c) return LZFSE_MI_BAD_ARGUMENT;
-    int lanes = c->opt_lanes_dec ? c->opt_lanes_dec : 2;
-    if (!c->opt_lanes_dec && c->opt_pipe != 1 && !c->pipe_broken && count <= 128 && dst_cap) {
-        // few streams, some of them large: the LZ stage gives every stream several workgroups (dec_lzp_kernel), which
-        // wants the whole chip for one pass; sub-batches side by side would take the CUs from each other
-        bool big = false;
-        for (size_t i = 0; i < count; i++) big |= dst_cap[i] >= PIPE_MIN_RAW;
-        if (big) lanes = 1;
-    }
+    // One pass by default. (Round 2 ran two sub-batches side by side here: the entropy stage was bound by instruction issue and
+    // a second lane filled its gaps. With the round-3 decode steps a single pass is as fast or faster at every batch size
+    // measured -- Snappy x 64 / 256 / 512: 72.5 / 124.5 / 137.5 GB/s against 69.6 / 119.3 / 136.4 -- and few large streams
+    // want the chip for one pass of the pipelined LZ kernel anyway. LZFSE_MI_OPT_DECODE_LANES still splits on request.)
+    const int lanes = c->opt_lanes_dec ? c->opt_lanes_dec : 1;
     return split_batch(c, decode_batch_device_one, lanes, false, count, d_src, src_off, src_len, d_dst,
                        dst_off, dst_cap, out_lens, statuses);
 }
@@ -906,15 +903,13 @@ int lzfse_mi_set_option(lzfse_mi_ctx *c, int option, int64_t value) {
     case LZFSE_MI_OPT_DIAG_CHAIN: c->diag_chain = (int)value; return LZFSE_MI_OK;
     case LZFSE_MI_OPT_DIAG_WALK: c->diag_walk = (int)value; return LZFSE_MI_OK;
     case LZFSE_MI_OPT_DIAG_PIPE_SCATTER: c->diag_pipe_scatter = (int)value; c->pipe_broken = false; return LZFSE_MI_OK;
-    case LZFSE_MI_OPT_DIAG_FSE: c->diag_fse = (int)value; return LZFSE_MI_OK;
 #else
     case LZFSE_MI_OPT_DIAG_LZ_PATH:
     case LZFSE_MI_OPT_DIAG_LZ_TILE:
     case LZFSE_MI_OPT_DIAG_STATS:
     case LZFSE_MI_OPT_DIAG_CHAIN:
     case LZFSE_MI_OPT_DIAG_WALK:
-    case LZFSE_MI_OPT_DIAG_PIPE_SCATTER:
-    case LZFSE_MI_OPT_DIAG_FSE: return LZFSE_MI_UNSUPPORTED;
+    case LZFSE_MI_OPT_DIAG_PIPE_SCATTER: return LZFSE_MI_UNSUPPORTED;
 #endif
     default: return LZFSE_MI_BAD_ARGUMENT;
     }
@@ -1097,7 +1092,7 @@ static int host_batch(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, size_
     lzfse_mi_ctx *p = c->host_peer;
     p->opt_lanes_enc = c->opt_lanes_enc; p->opt_lanes_dec = c->opt_lanes_dec; p->opt_stagger = c->opt_stagger; p->opt_pipe = c->opt_pipe;
     p->diag_lz_jump = c->diag_lz_jump; p->diag_lz_variant = c->diag_lz_variant; p->diag_stats = c->diag_stats; p->diag_chain = c->diag_chain;
-    p->diag_walk = c->diag_walk; p->diag_pipe_scatter = c->diag_pipe_scatter; p->diag_fse = c->diag_fse;
+    p->diag_walk = c->diag_walk; p->diag_pipe_scatter = c->diag_pipe_scatter;
     p->parse_ring = c->parse_ring;
     int rB = 0;
     bool started = false;

@@ -852,365 +852,6 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
     }
 }
 
-// ------------------------------------------------------------------------------------ entropy stage, four blocks per workgroup
-//
-// dec_fse_kernel spends a 64-lane vector instruction on the three (LMD) or four (literal) lanes of ONE block's step, and a
-// full chip of it is bound by the vector pipe: 18 vector instructions per step x 4 cycles x 8 waves per SIMD. Here a wave
-// decodes the same-role streams of FOUR blocks at once, one block per row of 16 lanes (the DPP prefix of a step already
-// stays inside a row), so the same instructions serve four block-steps; what was a scalar per block -- the cursor, the
-// ring, the refill state -- is a row-uniform vector register. The staging and the flush of the decoded values work row
-// by row with row-local scans. Blocks come longest first, so the four of a workgroup are of about one length.
-// Chosen for batches that fill the chip (launch_dec_fse); a few blocks are better off with one workgroup each.
-constexpr int FSE_R = 4;
-
-struct FseRow {   // what the decode waves need of a block (written by thread 0 during the set-up)
-    uint64_t pos;                  // offset of the block in src
-    uint64_t lit_base, lmd_base;   // where its literals / LMD records go
-    uint32_t valid, block;
-    uint32_t lit_off, lit_len, lit_bits, lit_num, lit_state[4], lit_short;
-    uint32_t lmd_off, lmd_len, lmd_bits, lmd_num, lmd_state[3], lmd_short;
-    uint32_t n_raw;
-};
-
-struct RowWindow {   // BitWindow with row-uniform vector registers; r2 = rem - 64 - 32 cb as in dec_fse_kernel's steps
-    int32_t r2, cb, base_bit;
-    const uint8_t *ga;
-    uint32_t pend[4];   // prefetched dwords cb - 64 + 16 q + sub
-};
-
-__device__ __forceinline__ uint32_t rw_gload(const RowWindow &w, int32_t dw, const uint8_t *glo, const uint8_t *ghi) {
-    const uint8_t *a = w.ga + (int64_t)dw * 4;
-    typedef const __attribute__((address_space(1))) uint32_t *gptr;
-    return (a >= glo && a + 4 <= ghi) ? *(gptr)(uintptr_t)a : 0u;
-}
-__device__ __forceinline__ uint32_t row_incl_sum(uint32_t v) {   // inclusive prefix sum inside a row of 16 lanes
-    v += dpp_take<0x111, 0xF>(0u, v);
-    v += dpp_take<0x112, 0xF>(0u, v);
-    v += dpp_take<0x114, 0xF>(0u, v);
-    v += dpp_take<0x118, 0xF>(0u, v);
-    return v;
-}
-template <int Q>   // lane Q of every quad, to all four lanes of the quad
-__device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
-    int t = __builtin_amdgcn_update_dpp(0, (int)v, Q * 0x55, 0xF, 0xF, false);
-    // (kept as a v_mov_b32_dpp of its own: folded into its consumer -- v_subrev_u32_dpp ... quad_perm:[2,2,2,2] -- the cursors
-    // came out wrong on gfx950 with ROCm 7.2, with the move kept apart every stream decodes; one instruction per step)
-    asm volatile("" : "+v"(t));
-    return (uint32_t)t;
-}
-
-// bit_reader.rs:20-30 for one row (its 16 lanes call with the same arguments); returns BadBitStream or 0
-__device__ __forceinline__ int rw_init(RowWindow &w, uint32_t *buf, const uint8_t *base, uint32_t len, uint32_t off, int sub,
-                                       const uint8_t *glo, const uint8_t *ghi) {
-    const uintptr_t b = (uintptr_t)base;
-    w.ga = (const uint8_t *)(b & ~(uintptr_t)3);
-    w.base_bit = (int32_t)(b & 3) * 8;
-    const int32_t rem = w.base_bit + (int32_t)(8 * len) - (int32_t)off;
-    const int32_t t0 = (rem - 64) >> 5;
-    w.cb = (t0 - 32) & ~63;
-    w.r2 = rem - 64 - 32 * w.cb;
-#pragma unroll
-    for (int q = 0; q < 8; q++) buf[16 * q + sub] = rw_gload(w, w.cb + 16 * q + sub, glo, ghi);
-#pragma unroll
-    for (int q = 0; q < 4; q++) w.pend[q] = rw_gload(w, w.cb - 64 + 16 * q + sub, glo, ghi);
-    // the unused top `off` bits of the last byte must be zero (Error::BadBitStream)
-    return (off != 0 && (base[len - 1] >> (8 - off)) != 0) ? LZFSE_MI_BAD_BIT_STREAM : 0;
-}
-// keeps `steps` steps of at most 64 bits inside the ring (bw_refill, by the row's 16 lanes)
-__device__ __forceinline__ void rw_refill(RowWindow &w, uint32_t *buf, int32_t steps, int sub, const uint8_t *glo, const uint8_t *ghi) {
-    if ((w.r2 >> 5) < 2 * steps + 2) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t low = buf[16 * q + sub];
-            buf[64 + 16 * q + sub] = low;
-            buf[16 * q + sub] = w.pend[q];
-        }
-        w.cb -= 64;
-        w.r2 += 64 * 32;
-#pragma unroll
-        for (int q = 0; q < 4; q++) w.pend[q] = rw_gload(w, w.cb - 64 + 16 * q + sub, glo, ghi);
-    }
-}
-
-__global__ __launch_bounds__(FSE_THREADS) void dec_fse4_kernel(
-    const uint8_t *__restrict__ src, uint64_t src_total, const BlockDesc *__restrict__ blocks,
-    uint32_t n_blocks, uint8_t *__restrict__ lit_out, LmdRec *__restrict__ lmd_out,
-    BlockResult *__restrict__ results, const uint32_t *__restrict__ order) {
-    __shared__ __attribute__((aligned(16))) FseLds lds[FSE_R];
-    __shared__ FseRow rows[FSE_R];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint8_t *glo = src, *ghi = src + ((src_total + 3) & ~3ull);
-
-    // ---- set-up: headers, weights, tables, one block after the other by the whole workgroup ----
-    for (int r = 0; r < FSE_R; r++) {
-        const uint32_t oi = blockIdx.x * FSE_R + (uint32_t)r;
-        bool valid = oi < n_blocks;
-        uint32_t b = 0;
-        BlockDesc d = {};
-        FseHeader h = {};
-        int st = 0;
-        if (valid) {
-            b = order[oi];   // longest blocks first (dec_order_*)
-            d = blocks[b];
-            valid = d.kind == KIND_VX2 || d.kind == KIND_VX1;
-        }
-        const uint8_t *p = src + d.src_pos;
-        uint64_t avail = 0;
-        if (valid) {
-            st = d.kind == KIND_VX1 ? fse_load_v1(p, h) : fse_load_v2(p, h);  // validated by the walk
-            avail = d.src_end - d.src_pos;
-            if (!st && avail < h.hdr_size) st = LZFSE_MI_PAYLOAD_UNDERFLOW;   // (see dec_fse_kernel)
-        }
-        if (tid < 2) lds[r].status[tid] = 0;
-        if (valid && !st) st = fse_build_tables(lds[r], d.kind, h, p);   // (uniform condition: barriers inside)
-        if (tid == 0) {
-            FseRow R = {};
-            R.valid = (valid && !st) ? 1u : 0u;
-            R.block = b;
-            R.pos = d.src_pos; R.lit_base = d.lit_base; R.lmd_base = d.lmd_base;
-            R.lit_off = h.hdr_size - 8;  // fse_core.rs:30-33,59: 8 bytes lent as reader pad
-            R.lit_len = h.lit_payload + 8; R.lit_bits = h.lit_bits; R.lit_num = h.lit_num;
-            for (int k = 0; k < 4; k++) R.lit_state[k] = h.lit_state[k];
-            R.lit_short = avail < (uint64_t)h.hdr_size + h.lit_payload;
-            R.lmd_off = h.hdr_size + h.lit_payload; R.lmd_len = h.lmd_payload; R.lmd_bits = h.lmd_bits; R.lmd_num = h.lmd_num;
-            for (int k = 0; k < 3; k++) R.lmd_state[k] = h.lmd_state[k];
-            R.lmd_short = avail < (uint64_t)h.hdr_size + h.lit_payload + h.lmd_payload;
-            R.n_raw = h.n_raw;
-            rows[r] = R;
-            if (valid && st) { BlockResult br; br.status = st; br.sum_l = 0; br.sum_m = 0; br.ok_until = 0; results[b] = br; }
-        }
-    }
-    __syncthreads();
-
-    // ---- the bit streams: row = block, lanes 0..2 (LMD wave) / 0..3 (literal wave) of the row carry the states ----
-    const int row = lane >> 4, sub = lane & 15;
-    const uint32_t rsh = 16u * (uint32_t)row;
-    FseLds &L = lds[row];
-    const FseRow &R = rows[row];
-    const bool valid = R.valid != 0;
-    constexpr uint32_t SUB = 16;
-    if (wave == 1) {
-        // literals.rs:49-91
-        uint32_t *const ringw = L.pool + 128;
-        uint8_t *const stg = reinterpret_cast<uint8_t *>(L.pool + 256 + 194);
-        const uint32_t *const ut = L.u_tab;
-        const bool lshort = R.lit_short != 0;
-        RowWindow w;
-        w.r2 = 4096; w.cb = 0; w.base_bit = 0; w.ga = glo; w.pend[0] = w.pend[1] = w.pend[2] = w.pend[3] = 0;
-        int e = 0;
-        if (valid) {
-            if (lshort) e = LZFSE_MI_PAYLOAD_UNDERFLOW;
-            else e = rw_init(w, ringw, src + R.pos + R.lit_off, R.lit_len, R.lit_bits, sub, glo, ghi);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t n_row = (valid && !e) ? R.lit_num >> 2 : 0u;
-        uint32_t n_max = n_row;
-        n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, 16));
-        n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, 32));
-        uint32_t state = R.lit_state[sub & 3];
-        uint32_t *const out32 = reinterpret_cast<uint32_t *>(lit_out + R.lit_base);
-        uint32_t ent = ut[state];
-        uint64_t win;
-        {
-            const int32_t di = w.r2 >> 5;
-            const uint32_t d0 = ringw[di], d1 = ringw[di + 1], d2 = ringw[di + 2];
-            win = (uint64_t)__builtin_amdgcn_alignbit(d1, d0, (uint32_t)w.r2) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, (uint32_t)w.r2) << 32);
-        }
-        uint32_t sidx = (uint32_t)sub;
-        for (uint32_t g0 = 0; g0 < n_max; g0 += SUB) {
-            rw_refill(w, ringw, (int32_t)SUB, sub, glo, ghi);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const bool act = g0 < n_row, full = g0 + SUB <= n_row;
-            const int32_t low57 = w.base_bit + 57 - 64 - 32 * w.cb;
-            int32_t r2 = w.r2;
-            auto lit_step = [&](auto safe_tag, uint32_t slot_off) {
-                constexpr bool SAFE = decltype(safe_tag)::value;
-                const uint32_t k = ent >> 24;
-                uint32_t pre = k + dpp_shr<1>(k);
-                pre += dpp_shr<2>(pre);  // inclusive prefix over lanes 0..3 of the row
-                const uint32_t x = (uint32_t)(win >> ((0u - pre) & 63));
-                const uint32_t bits = __builtin_amdgcn_ubfe(x, 0u, k);
-                state = (bits + (ent & 0xFFFFu)) & 1023u;
-                stg[sidx + slot_off] = (uint8_t)(ent >> 16);
-                ent = ut[state];
-                r2 -= (int32_t)quad_bcast<3>(pre);
-                const int32_t di = r2 >> 5;
-                const uint32_t d0 = ringw[di], d1 = ringw[di + 1], d2 = ringw[di + 2];
-                win = (uint64_t)__builtin_amdgcn_alignbit(d1, d0, (uint32_t)r2) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, (uint32_t)r2) << 32);
-                if (SAFE && r2 < low57) win = 0;
-            };
-            const bool safe_row = act && (!full || r2 - 64 * (int32_t)SUB < low57);
-            if (__ballot(safe_row) == 0) {
-                if (sub < 4 && act) {
-#pragma unroll
-                    for (uint32_t j = 0; j < SUB; j++) lit_step(std::false_type{}, 4u * j);
-                    sidx += 4u * SUB;
-                }
-            } else {
-                if (sub < 4 && act) {
-                    const uint32_t g1 = n_row - g0 < SUB ? n_row : g0 + SUB;
-                    for (uint32_t g = g0; g < g1; g++) { lit_step(std::true_type{}, 0u); sidx += 4u; }
-                }
-            }
-            w.r2 = __shfl(r2, (int)rsh);   // (row-uniform again: the lanes that were off kept the old value)
-            const uint32_t g1 = g0 + SUB;
-            if ((g1 & 63) == 0) {
-                if (n_row >= g1) {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) out32[(g1 - 64) + 16 * q + sub] = reinterpret_cast<const uint32_t *>(stg)[16 * q + sub];
-                }
-                sidx = (uint32_t)sub;
-            }
-        }
-        if (n_row & 63) {
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                if ((uint32_t)(16 * q + sub) < (n_row & 63)) out32[(n_row & ~63u) + 16 * q + sub] = reinterpret_cast<const uint32_t *>(stg)[16 * q + sub];
-        }
-        if (!e && (w.r2 + 64 + 32 * w.cb - w.base_bit < 64)) e = LZFSE_MI_PAYLOAD_UNDERFLOW;   // bit_reader.rs:64-71
-        const uint32_t s0 = (uint32_t)__shfl((int)state, (int)rsh) | (uint32_t)__shfl((int)state, (int)rsh + 1) |
-                            (uint32_t)__shfl((int)state, (int)rsh + 2) | (uint32_t)__shfl((int)state, (int)rsh + 3);
-        if (!e && s0 != 0) e = LZFSE_MI_FSE_BAD_LMD_PAYLOAD;  // literals.rs:78-88
-#ifdef FSE4_DEBUG
-        if (sub == 0 && valid) printf("fse4 lit row %d blk %u: e %d n_row %u s0 %u rem-base %d\n", row, R.block, e, n_row, s0, w.r2 + 64 + 32 * w.cb - w.base_bit);
-#endif
-        if (sub == 0) L.status[1] = e;
-    } else {
-        // fse_core.rs:91-141 (entropy part): L, M, D in lanes 0, 1, 2 of the row
-        uint32_t *const ringw = L.pool;
-        uint32_t *const stg = L.pool + 256;
-        const bool lshort = R.lmd_short != 0;
-        RowWindow w;
-        w.r2 = 4096; w.cb = 0; w.base_bit = 0; w.ga = glo; w.pend[0] = w.pend[1] = w.pend[2] = w.pend[3] = 0;
-        int e = 0;
-        if (valid) {
-            if (lshort) e = LZFSE_MI_PAYLOAD_UNDERFLOW;
-            else e = rw_init(w, ringw, src + R.pos + R.lmd_off, R.lmd_len, R.lmd_bits, sub, glo, ghi);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t n_row = (valid && !e) ? R.lmd_num : 0u;
-        uint32_t n_max = n_row;
-        n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, 16));
-        n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, 32));
-        const int li = sub < 2 ? sub : 2;
-        uint32_t state = R.lmd_state[li];
-        const uint2 *const vt = L.v_tab + (li == 0 ? 0u : (li == 1 ? 64u : 128u));
-        const uint32_t smask = li == 2 ? 255u : 63u;
-        LmdRec *const out = lmd_out + R.lmd_base;
-        uint2 ent = vt[state];
-        uint64_t win;
-        {
-            const int32_t di = w.r2 >> 5;
-            const uint32_t d0 = ringw[di], d1 = ringw[di + 1], d2 = ringw[di + 2];
-            win = (uint64_t)__builtin_amdgcn_alignbit(d1, d0, (uint32_t)w.r2) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, (uint32_t)w.r2) << 32);
-        }
-        uint32_t sidx = (uint32_t)sub;
-        uint32_t cum_l = 0, acc_m = 0, carry_d = 0;   // row-uniform: literals so far, match bytes of this lane's records, last distance
-        uint32_t lit_over = 0xFFFFFFFFu;              // first LMD whose literals run past LITERALS_PER_BLOCK (fse_core.rs:119-128)
-        // 64 staged steps of a row -> 64 LMD records, 16 at a time by the row's lanes: D = 0 takes the previous distance
-        // (lmd_type.rs:153-160) by a row-local scan, the sums of L and M accumulate, the records are stored coalesced
-        auto flush = [&](bool doit, uint32_t base, uint32_t cnt) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t j = 16u * (uint32_t)q + (uint32_t)sub;
-                const bool have = doit && j < cnt;
-                const uint32_t vl = have ? stg[3 * j] : 0u, vm = have ? stg[3 * j + 1] : 0u, vd = have ? stg[3 * j + 2] : 0u;
-                const uint32_t rb = (uint32_t)(__ballot(vd != 0) >> rsh) & 0xFFFFu;
-                const uint32_t upto = rb & ((2u << sub) - 1u);
-                const uint32_t from = (uint32_t)__shfl((int)vd, (int)(rsh + (upto ? 31u - (uint32_t)__builtin_clz(upto) : (uint32_t)sub)));
-                const uint32_t dv = upto ? from : carry_d;
-                if (have) out[base + j] = make_uint2(vl | (vm << 16), dv);
-                const uint32_t il = row_incl_sum(vl);
-                const uint32_t orb = (uint32_t)(__ballot(have && cum_l + il > LITERALS_PER_BLOCK) >> rsh) & 0xFFFFu;
-                if (orb && lit_over == 0xFFFFFFFFu) lit_over = base + 16u * (uint32_t)q + (uint32_t)__builtin_ctz(orb);
-                cum_l += (uint32_t)__shfl((int)il, (int)rsh + 15);
-                acc_m += vm;
-                const uint32_t last = (uint32_t)__shfl((int)vd, (int)(rsh + (rb ? 31u - (uint32_t)__builtin_clz(rb) : 0u)));
-                if (rb) carry_d = last;
-            }
-        };
-        for (uint32_t i0 = 0; i0 < n_max; i0 += SUB) {
-            rw_refill(w, ringw, (int32_t)SUB, sub, glo, ghi);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const bool act = i0 < n_row, full = i0 + SUB <= n_row;
-            const int32_t low57 = w.base_bit + 57 - 64 - 32 * w.cb;
-            int32_t r2 = w.r2;
-            auto lmd_step = [&](auto safe_tag, uint32_t slot_off) {
-                constexpr bool SAFE = decltype(safe_tag)::value;
-                const uint32_t k = ent.x & 0xFF, vb = __builtin_amdgcn_ubfe(ent.x, 8u, 8u);
-                const uint32_t tot = k + vb;
-                uint32_t pre = tot + dpp_shr<1>(tot);
-                pre += dpp_shr<2>(tot);
-                const uint32_t x = (uint32_t)(win >> ((0u - pre) & 63));
-                const uint32_t extra = __builtin_amdgcn_ubfe(x, 0u, vb);
-                const uint32_t sb = __builtin_amdgcn_ubfe(x, vb, k);
-                state = (sb + (ent.x >> 16)) & smask;
-                stg[sidx + slot_off] = ent.y + extra;
-                ent = vt[state];
-                r2 -= (int32_t)quad_bcast<2>(pre);
-                const int32_t di = r2 >> 5;
-                const uint32_t d0 = ringw[di], d1 = ringw[di + 1], d2 = ringw[di + 2];
-                win = (uint64_t)__builtin_amdgcn_alignbit(d1, d0, (uint32_t)r2) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, (uint32_t)r2) << 32);
-                if (SAFE && r2 < low57) win = 0;
-            };
-            const bool safe_row = act && (!full || r2 - 64 * (int32_t)SUB < low57);
-            if (__ballot(safe_row) == 0) {
-                if (sub < 3 && act) {
-#pragma unroll
-                    for (uint32_t j = 0; j < SUB; j++) lmd_step(std::false_type{}, 3u * j);
-                    sidx += 3u * SUB;
-                }
-            } else {
-                if (sub < 3 && act) {
-                    const uint32_t i1 = n_row - i0 < SUB ? n_row : i0 + SUB;
-                    for (uint32_t i = i0; i < i1; i++) { lmd_step(std::true_type{}, 0u); sidx += 3u; }
-                }
-            }
-            w.r2 = __shfl(r2, (int)rsh);
-            const uint32_t i1 = i0 + SUB;
-            if ((i1 & 63) == 0) {
-                flush(n_row >= i1, i1 - 64, 64);
-                sidx = (uint32_t)sub;
-            }
-        }
-        flush((n_row & 63) != 0, n_row & ~63u, n_row & 63);
-        uint32_t sum_m = acc_m;
-#pragma unroll
-        for (int dd = 8; dd > 0; dd >>= 1) sum_m += (uint32_t)__shfl_xor((int)sum_m, dd);
-        const uint32_t sum_l = cum_l;
-        // order of the reference (fse_core.rs:91-141): reader init, then per LMD the literal_index test (and the match
-        // copy, whose BadDValue the LZ stage raises for the first ok_until LMDs), then reader.finalize, then the totals
-        uint32_t ok_until = 0;
-        if (!e) {
-            if (lit_over != 0xFFFFFFFFu) { e = LZFSE_MI_FSE_BAD_LMD_PAYLOAD; ok_until = lit_over; }
-            else {
-                ok_until = n_row;
-                if (w.r2 + 64 + 32 * w.cb - w.base_bit < 64) e = LZFSE_MI_PAYLOAD_UNDERFLOW;
-            }
-        }
-        const uint32_t s0 = (uint32_t)__shfl((int)state, (int)rsh) | (uint32_t)__shfl((int)state, (int)rsh + 1) | (uint32_t)__shfl((int)state, (int)rsh + 2);
-        if (!e && lit_over == 0xFFFFFFFFu && !(sum_l <= R.lit_num && sum_l + sum_m == R.n_raw && s0 == 0)) e = LZFSE_MI_FSE_BAD_LMD_PAYLOAD;
-#ifdef FSE4_DEBUG
-        if (sub == 0 && valid) printf("fse4 lmd row %d blk %u: e %d n_row %u sum_l %u sum_m %u lit_num %u n_raw %u s0 %u lit_over %u rem-base %d carry %u\n", row, R.block, e, n_row, sum_l, sum_m, R.lit_num, R.n_raw, s0, lit_over, w.r2 + 64 + 32 * w.cb - w.base_bit, carry_d);
-#endif
-        if (sub == 0) { L.status[0] = e; L.sums[0] = sum_l; L.sums[1] = sum_m; L.sums[2] = ok_until; }
-    }
-    __syncthreads();
-    if (tid < FSE_R && rows[tid].valid) {
-        const FseLds &Lr = lds[tid];
-        BlockResult r;
-        // literals are loaded before the LMD stream is touched (decoder.rs:127-141)
-        r.status = Lr.status[1] ? Lr.status[1] : Lr.status[0];
-        r.sum_l = Lr.sums[0]; r.sum_m = Lr.sums[1];
-        r.ok_until = Lr.status[1] ? 0u : Lr.sums[2];
-        results[rows[tid].block] = r;
-    }
-}
-
 // ------------------------------------------------------------------------------------ LZ stage
 
 // exactly n <= 24 bytes, given as three little-endian words, to byte-aligned LDS in at most five stores of 8 / 8 / 4 / 2 / 1 bytes
@@ -2333,22 +1974,14 @@ void launch_dec_emit(const StreamIn *streams, uint32_t n_streams, const StreamPl
 }
 
 void launch_dec_fse(const uint8_t *src, uint64_t src_total, const BlockDesc *blocks, uint32_t n_blocks,
-                    uint8_t *lit_out, LmdRec *lmd_out, BlockResult *results, uint32_t *order_hist, uint32_t *order, int force, hipStream_t st) {
+                    uint8_t *lit_out, LmdRec *lmd_out, BlockResult *results, uint32_t *order_hist, uint32_t *order, hipStream_t st) {
     if (!n_blocks) return;
     // order_hist: 64 zeroed words; order: n_blocks words
     hipLaunchKernelGGL(dec_order_count_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, st, blocks, n_blocks, order_hist);
     hipLaunchKernelGGL(dec_order_scan_kernel, dim3(1), dim3(64), 0, st, order_hist);
     hipLaunchKernelGGL(dec_order_place_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, st, blocks, n_blocks, order_hist, order);
-    // Four blocks per workgroup when the batch fills the chip (then the vector pipe is what a block costs); below that a
-    // block's own dependency chain sets the time, and one workgroup per block spreads them over more CUs.
-    // (force: 0 by the batch, 1 one block per workgroup, 2 four -- the diagnostic build's LZFSE_MI_OPT_DIAG_FSE)
-    const bool four = force == 2 || (force == 0 && n_blocks > 256u * 16u);
-    if (four)
-        hipLaunchKernelGGL(dec_fse4_kernel, dim3((n_blocks + FSE_R - 1) / FSE_R), dim3(FSE_THREADS), 0, st, src, src_total, blocks,
-                           n_blocks, lit_out, lmd_out, results, order);
-    else
-        hipLaunchKernelGGL(dec_fse_kernel, dim3(n_blocks), dim3(FSE_THREADS), 0, st, src, src_total, blocks,
-                           n_blocks, lit_out, lmd_out, results, order);
+    hipLaunchKernelGGL(dec_fse_kernel, dim3(n_blocks), dim3(FSE_THREADS), 0, st, src, src_total, blocks,
+                       n_blocks, lit_out, lmd_out, results, order);
 }
 
 void launch_dec_lz(int variant, const uint8_t *src, const StreamIn *streams, const StreamPlan *plan,

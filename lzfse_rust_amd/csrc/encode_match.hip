@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint32_t dk = ln[k] ? i - cc[k] : NONE;
-        const uint32_t dlo = __shfl_up(dk, 1);
+        const uint32_t dlo = dpp_take<0x138, 0xF>(NONE, dk);   // wave_shr:1 -- one vector instruction; __shfl_up is a trip through the LDS crossbar
         fol[k] = ln[k] != 0 && lane > 0 && dlo == dk;
     }
     // ---- phase 2: the first CAND_C1 bytes of all heads together. A candidate's bytes come from ONE dword-aligned 16-byte
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
     {
         constexpr uint32_t BW_CALC = 16;   // two 8-byte steps; stored as min(.., BCAP)
         const uint32_t bd = best_len ? i - best_idx : NONE;
-        const uint32_t bd_lo = __shfl_up(bd, 1);
+        const uint32_t bd_lo = dpp_take<0x138, 0xF>(NONE, bd);
         const bool bfol = best_len != 0 && lane > 0 && bd_lo == bd;
         const uint32_t bmax = best_idx < BW_CALC ? best_idx : BW_CALC;
         uint32_t bw = 0;

@@ -50,7 +50,7 @@ void launch_dec_fastwalk(const uint8_t *src, const StreamIn *streams, const uint
 void launch_dec_emit(const StreamIn *streams, uint32_t n_streams, const StreamPlan *plan, const BlockDesc *cache, uint64_t cache_total,
                      BlockDesc *blocks, hipStream_t st);
 void launch_dec_fse(const uint8_t *src, uint64_t src_total, const BlockDesc *blocks, uint32_t n_blocks,
-                    uint8_t *lit_out, LmdRec *lmd_out, BlockResult *results, uint32_t *order_hist, uint32_t *order, int force, hipStream_t st);
+                    uint8_t *lit_out, LmdRec *lmd_out, BlockResult *results, uint32_t *order_hist, uint32_t *order, hipStream_t st);
 void launch_dec_lz(int variant, const uint8_t *src, const StreamIn *streams, const StreamPlan *plan,
                    uint32_t n_streams, const BlockDesc *blocks, const BlockResult *bres, const LmdRec *lmds,
                    const uint8_t *lits, uint8_t *dst, StreamResult *sres, hipStream_t st);

@@ -220,11 +220,10 @@ def test_decode_many_tiny_blocks_rewalk(ctx, oracle, snappy_raw):
     assert len(outs[1]) == 3000 and len(outs[3]) == 1500
 
 
-def test_entropy_stage_one_and_four_blocks_per_workgroup(diag_ctx, oracle, golden_dir, snappy_raw):
-    """dec_fse_kernel (one block per workgroup) and dec_fse4_kernel (four blocks per workgroup, one per row of 16 lanes) are
-    chosen by the size of the batch; the diagnostic build forces either. Both must give the oracle's bytes and status
-    codes: every fixture, multi-block streams whose blocks differ in length, blocks cut short, damaged payloads (the
-    run-out rule of the bit reader, literals past the block limit, bad final states), counts that are not multiples of 4."""
+def test_entropy_stage_damaged_and_cut_blocks(diag_ctx, oracle, golden_dir, snappy_raw):
+    """The entropy stage on what its fast path must hand to the careful one: every fixture, multi-block streams whose blocks
+    differ in length, blocks cut short, damaged payloads (the run-out rule of the bit reader, literals past the block limit,
+    bad final states) -- the oracle's bytes and status codes."""
     import glob
     import os
     rng = np.random.default_rng(77)
@@ -251,13 +250,8 @@ def test_entropy_stage_one_and_four_blocks_per_workgroup(diag_ctx, oracle, golde
     for s in srcs:
         st = oracle.decode_status(s, cap)
         want.append((st, oracle.decode(s, cap=cap) if st == 0 else None))
-    try:
-        for mode in (1, 2):
-            diag_ctx.set_option("diag_fse", mode)
-            outs, st = diag_ctx.decode_batch(srcs, caps=[cap] * len(srcs))
-            for i, (o, e) in enumerate(zip(outs, st)):
-                assert e == want[i][0], (mode, i, e, want[i][0])
-                if e == 0:
-                    assert o.tobytes() == want[i][1], (mode, i)
-    finally:
-        diag_ctx.set_option("diag_fse", 0)
+    outs, st = diag_ctx.decode_batch(srcs, caps=[cap] * len(srcs))
+    for i, (o, e) in enumerate(zip(outs, st)):
+        assert e == want[i][0], (i, e, want[i][0])
+        if e == 0:
+            assert o.tobytes() == want[i][1], i
