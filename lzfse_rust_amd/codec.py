@@ -309,7 +309,8 @@ class LzfseRingDecoder:
 
         def _write(_user, p, n):
             try:
-                writer.write(C.string_at(p, n))
+                # (a view of the library's buffer, valid during the call: the writer takes its copy, no second one is made here)
+                writer.write(memoryview((C.c_uint8 * n).from_address(C.addressof(p.contents))) if n else b"")
                 return 0
             except Exception as e:   # the sink's error travels back through the C layer as LZFSE_MI_IO
                 failure.append(e)

@@ -968,6 +968,18 @@ static uint64_t staged_at(const std::vector<CopyJob> &jobs, const std::vector<ui
     return stage[k] + (pos - pre[k]);
 }
 
+// Streams of this size and more travel by ONE DMA each straight between the caller's buffer and device memory: the
+// runtime's own transfer of pageable memory runs at the link's rate (56 GB/s both ways for 8 MiB .. 1 GiB on this pool,
+// pinned or not, scripts/pcie_probe.py -> profiles/r03_pcie_probe.txt), so a staging copy through this library's pinned
+// buffers only adds a pass over the bytes. A transfer call costs 16 (in) / 27 (out) microseconds, which is the time of
+// half a megabyte: smaller streams are packed into the pinned granules as before (3 072 x 245 KiB moved one by one: 15 / 9 GB/s).
+#ifndef HOST_DIRECT_IN
+#define HOST_DIRECT_IN ((uint64_t)1 << 20)
+#endif
+#ifndef HOST_DIRECT_OUT
+#define HOST_DIRECT_OUT ((uint64_t)1 << 20)
+#endif
+
 static int host_batch_one(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, size_t count, const uint8_t *const *srcs,
                           const size_t *lens, uint8_t *const *dsts, const size_t *caps, size_t *out_lens,
                           int *statuses, const std::function<void()> *on_staged) {
@@ -975,29 +987,35 @@ static int host_batch_one(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, s
     if (count == 0) { if (on_staged) (*on_staged)(); return LZFSE_MI_OK; }
     HIP_TRY(hipSetDevice(c->device));
     std::vector<uint64_t> so(count), sl(count), dof(count), dc(count), ol(count);
-    uint64_t in_total = 0, out_total = 0;
-    for (size_t i = 0; i < count; i++) {
-        so[i] = in_total; sl[i] = lens[i];
-        in_total += (lens[i] + 255) & ~(uint64_t)255;
-        dof[i] = out_total; dc[i] = caps[i];
-        out_total += (caps[i] + 255) & ~(uint64_t)255;
+    // device layout: the staged (small) streams first, in the caller's order, then the direct (large) ones
+    uint64_t in_total = 0, out_total = 0, in_staged = 0, out_staged = 0;
+    for (int big = 0; big < 2; big++) {
+        for (size_t i = 0; i < count; i++)
+            if ((lens[i] >= HOST_DIRECT_IN) == (big != 0)) { so[i] = in_total; sl[i] = lens[i]; in_total += (lens[i] + 255) & ~(uint64_t)255; }
+        if (!big) in_staged = in_total;
     }
-    if (!c->d_in.ensure(in_total + 256) || !c->d_out.ensure(out_total + 256) || !c->h_in.ensure(in_total + 256) ||
-        !c->h_out.ensure(out_total + 256))
+    for (int big = 0; big < 2; big++) {
+        for (size_t i = 0; i < count; i++)
+            if ((caps[i] >= HOST_DIRECT_OUT) == (big != 0)) { dof[i] = out_total; dc[i] = caps[i]; out_total += (caps[i] + 255) & ~(uint64_t)255; }
+        if (!big) out_staged = out_total;
+    }
+    if (!c->d_in.ensure(in_total + 256) || !c->d_out.ensure(out_total + 256) || !c->h_in.ensure(in_staged + 256))
         return LZFSE_MI_IO;
     std::vector<CopyJob> jobs;
     std::vector<uint64_t> pre, stage;   // per job: first byte in the concatenation, offset in the staging buffer
     jobs.reserve(count); pre.reserve(count + 1); stage.reserve(count);
-    // ---- in: granules of HOST_GROUP bytes (a large stream is several); the DMA of one runs under the staging copy of the next ----
+    // ---- in: granules of HOST_GROUP bytes; the DMA of one runs under the staging copy of the next ----
     uint64_t n_in = 0;
     for (size_t i = 0; i < count; i++)
-        if (lens[i]) { jobs.push_back({(uint8_t *)c->h_in.p + so[i], srcs[i], lens[i]}); pre.push_back(n_in); stage.push_back(so[i]); n_in += lens[i]; }
+        if (lens[i] && lens[i] < HOST_DIRECT_IN) { jobs.push_back({(uint8_t *)c->h_in.p + so[i], srcs[i], lens[i]}); pre.push_back(n_in); stage.push_back(so[i]); n_in += lens[i]; }
     for (uint64_t lo = 0; lo < n_in; lo += HOST_GROUP) {
         const uint64_t hi = std::min(n_in, lo + HOST_GROUP);
         par_copy(c, jobs, pre, lo, hi);
         const uint64_t a = staged_at(jobs, pre, stage, lo), b = staged_at(jobs, pre, stage, hi - 1) + 1;
         HIP_TRY(hipMemcpyAsync((uint8_t *)c->d_in.p + a, (uint8_t *)c->h_in.p + a, b - a, hipMemcpyHostToDevice, c->stream));
     }
+    for (size_t i = 0; i < count; i++)
+        if (lens[i] >= HOST_DIRECT_IN) HIP_TRY(hipMemcpyAsync((uint8_t *)c->d_in.p + so[i], srcs[i], lens[i], hipMemcpyHostToDevice, c->stream));
     if (on_staged) (*on_staged)();   // (the inputs are on their way: the other half of a split call may start staging)
     int r = fn(c, count, c->d_in.p, so.data(), sl.data(), c->d_out.p, dof.data(), dc.data(), ol.data(), statuses);
     if (r) return r;
@@ -1013,16 +1031,26 @@ static int host_batch_one(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, s
     }
     if (!produced) return LZFSE_MI_OK;
     const uint8_t *d_from = (const uint8_t *)c->d_out.p;
+    uint64_t staged_span = out_staged;      // the staged outputs lie in [0, staged_span) of the buffer that travels
+    std::vector<uint8_t> big_out(count);    // which outputs travel by a transfer of their own: by capacity (the layout) ...
+    for (size_t i = 0; i < count; i++) big_out[i] = caps[i] >= HOST_DIRECT_OUT;
     if (pack_outputs && fits32 && produced + (produced >> 2) < hi_off) {
         uint64_t pk = 0;
         std::vector<SmallDesc> desc;
         std::vector<uint64_t> packed(count, 0);
         desc.reserve(count);
-        for (size_t i = 0; i < count; i++) {
-            packed[i] = pk;
-            if (!out_lens[i]) continue;
-            desc.push_back({dof[i], pk, (uint32_t)out_lens[i], 0u});
-            pk += (out_lens[i] + 15) & ~(uint64_t)15;
+        uint64_t pk_staged = 0;
+        // ... or, when the outputs are packed anyway (encoded streams: a third of their capacity), by what they really hold
+        for (size_t i = 0; i < count; i++) big_out[i] = out_lens[i] >= HOST_DIRECT_OUT;
+        for (int big = 0; big < 2; big++) {   // (staged streams first)
+            for (size_t i = 0; i < count; i++) {
+                if ((big_out[i] != 0) != (big != 0)) continue;
+                packed[i] = pk;
+                if (!out_lens[i]) continue;
+                desc.push_back({dof[i], pk, (uint32_t)out_lens[i], 0u});
+                pk += (out_lens[i] + 15) & ~(uint64_t)15;
+            }
+            if (!big) pk_staged = pk;
         }
         // (the inputs are dead: the packed copy takes their place, its descriptors behind it)
         const uint64_t desc_at = (pk + 255) & ~(uint64_t)255;
@@ -1034,13 +1062,17 @@ static int host_batch_one(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, s
             HIP_TRY(hipStreamSynchronize(c->stream));   // (`desc` is pageable memory of this scope)
             d_from = (const uint8_t *)c->d_in.p;
             at = packed;
+            staged_span = pk_staged;
+        } else {
+            for (size_t i = 0; i < count; i++) big_out[i] = caps[i] >= HOST_DIRECT_OUT;
         }
     }
+    if (!c->h_out.ensure(staged_span + 256)) return LZFSE_MI_IO;
     // ---- granules again: every DMA is queued, and a granule is copied to its destinations as soon as it has arrived ----
     jobs.clear(); pre.clear(); stage.clear();
     uint64_t n_out = 0;
     for (size_t i = 0; i < count; i++)
-        if (out_lens[i]) { jobs.push_back({dsts[i], (const uint8_t *)c->h_out.p + at[i], out_lens[i]}); pre.push_back(n_out); stage.push_back(at[i]); n_out += out_lens[i]; }
+        if (out_lens[i] && !big_out[i]) { jobs.push_back({dsts[i], (const uint8_t *)c->h_out.p + at[i], out_lens[i]}); pre.push_back(n_out); stage.push_back(at[i]); n_out += out_lens[i]; }
     const size_t n_gran = (size_t)((n_out + HOST_GROUP - 1) / HOST_GROUP);
     while (c->host_ev.size() < n_gran) {
         hipEvent_t e;
@@ -1053,11 +1085,20 @@ static int host_batch_one(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, s
         HIP_TRY(hipMemcpyAsync((uint8_t *)c->h_out.p + a, d_from + a, b - a, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipEventRecord(c->host_ev[g], c->stream));
     }
+    // the large streams go straight into the caller's buffers (behind the granules on the stream: those are unpacked by the
+    // helper threads while these travel)
+    bool any_direct = false;
+    for (size_t i = 0; i < count; i++)
+        if (out_lens[i] && big_out[i]) {
+            HIP_TRY(hipMemcpyAsync(dsts[i], d_from + at[i], out_lens[i], hipMemcpyDeviceToHost, c->stream));
+            any_direct = true;
+        }
     for (size_t g = 0; g < n_gran; g++) {
         HIP_TRY(hipEventSynchronize(c->host_ev[g]));
         const uint64_t lo = g * HOST_GROUP;
         par_copy(c, jobs, pre, lo, std::min(n_out, lo + HOST_GROUP));
     }
+    if (any_direct) HIP_TRY(hipStreamSynchronize(c->stream));
     return LZFSE_MI_OK;
 }
 

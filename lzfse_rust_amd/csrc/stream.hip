@@ -2,7 +2,7 @@
 // (decode/ring_decoder.rs:58-68) -- the same block loop as the slice path (decode/decoder.rs:73-99: blocks until bvx$,
 // which must be the last 4 bytes of the input) over a source that arrives in pieces and a sink that takes the output in
 // pieces. Host code over the public entry points: the input is cut at block boundaries, every window of complete blocks
-// (LZFSE_MI_STREAM_WINDOW = 16 MiB of raw bytes unless the caller says otherwise) is decoded as one stream on the device, and the 262 139 bytes a match may
+// (LZFSE_MI_STREAM_WINDOW = 64 MiB of raw bytes unless the caller says otherwise) is decoded as one stream on the device, and the 262 139 bytes a match may
 // reach back (fse/constants.rs:42) travel with it as a leading raw block (bvx-), so no kernel knows about windows. The
 // first error in stream order is reported with the slice path's code: the windows before it decoded cleanly, and the
 // window that holds it is decoded by the same kernels.

@@ -252,3 +252,30 @@ def test_bvxn_header_that_promises_gigabytes(ctx, oracle):
                 m.LzfseRingDecoder(context=ctx).decode(PieceReader(stream, sizes), io.BytesIO())
             assert e.value.status == want
         assert resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - before < (256 << 10)   # KiB: no gigabyte was allocated
+
+
+def test_fuzz_read(ctx, oracle):
+    """test/src/fuzz_read.rs:8-33 at the reference's size: 8 MiB of Seq encoded by the slice encoder, read back through
+    LzfseRingDecoder::reader in random-length reads of (gen % 0x20) * multiplier bytes until a read comes back short.
+    Multipliers 0x100 / 0x1000 / 0x10000 with the reference's seeds 0 .. (a few each: its 0x100 seeds per multiplier only
+    vary the read lengths; 1 and 0x10 are half a million Python calls a seed), plus one seed of 0x10."""
+    import lzfse_rust_amd as m
+    import test_kit as tk
+    data = tk.seq(0x0080_0000)
+    enc = bytearray()
+    m.LzfseEncoder(context=ctx).encode_bytes(data, enc)
+    assert bytes(enc) == oracle.encode(data)
+    dec = m.LzfseRingDecoder(context=ctx)
+    for mult, seeds in ((0x10, 1), (0x100, 2), (0x1000, 4), (0x10000, 6)):
+        for seed in range(seeds):
+            rdr = dec.reader(io.BytesIO(bytes(enc)))
+            rng = tk.Rng(seed)
+            got = bytearray()
+            while True:
+                n = (rng.gen() % 0x20) * mult
+                piece = rdr.read(n)
+                got += piece
+                if len(piece) != n:
+                    break
+            rdr.into_inner()
+            assert bytes(got) == data, (mult, seed)
