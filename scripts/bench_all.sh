@@ -1,7 +1,7 @@
 #!/bin/bash
 # Every bench line of a round besides the default one (scripts/profile_all.sh): the other BASELINE configs, the small
 # batch, and the per-file table. Outputs: gpurun_out/all_$TAG/*.json (copy what is to be judged into profiles/).
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/all_$TAG
 mkdir -p $OUT
 for w in text64m chunks4m chunks1g; do
@@ -10,6 +10,9 @@ for w in text64m chunks4m chunks1g; do
 done
 timeout -k 10 300 python bench.py --replicas 64 --steps 5 --warmup 1 > $OUT/bench_snappy_r64.json 2> $OUT/bench_snappy_r64.err || exit 1
 timeout -k 10 300 python bench.py --per-file 256 > $OUT/snappy_table.json 2> $OUT/snappy_table.err || exit 1
+timeout -k 10 300 python bench.py --per-file 64 > $OUT/snappy_table_r64.json 2> $OUT/snappy_table_r64.err || exit 1
+timeout -k 10 300 python bench.py --per-file 16 > $OUT/snappy_table_r16.json 2> $OUT/snappy_table_r16.err || exit 1
+echo "tables done" >> $OUT/progress.txt
 for f in $OUT/bench_*.json; do python - "$f" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

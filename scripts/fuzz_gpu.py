@@ -1,5 +1,7 @@
 """One-off randomised parity campaign on a GPU box (not part of the test-suite: the suite's cases are fixed):
-    python scripts/fuzz_gpu.py [ROUNDS] [SEED] [walk|pipe|big]  (walk: the diagnostic build, every stream through the parallel header walk first;
+    python scripts/fuzz_gpu.py [ROUNDS] [SEED] [walk|pipe|big|ring]  (ring: the streams are ALSO encoded with the ring / stream encoder's parse and
+                                                              compared with the restated frontend_ring.rs; lengths reach across the 512 KiB ring;
+                                                              walk: the diagnostic build, every stream through the parallel header walk first;
                                                               pipe: every stream of the tile kernel through the pipelined LZ kernel, K and tile size changing per round;
                                                               big: 2 to 9 streams of 2 .. 24 MiB per round: pointer jumping, the parallel header walk and several
                                                               workgroups per stream, as the cost model mixes them)
@@ -23,6 +25,7 @@ else:
     ctx = lz.Context(0)
 PIPE = len(sys.argv) > 3 and sys.argv[3] == "pipe"
 BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
+RING = len(sys.argv) > 3 and sys.argv[3] == "ring"
 rng = np.random.default_rng(seed)
 words = [bytes(rng.integers(97, 123, size=int(rng.integers(1, 12)), dtype=np.uint8)) for _ in range(800)]
 TILE = 65472
@@ -62,6 +65,8 @@ def length():
         return int(TILE * rng.integers(1, 6) + 3 + rng.integers(-3, 70))
     if r < 0.3:
         return int(rng.integers(4097, 20000))
+    if RING and r < 0.5:   # around the ring size and the round ends (multiples of 16 KiB beyond 512 KiB)
+        return int(0x80000 + 0x4000 * rng.integers(-2, 40) + rng.integers(-40, 41))
     if r < 0.9:
         return int(rng.integers(20000, 600000))
     return int(rng.integers(600000, 3 << 20))
@@ -80,6 +85,17 @@ for rd in range(rounds):
     assert all(e == 0 for e in st), st
     for i, (r, o, w) in enumerate(zip(raws, outs, want)):
         assert o.tobytes() == w, f"round {rd}: encode differs, stream {i} of {len(r)} bytes"
+    if RING:
+        rwant = [O.ring_encode(r) for r in raws]
+        routs, rst = ctx.encode_batch(raws, ring=True)
+        assert all(e == 0 for e in rst), rst
+        for i, (r, o, w) in enumerate(zip(raws, routs, rwant)):
+            assert o.tobytes() == w, f"round {rd}: ring encode differs, stream {i} of {len(r)} bytes"
+        # small size classes too
+        smalls = [gen(int(rng.integers(0, 7)), int(rng.integers(0, 4097))) for _ in range(60)]
+        souts, sst = ctx.encode_batch(smalls, ring=True)
+        for r, o in zip(smalls, souts):
+            assert o.tobytes() == O.ring_encode(r), f"round {rd}: ring encode differs, small stream of {len(r)} bytes"
     dec, st2 = ctx.decode_batch(want)
     assert all(e == 0 for e in st2)
     for r, o in zip(raws, dec):

@@ -15,5 +15,7 @@ timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write --output-format c
 python scripts/summarize_pmc.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json 4 > $OUT/pmc_summary.txt
 timeout -k 10 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d $OUT/pmc_sq --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $OUT/pmc_sq.log 2>&1 || exit 1
 python scripts/pmc_generic.py $OUT/pmc_sq > $OUT/sq_counters.txt
-rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
+echo "sq done" >> $OUT/progress.txt
+timeout -k 10 400 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d $OUT/pmc_cache --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --lanes 1 > $OUT/pmc_cache.log 2>&1 && python scripts/pmc_generic.py $OUT/pmc_cache > $OUT/cache_counters.txt
+rm -rf $OUT/pmc_cache $OUT/stats $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
 tail -1 $OUT/bench.log | cut -c1-400

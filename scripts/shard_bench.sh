@@ -9,7 +9,7 @@ python bench.py --workload chunks1g --no-cpu-baseline --no-extras > $OUT/shard_1
 for N in 2 4 8; do
   python bench.py --workload chunks1g --emulate-world $N --no-cpu-baseline --no-extras > $OUT/shard_$N.json 2>> $OUT/err.log || exit 1
 done
-python - "$OUT" <<'PY'
+python - "$OUT" > $OUT/summary.txt <<'PY'
 import json, sys
 o = sys.argv[1]
 base = json.load(open(f"{o}/shard_1.json"))
@@ -18,3 +18,4 @@ for n in (1, 2, 4, 8):
     print(f"N={n}: {d['config']['streams_rank0']:4d} streams  value {d['value']/1e3:6.2f} GB/s  encode {d['encode_MBps']/1e3:6.2f}  decode {d['decode_MBps']/1e3:6.2f}"
           f"  -> {n} ranks at this rate = {n * d['value'] / base['value']:.2f} x one GPU ({100 * d['value'] / base['value']:.0f} % efficiency)")
 PY
+cat $OUT/summary.txt
