@@ -481,6 +481,21 @@ def pcie_inclusive(ctx, lz, batch_raw):
             "sample": f"{n} streams, {raw} raw bytes through lzfse_mi_encode_batch / _decode_batch (host pointers), best of 3"}
 
 
+def cpu_quota():
+    """CPUs this process may use at once (the cgroup's quota), or None when unlimited / unknown."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())        # cgroup v1
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
+
+
 def cpu_baseline(sample):
     """The oracle (C restatement of lzfse_rust's CPU path; the reference itself cannot be built: no Rust toolchain)
     timed on this box's host cores by oracle/lzo_bench.c: pthreads that loop over their own streams for the whole
@@ -514,13 +529,19 @@ def cpu_baseline(sample):
         e, d = rates
         return 1.0 / (1.0 / e + 1.0 / d), e, d     # encode + decode of the same bytes, one after the other
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    visible = cores
+    quota = cpu_quota()
+    if quota and quota < cores:
+        cores = max(1, int(quota + 0.5))   # the box's CPU share: more threads than that only take turns
     v1, e1, d1 = run(1, 4.0)
     vn, en, dn = run(cores, 5.0) if cores > 1 else (v1, e1, d1)
     return {"value": round(vn, 2), "unit": "MB/s", "cores": cores, "kind": "port",
             "encode_MBps": round(en, 2), "decode_MBps": round(dn, 2),
             "single_thread": {"value": round(v1, 2), "encode_MBps": round(e1, 2), "decode_MBps": round(d1, 2)},
             "threads_over_single": {"encode": round(en / e1, 1), "decode": round(dn / d1, 1)},
-            "sample": f"{n} stream(s), {nbytes} raw bytes; per direction ~4 s on 1 thread and ~5 s on {cores} pthreads, every "
+            "cpus_visible": visible, "cpu_quota": quota,
+            "sample": f"{n} stream(s), {nbytes} raw bytes; per direction ~4 s on 1 thread and ~5 s on {cores} pthreads (cores = threads used: "
+                      f"the cgroup's CPU quota when there is one, else the CPUs visible), every "
                       "thread looping over its own streams for the whole budget (oracle/lzo_bench.c, no Python in the "
                       "loop); value = 1 / (1/encode + 1/decode); gcc -O3 -march=native C restatement of lzfse_rust's slice "
                       "path (oracle/)"}

@@ -4,6 +4,7 @@ TAG=${1:-r03}
 cd "$(dirname "$0")/.."
 export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 bash scripts/profile_all.sh $TAG || exit 1
+cp gpurun_out/prof_$TAG/pmc_traffic.json profiles/${TAG}_pmc_traffic.json
 python bench.py > gpurun_out/prof_$TAG/bench_final.json 2> gpurun_out/prof_$TAG/bench_final.err || exit 1
 echo "final bench done" >> gpurun_out/prof_$TAG/progress.txt
 bash scripts/bench_all.sh $TAG || exit 1
