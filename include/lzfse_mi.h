@@ -231,13 +231,18 @@ LZFSE_MI_API int lzfse_mi_encode_ring_batch_device(lzfse_mi_ctx *ctx, size_t cou
                                                    const uint64_t *src_off, const uint64_t *src_len, void *d_dst,
                                                    const uint64_t *dst_off, const uint64_t *dst_cap,
                                                    uint64_t *out_lens, int *statuses);
-/* LzfseWriter: feed = Write::write (any piece sizes), finish = finalize(): the stream leaves through `write` (which
+/* LzfseWriter: feed = Write::write (any piece sizes), finish = finalize(); the stream leaves through `write` (which
  * returns 0 to go on; anything else ends the call with LZFSE_MI_IO), *bytes_in / *bytes_out are the (u64, u64)
- * LzfseRingEncoder::encode returns. The parse needs the 256 KiB behind and ahead of a position, so the device does it
- * when the input is complete: feed stores, finish encodes (memory: the input, once). A stream object is used once. */
+ * LzfseRingEncoder::encode returns. The input is encoded a WINDOW at a time (`window` new bytes per device call, 0 =
+ * LZFSE_MI_STREAM_WINDOW, at least 1 MiB): the reference's ring encoder decides everything about a position from the 256 KiB
+ * behind and ahead of it, so the blocks of a window that end more than that before its last byte are final -- they leave
+ * through `write` during feed, and the object keeps only what the parse may still reach back to (328 KiB) plus the input it
+ * has not finished with. Memory: about window + 600 KiB of input and one window's output, whatever the length of the
+ * stream (inputs that are a few matches of many MiB each can take longer to yield a final block; the window grows then).
+ * The bytes are those of lzfse_mi_encode_ring on the whole input, whatever the window and the pieces. Used once. */
 typedef struct lzfse_mi_estream lzfse_mi_estream;
-LZFSE_MI_API int lzfse_mi_estream_create(lzfse_mi_ctx *ctx, lzfse_mi_estream **out);
-LZFSE_MI_API int lzfse_mi_estream_feed(lzfse_mi_estream *s, const uint8_t *src, size_t n);
+LZFSE_MI_API int lzfse_mi_estream_create(lzfse_mi_ctx *ctx, size_t window, lzfse_mi_estream **out);
+LZFSE_MI_API int lzfse_mi_estream_feed(lzfse_mi_estream *s, const uint8_t *src, size_t n, lzfse_mi_write_fn write, void *user);
 LZFSE_MI_API int lzfse_mi_estream_finish(lzfse_mi_estream *s, lzfse_mi_write_fn write, void *user, uint64_t *bytes_in,
                                          uint64_t *bytes_out);
 LZFSE_MI_API void lzfse_mi_estream_destroy(lzfse_mi_estream *s);

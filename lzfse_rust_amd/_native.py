@@ -102,9 +102,9 @@ def _load(path):
     L.lzfse_mi_dstream_destroy.restype = None
     L.lzfse_mi_dstream_destroy.argtypes = [vp]
     L.lzfse_mi_estream_create.restype = C.c_int
-    L.lzfse_mi_estream_create.argtypes = [vp, C.POINTER(vp)]
+    L.lzfse_mi_estream_create.argtypes = [vp, sz, C.POINTER(vp)]
     L.lzfse_mi_estream_feed.restype = C.c_int
-    L.lzfse_mi_estream_feed.argtypes = [vp, vp, sz]
+    L.lzfse_mi_estream_feed.argtypes = [vp, vp, sz, WRITE_FN, vp]
     L.lzfse_mi_estream_finish.restype = C.c_int
     L.lzfse_mi_estream_finish.argtypes = [vp, WRITE_FN, vp, u64p, u64p]
     L.lzfse_mi_estream_destroy.restype = None

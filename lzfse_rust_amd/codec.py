@@ -200,12 +200,13 @@ class LzfseRingEncoder:
     encoder's (ring_encoder.rs:71-73); writer(inner) / writer_bytes(vec) give the Write front ends. The streams are the
     ring front end's (encode/frontend_ring.rs), not the slice encoder's bytes."""
 
-    def __init__(self, device=0, context=None, read_size=1 << 20):
+    def __init__(self, device=0, context=None, read_size=1 << 20, window=0):
         self._ctx = context or Context(device)
         self._read_size = read_size
+        self._window = window    # input bytes per device call (0 = 64 MiB)
 
     def encode(self, reader, writer):
-        w = LzfseWriter(self._ctx, writer)
+        w = LzfseWriter(self._ctx, writer, self._window)
         n_in = 0
         while True:
             piece = reader.read(self._read_size)
@@ -220,28 +221,46 @@ class LzfseRingEncoder:
 
     def writer(self, inner):
         """LzfseRingEncoder::writer (ring_encoder.rs:79-84)"""
-        return LzfseWriter(self._ctx, inner)
+        return LzfseWriter(self._ctx, inner, self._window)
 
     def writer_bytes(self, vec):
         """LzfseRingEncoder::writer_bytes (ring_encoder.rs:91-96): `vec` (a bytearray) is appended to"""
-        return LzfseWriterBytes(self._ctx, vec)
+        return LzfseWriterBytes(self._ctx, vec, self._window)
 
 
 class LzfseWriter:
-    """encode/writer.rs:12-75: write(buf) takes all of buf, flush() does nothing, finalize() ends the stream (the
-    bytes reach `inner` then) and returns `inner`. Dropping a writer without finalize() loses the stream, as in the
-    reference (writer.rs:36-38)."""
+    """encode/writer.rs:12-75: write(buf) takes all of buf, flush() does nothing, finalize() ends the stream and returns
+    `inner`. The stream reaches `inner` a window at a time (`window` input bytes per device call, 0 = 64 MiB): the blocks
+    no later input can change leave during write(), the rest at finalize(). Dropping a writer without finalize() loses
+    the end of the stream, as in the reference (writer.rs:36-38)."""
 
-    def __init__(self, context, inner):
+    def __init__(self, context, inner, window=0):
         self._ctx, self._inner = context, inner
         self._lib = context._lib
         self._h = C.c_void_p()
-        _check(self._lib.lzfse_mi_estream_create(context._h, C.byref(self._h)))
+        self._failure = []
+
+        def _write(_user, p, n):
+            try:
+                self._sink(C.string_at(p, n))
+                return 0
+            except Exception as e:   # the sink's error travels back through the C layer as LZFSE_MI_IO
+                self._failure.append(e)
+                return 1
+
+        self._cb = _native.WRITE_FN(_write)
+        _check(self._lib.lzfse_mi_estream_create(context._h, window, C.byref(self._h)))
         self.bytes_out = 0
 
     def write(self, buf):
-        a = np.frombuffer(bytes(buf), dtype=np.uint8)
-        _check(self._lib.lzfse_mi_estream_feed(self._h, a.ctypes.data if a.size else None, a.size))
+        try:
+            a = np.frombuffer(buf, dtype=np.uint8)     # (no copy: the library takes the bytes into its own buffer)
+        except (TypeError, ValueError):
+            a = np.frombuffer(bytes(buf), dtype=np.uint8)
+        st = self._lib.lzfse_mi_estream_feed(self._h, a.ctypes.data if a.size else None, a.size, self._cb, None)
+        if self._failure:
+            raise self._failure.pop()
+        _check(st)
         return a.size
 
     def flush(self):
@@ -251,24 +270,13 @@ class LzfseWriter:
         self._inner.write(piece)
 
     def finalize(self):
-        failure = []
-
-        def _write(_user, p, n):
-            try:
-                self._sink(C.string_at(p, n))
-                return 0
-            except Exception as e:   # the sink's error travels back through the C layer as LZFSE_MI_IO
-                failure.append(e)
-                return 1
-
-        cb = _native.WRITE_FN(_write)
         u, v = C.c_uint64(0), C.c_uint64(0)
         try:
-            st = self._lib.lzfse_mi_estream_finish(self._h, cb, None, C.byref(u), C.byref(v))
+            st = self._lib.lzfse_mi_estream_finish(self._h, self._cb, None, C.byref(u), C.byref(v))
         finally:
             self.close()
-        if failure:
-            raise failure[0]
+        if self._failure:
+            raise self._failure.pop()
         _check(st)
         self.bytes_out = v.value
         return self._inner

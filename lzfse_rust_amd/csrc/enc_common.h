@@ -50,27 +50,41 @@ __device__ __forceinline__ uint32_t seen_make(uint32_t off1, uint32_t v) { retur
 constexpr uint32_t RING_SIZE = 0x80000u, RING_BLK = 0x4000u, RING_HALF = RING_SIZE / 2;
 constexpr uint32_t RING_FIRST_END = RING_HALF + RING_BLK;                    // end of round 0
 constexpr uint32_t RING_LONG_MATCH = RING_HALF - RING_BLK - 44u;             // LONG_MATCH_LEN (:110), OVERMATCH_SLACK = 4 + 40 (:21)
+// A WINDOW of a longer stream (lzfse_mi_estream_*: the stream encoder feeds the device in windows) carries ring = 3: its
+// positions are relative to a base that is a multiple of RING_BLK and lies beyond the first ring, so the two rules about
+// the beginning of a stream (round 0 is longer; the ring has not wrapped yet) do not apply, and every other rule is
+// invariant under such a shift. n is then the end of the data the window holds.
+constexpr uint32_t RING_CONT = 2u;
 struct RingGeo {
     uint32_t head, tail;
     bool is_short;     // matched by match_short: forward length limited by the end of the input, not by LONG_MATCH_LEN
+    bool wrapped;      // whatever lies one ring before a position past the tail is input (not the zeros of a fresh ring)
 };
 __host__ __device__ __forceinline__ uint32_t ring_t_last(uint32_t n) { return ((n - RING_HALF) & ~(RING_BLK - 1)) + RING_BLK; }  // n >= RING_SIZE
-__host__ __device__ __forceinline__ RingGeo ring_geo(uint32_t n, uint32_t p) {
+__host__ __device__ __forceinline__ uint32_t ring_head_at(uint32_t p_aligned) { return p_aligned < RING_HALF ? 0u : p_aligned - RING_HALF; }
+__host__ __device__ __forceinline__ RingGeo ring_geo(uint32_t ring, uint32_t n, uint32_t p) {
     RingGeo g;
-    if (n < RING_SIZE) { g.head = 0; g.tail = n; g.is_short = true; return g; }
+    const bool cont = (ring & RING_CONT) != 0;
+    g.wrapped = cont;
+    if (!cont && n < RING_SIZE) { g.head = 0; g.tail = n; g.is_short = true; return g; }
     const uint32_t tl = ring_t_last(n);
     if (p < tl) {
-        g.head = p < RING_FIRST_END ? 0u : (p & ~(RING_BLK - 1)) - RING_HALF;
+        g.head = (!cont && p < RING_FIRST_END) ? 0u : ring_head_at(p & ~(RING_BLK - 1));
         g.tail = g.head + RING_SIZE; g.is_short = false;
-    } else { g.head = tl - RING_HALF; g.tail = n; g.is_short = true; }
+    } else { g.head = ring_head_at(tl); g.tail = n; g.is_short = true; }
     return g;
 }
 // lowest position a backward extension of a match found at p may reach (find_match :482: match_idx - head); 0 for the slice parse
 __host__ __device__ __forceinline__ uint32_t parse_head(uint32_t ring, uint32_t n, uint32_t p) {
-    if (!ring || n < RING_SIZE || p < RING_FIRST_END) return 0u;
+    if (!ring) return 0u;
+    if (!(ring & RING_CONT) && (n < RING_SIZE || p < RING_FIRST_END)) return 0u;
     const uint32_t tl = ring_t_last(n);
-    return ((p < tl ? p : tl) & ~(RING_BLK - 1)) - RING_HALF;
+    return ring_head_at((p < tl ? p : tl) & ~(RING_BLK - 1));
 }
+// the rounds of match_long exist (frontend_ring.rs:216-219)
+__host__ __device__ __forceinline__ bool ring_rounds(uint32_t ring, uint32_t n) { return ring && ((ring & RING_CONT) || n >= RING_SIZE); }
+// end of the first round at or after position B0 = a multiple of RING_BLK
+__host__ __device__ __forceinline__ uint32_t ring_round_floor(uint32_t ring, uint32_t B) { return (!(ring & RING_CONT) && B < RING_FIRST_END) ? RING_FIRST_END : B; }
 
 struct EncStream {       // one input stream (n > VN_CUTOFF) of the batch
     uint64_t src_off;    // offset of the stream in d_src
@@ -90,7 +104,10 @@ struct EncStream {       // one input stream (n > VN_CUTOFF) of the batch
     uint32_t range_base, range_cap;
     uint64_t match_base;           // offset into the match / gap / prefix-sum arrays
     uint32_t match_cap;
-    uint32_t ring;                 // 1: the ring / stream encoder's parse (encode/frontend_ring.rs), 0: the slice parse
+    uint32_t ring;                 // 1: the ring / stream encoder's parse (encode/frontend_ring.rs), 0: the slice parse; 3: a window of it (RING_CONT)
+    // a window that continues a stream: the parse starts from this state instead of (0, 0, nothing pending)
+    uint32_t start, st_index, st_lit, st_pidx, st_pmidx, st_plen;
+    uint32_t st_skip;   // bytes of the window's first event (its literals, then its match) that the window before has emitted already
 };
 
 struct SpecEvent {   // one emitted match of a segment walker + the walker state after it
@@ -125,9 +142,20 @@ struct EncBlock {        // one bvx2 block (written by the walk kernel)
     uint32_t src_start;  // first raw byte of the block (stream relative)
     uint32_t n_lmd, n_lit, n_match;
     // filled by the block kernel
-    uint32_t hdr_len, lit_len, lmd_len, pad;
+    uint32_t hdr_len, lit_len, lmd_len;
+    uint32_t cut_ev;     // the event the NEXT block begins with ...
     // events that lie completely inside the block (enc_segment_kernel -> enc_lmd_kernel)
     uint32_t ev_begin, ev_end, head_lmds, head_prev_d;
+    uint32_t cut_skip, pad;   // ... and how many of its bytes (literals first, then match bytes) this and earlier blocks hold already
+};
+
+// Where a window of a longer stream may be cut (enc_cut_kernel): behind the last block that ends between two events whose
+// parse no later data can change; the state of the parse there.
+struct EncCut {
+    uint32_t found, n_blocks;            // blocks [0, n_blocks) are final
+    uint32_t index, lit, p_idx, p_midx, p_len;   // the walk's state in front of the event the next block begins with
+    uint32_t skip;                       // bytes of that event the final blocks hold already
+    uint64_t out_len;                    // their bytes
 };
 
 struct EncStreamOut {
@@ -161,7 +189,9 @@ void launch_enc_spec(const uint8_t *src, const EncStream *streams, const uint2 *
                      const uint32_t *rec, const uint64_t *bitmap, SpecEvent *logs, SpecHeader *hdrs, hipStream_t st);
 void launch_enc_stitch(const uint8_t *src, const EncStream *streams, uint32_t ns, const uint2 *segs, uint32_t n_segs, const uint32_t *prev,
                        const uint32_t *rec, const uint64_t *bitmap, const SpecEvent *logs, const SpecHeader *hdrs, uint4 *sync,
-                       RangeRec *ranges, MatchRec *gaps, EncStreamOut *outs, hipStream_t st);
+                       RangeRec *ranges, MatchRec *gaps, uint4 *gstate /* may be null */, EncStreamOut *outs, hipStream_t st);
+void launch_enc_cut(const EncStream *streams, uint32_t ns, const EncStreamOut *outs, const EncBlock *blocks, const RangeRec *ranges,
+                    const SpecEvent *logs, const MatchRec *gaps, const uint4 *gstate, EncCut *cuts, hipStream_t st);
 void launch_enc_compact(const EncStream *streams, const uint32_t *slot_stream, uint32_t n_slots, uint32_t ns, const EncStreamOut *outs,
                         const RangeRec *ranges, const SpecEvent *logs, const MatchRec *gaps, MatchRec *matches, uint32_t *pc,
                         uint32_t *pl, uint2 *rsum, hipStream_t st);

@@ -685,7 +685,7 @@ __global__ __launch_bounds__(256) void enc_pack_kernel(const EncStream *__restri
 // ------------------------------------------------------------------------------------ host side
 
 enum { EB_STREAMS, EB_TILES, EB_PREV, EB_SUMMARY, EB_REC, EB_LMDS, EB_BLOCKS, EB_OUTS, EB_STAGE, EB_SLOTS,
-       EB_BITMAP, EB_SEGS, EB_LOGS, EB_HDRS, EB_RANGES, EB_GAPS, EB_MATCHES, EB_PC, EB_PL, EB_RSLOTS, EB_SYNC, EB_RSUM, EB_DBG, EB_SEGFLAG, EB_N };
+       EB_BITMAP, EB_SEGS, EB_LOGS, EB_HDRS, EB_RANGES, EB_GAPS, EB_MATCHES, EB_PC, EB_PL, EB_RSLOTS, EB_SYNC, EB_RSUM, EB_DBG, EB_SEGFLAG, EB_GSTATE, EB_CUT, EB_N };
 static_assert(EB_N <= 32, "EncScratch slots");
 
 static bool eb_ensure(EncScratch &s, int i, size_t n) {
@@ -720,7 +720,11 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         ~GateRelease() { if (g) g->open(2); }
     } gate_release{ctx_gate_out(c)};
     std::vector<EncStream> hs;
-    const uint32_t ring = ctx_parse_ring(c) ? 1u : 0u;   // the ring / stream encoder's parse (encode/frontend_ring.rs) instead of the slice parse
+    uint32_t ring = ctx_parse_ring(c) ? 1u : 0u;   // the ring / stream encoder's parse (encode/frontend_ring.rs) instead of the slice parse
+    // one window of a longer stream (stream.hip): a single stream, ring parse
+    EncWindow *win = ctx_window(c);
+    if (win && (count != 1 || !ring || src_len[0] < RING_SIZE || src_len[0] > 0x7FFFFFFFull)) return LZFSE_MI_BAD_ARGUMENT;
+    if (win && win->beyond) ring |= RING_CONT;
     for (uint32_t i = 0; i < count; i++) {
         out_lens[i] = 0;
         statuses[i] = LZFSE_MI_OK;
@@ -730,6 +734,10 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         EncStream e{};
         e.src_off = src_off[i]; e.dst_off = dst_off[i]; e.dst_cap = dst_cap[i];
         e.n = (uint32_t)n; e.user_index = i; e.ring = ring;
+        if (win && win->start) {
+            e.start = 1; e.st_index = win->st[0]; e.st_lit = win->st[1]; e.st_pidx = win->st[2]; e.st_pmidx = win->st[3]; e.st_plen = win->st[4]; e.st_skip = win->skip;
+            if (e.st_lit > e.st_index || e.st_index >= e.n - 3) return LZFSE_MI_BAD_ARGUMENT;
+        }
         hs.push_back(e);
     }
     const uint32_t ns = (uint32_t)hs.size();
@@ -835,10 +843,15 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
             StageTimer t(c, "enc_spec");
             launch_enc_spec(d_src, d_streams, d_segs, nseg, d_prev, d_rec, d_bitmap, d_logs, d_hdrs, stq);
         }
+        uint4 *d_gstate = nullptr;
+        if (win && !win->final) {
+            if (!eb_ensure(S, EB_GSTATE, match_total * sizeof(uint4)) || !eb_ensure(S, EB_CUT, ns * sizeof(EncCut))) return LZFSE_MI_IO;
+            d_gstate = (uint4 *)S.bufs[EB_GSTATE];
+        }
         {
             StageTimer t(c, "enc_stitch");
             launch_enc_stitch(d_src, d_streams, ns, d_segs, nseg, d_prev, d_rec, d_bitmap, d_logs, d_hdrs, (uint4 *)S.bufs[EB_SYNC], d_ranges, d_gaps,
-                              d_outs, stq);
+                              d_gstate, d_outs, stq);
         }
         {
             StageTimer t(c, "enc_compact");
@@ -873,6 +886,13 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         hipLaunchKernelGGL(enc_pack_kernel, dim3(blk_total), dim3(256), 0, stq, d_streams, d_slots, d_blocks, d_stage, d_dst, d_outs);
     }
     std::vector<EncStreamOut> ho(ns);
+    EncCut hcut{};
+    if (win && !win->final) {
+        // where this window of a longer stream is cut: the blocks in front of that point are final, the parse goes on from there
+        launch_enc_cut(d_streams, ns, d_outs, d_blocks, (const RangeRec *)S.bufs[EB_RANGES], (const SpecEvent *)S.bufs[EB_LOGS],
+                       (const MatchRec *)S.bufs[EB_GAPS], (const uint4 *)S.bufs[EB_GSTATE], (EncCut *)S.bufs[EB_CUT], stq);
+        E_TRY(hipMemcpyAsync(&hcut, S.bufs[EB_CUT], sizeof hcut, hipMemcpyDeviceToHost, stq));
+    }
     E_TRY(hipMemcpyAsync(ho.data(), d_outs, ns * sizeof(EncStreamOut), hipMemcpyDeviceToHost, stq));
     E_TRY(hipStreamSynchronize(stq));
     if (hipGetLastError() != hipSuccess) return LZFSE_MI_IO;
@@ -880,6 +900,11 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         uint32_t u = hs[i].user_index;
         statuses[u] = ho[i].status;
         out_lens[u] = ho[i].status ? 0 : ho[i].out_len;
+    }
+    if (win && !win->final && !ho[0].status) {
+        win->found = hcut.found;
+        win->index = hcut.index; win->lit = hcut.lit; win->p_idx = hcut.p_idx; win->p_midx = hcut.p_midx; win->p_len = hcut.p_len; win->skip_out = hcut.skip;
+        out_lens[hs[0].user_index] = hcut.found ? hcut.out_len : 0;
     }
     if ((diag_stats & 1) && S.bufs[EB_DBG]) {
         unsigned long long hc[8];

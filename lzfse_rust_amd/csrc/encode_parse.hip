@@ -157,8 +157,8 @@ __device__ uint32_t st_ring_fwd(const uint8_t *s, uint32_t p, uint32_t c, const 
         bool bad = false;
         if (q < thr) {
             const uint32_t xa = p + q, xb = c + q;
-            const uint8_t va = xa < g.tail ? s[xa] : (xa >= RING_SIZE ? s[xa - RING_SIZE] : (uint8_t)0);
-            const uint8_t vb = xb < g.tail ? s[xb] : (xb >= RING_SIZE ? s[xb - RING_SIZE] : (uint8_t)0);
+            const uint8_t va = xa < g.tail ? s[xa] : ((g.wrapped || xa >= RING_SIZE) ? s[xa - RING_SIZE] : (uint8_t)0);
+            const uint8_t vb = xb < g.tail ? s[xb] : ((g.wrapped || xb >= RING_SIZE) ? s[xb - RING_SIZE] : (uint8_t)0);
             bad = va != vb;
         }
         const uint64_t bm = __ballot(bad);
@@ -168,8 +168,8 @@ __device__ uint32_t st_ring_fwd(const uint8_t *s, uint32_t p, uint32_t c, const 
 }
 
 // find_match's forward part for the ring parse (frontend_ring.rs:453-481) at position p, exact, by the whole wave
-__device__ void st_ring_find(const uint8_t *s, const uint32_t *pv, uint32_t n, uint32_t p, uint32_t &best_len, uint32_t &best_idx) {
-    const RingGeo g = ring_geo(n, p);
+__device__ void st_ring_find(const uint8_t *s, const uint32_t *pv, uint32_t ring, uint32_t n, uint32_t p, uint32_t &best_len, uint32_t &best_idx) {
+    const RingGeo g = ring_geo(ring, n, p);
     const uint32_t max = g.is_short ? n - p : RING_LONG_MATCH;
     const uint32_t v = ld_u32(s + p);
     uint32_t c = p, d = link_dist(pv[p]);
@@ -396,10 +396,13 @@ __global__ __launch_bounds__(64) void enc_sync_kernel(const EncStream *__restric
     sync[g] = out;
 }
 
+constexpr uint32_t GS_NO_RESUME = 0x80000000u;   // (positions are 31 bits)
 struct Stitch {
     RangeRec *ranges;
     uint32_t n_ranges, range_cap;
     MatchRec *gaps;
+    uint4 *gstate;       // per gap event: the walk's state after it (index, pending); GS_NO_RESUME in x: the walk cannot be taken up there
+    uint32_t g_marked;   // gap events [g_marked, n_gaps) have no state yet
     uint32_t n_gaps, gap_cap;
     uint32_t out_count;  // matches emitted so far
     uint32_t gap_open;   // first gap event of the currently open gap range
@@ -433,13 +436,34 @@ __device__ __forceinline__ void sx_gap_event(Stitch &x, uint32_t lit_before, uin
     x.n_gaps++;
 }
 
+// end of a step of the true walk: the last event the step made is one the walk can be resumed behind (a window of a
+// stream may be cut there, enc_cut_kernel); an event that the same step followed with another one is not, and keeps
+// only where the walk stood when the step was over (not before that)
+__device__ __forceinline__ void sx_mark_state(Stitch &x, const WState &T) {
+    if (x.g_marked == x.n_gaps || !x.gstate) return;
+    if (e_lane() == 0) {
+        for (uint32_t g = x.g_marked; g + 1 < x.n_gaps; g++) x.gstate[g] = make_uint4(GS_NO_RESUME | T.index, 0, 0, 0);
+        x.gstate[x.n_gaps - 1] = make_uint4(T.index, T.p_len ? T.p_idx : 0, T.p_len ? T.p_midx : 0, T.p_len);
+    }
+    x.g_marked = x.n_gaps;
+}
+// the literals a round end pushed (the event just made): the walk stands at the round end B, nothing pending
+__device__ __forceinline__ void sx_mark_round(Stitch &x, uint32_t B) {
+    if (!x.gstate || x.status) return;
+    if (e_lane() == 0) {
+        for (uint32_t g = x.g_marked; g + 1 < x.n_gaps; g++) x.gstate[g] = make_uint4(GS_NO_RESUME | B, 0, 0, 0);
+        x.gstate[x.n_gaps - 1] = make_uint4(B, 0, 0, 0);
+    }
+    x.g_marked = x.n_gaps;
+}
+
 // One wave per stream; control flow and values are wave-uniform.
 __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
                                                         uint32_t n_streams, const uint32_t *__restrict__ prev,
                                                         const uint32_t *__restrict__ rec, const uint64_t *__restrict__ bitmap,
                                                         const SpecEvent *__restrict__ logs, const SpecHeader *__restrict__ hdrs,
                                                         const uint4 *__restrict__ sync, RangeRec *__restrict__ ranges,
-                                                        MatchRec *__restrict__ gaps, EncStreamOut *__restrict__ outs) {
+                                                        MatchRec *__restrict__ gaps, uint4 *__restrict__ gstate, EncStreamOut *__restrict__ outs) {
     const uint32_t si = blockIdx.x;
     if (si >= n_streams) return;
     const EncStream &es = streams[si];
@@ -451,13 +475,14 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
     // ring parse: the rounds of match_long end at the multiples of RING_BLK in [RING_FIRST_END, t_last]; a round that ends
     // with literals older than the new head pushes them as they are and drops the pending match (frontend_ring.rs:250-272)
     const uint32_t ring = es.ring;
-    const bool rounds = ring && n >= RING_SIZE;
+    const bool rounds = ring_rounds(ring, n);
     const uint32_t t_last = rounds ? ring_t_last(n) : 0u;
     const SpecEvent *L0 = logs + (uint64_t)es.seg_base * SEG_EV_CAP;
     const SpecHeader *H0 = hdrs + es.seg_base;
     Stitch x;
     x.ranges = ranges + es.range_base; x.n_ranges = 0; x.range_cap = es.range_cap;
     x.gaps = gaps + es.match_base; x.n_gaps = 0; x.gap_cap = es.match_cap;
+    x.gstate = gstate ? gstate + es.match_base : nullptr; x.g_marked = 0;
     x.out_count = 0; x.gap_open = 0; x.status = 0;
     uint32_t st_iters = 0, st_syncs = 0, st_fallbacks = 0;
     const uint64_t t_begin = __builtin_amdgcn_s_memtime();
@@ -466,6 +491,12 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
     WState T;                  // valid in walking mode
     T.index = 0; T.lit = 0; T.p_idx = 0; T.p_midx = 0; T.p_len = 0;
     bool walking = false, done = false;
+    if (es.start) {
+        // a window that continues a stream: the true walk goes on from the state the window before was cut at, until a log agrees
+        T.index = es.st_index; T.lit = es.st_lit; T.p_idx = es.st_pidx; T.p_midx = es.st_pmidx; T.p_len = es.st_plen;
+        walking = true;
+        k = T.index / SEG < K ? T.index / SEG : K - 1;
+    }
     while (!done && !x.status) {
         if (!walking) {
             // Following mode, 64 boundaries per step (one per lane). With a = first not yet adopted event of the log
@@ -536,13 +567,13 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
             // positions without a candidate are single steps of match_long: every round end B in (T.index, p] is reached
             // with idx == B, the head moves to B - RING/2, and literals below it are pushed (pending dropped)
             const uint32_t pe = p < end ? p : end;
-            uint32_t B = (T.index / RING_BLK + 1) * RING_BLK;
-            if (B < RING_FIRST_END) B = RING_FIRST_END;
+            uint32_t B = ring_round_floor(ring, (T.index / RING_BLK + 1) * RING_BLK);
             for (; B <= pe && B <= t_last && !x.status; B += RING_BLK)
                 if (T.lit < B - RING_HALF) {
                     T.p_len = 0;
                     sx_gap_event(x, T.lit, B - RING_HALF, 0, 1);
                     T.lit = B - RING_HALF;
+                    sx_mark_round(x, B);
                 }
         }
         if (p >= end) { T.index = end; done = true; break; }
@@ -555,7 +586,7 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
         if (fwd == FCAP) {
             // exact forward part of find_match (frontend_bytes.rs:214-231; ring parse: frontend_ring.rs:453-481) by the whole wave
             uint32_t best_len = 0, best_idx = 0;
-            if (ring) st_ring_find(s, pv, n, p, best_len, best_idx);
+            if (ring) st_ring_find(s, pv, ring, n, p, best_len, best_idx);
             else {
                 uint32_t v = ld_u32(s + p), c = p, d = link_dist(pv[p]);
                 for (int q = 0; q < 4 && d != 0; q++) {
@@ -588,8 +619,7 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
         }
         if (rounds) {
             // a step (or a match's skip) that carried idx over a round end: the round ends with this idx (:382-392)
-            uint32_t B = (p / RING_BLK + 1) * RING_BLK;
-            if (B < RING_FIRST_END) B = RING_FIRST_END;
+            const uint32_t B = ring_round_floor(ring, (p / RING_BLK + 1) * RING_BLK);
             if (B <= T.index && B <= t_last) {
                 const uint32_t nh = (T.index & ~(RING_BLK - 1)) - RING_HALF;
                 if (T.lit < nh) {
@@ -599,6 +629,7 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
                 }
             }
         }
+        sx_mark_state(x, T);
         if (emitted) {
             // does the log of the segment we are in agree with this state?
             uint32_t kk = T.index / SEG;
@@ -636,6 +667,8 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
             sx_close_gap(x);
         }
     }
+    if (x.gstate && e_lane() == 0)
+        for (uint32_t g = x.g_marked; g < x.n_gaps; g++) x.gstate[g] = make_uint4(GS_NO_RESUME | end, 0, 0, 0);   // (the end of the input: nothing to resume)
     if (e_lane() == 0) {
         EncStreamOut o;
         o.n_blocks = 0; o.status = x.status; o.out_len = 0;
@@ -685,6 +718,11 @@ __global__ __launch_bounds__(64) void enc_compact_kernel(const EncStream *__rest
                 m.lit_pos = e.e_lit; m.l = e.e_idx - e.e_lit; m.m = e.e_len; m.d = e.e_dist;
             } else {
                 m = g[q];
+            }
+            if (es.st_skip && rg.out_off + q == 0) {
+                // a window that continues a stream: the front of its first event left with the window before
+                const uint32_t sk = es.st_skip, sl = sk < m.l ? sk : m.l;
+                m.lit_pos += sk; m.l -= sl; m.m -= sk - sl;
             }
             out[q] = m;
             c = lmd_count_of(m.l, m.m);
@@ -825,7 +863,8 @@ __global__ __launch_bounds__(SEGM_THREADS) void enc_segment_kernel(const EncStre
     uint32_t j = 0;             // next unprocessed event
     bool rem = false;           // remainder of a boundary event pending
     uint32_t rem_l = 0, rem_m = 0, rem_d = 0;
-    uint32_t raw_pos = 0;       // first raw byte of the current block
+    uint32_t raw_pos = es.start ? es.st_lit + es.st_skip : 0u;   // first raw byte of the current block (a window that continues a stream: where it takes the stream up)
+    uint32_t rem_ev = 0, rem_all = 0;   // the event `rem` is what is left of, and its l + m
     bool more = true;
     // A block normally costs ONE memory round trip: the 64 lanes that probe the prefix sums just below the expected end
     // of the block also fetch the events there; the last complete event, the boundary event, the first event of the next
@@ -840,6 +879,8 @@ __global__ __launch_bounds__(SEGM_THREADS) void enc_segment_kernel(const EncStre
             if (em_buffer_push(w, rem_l, rem_m, rem_d)) rem = false; else full = true;
         }
         uint32_t ev_begin = j, ev_end = j, head_lmds = w.n_lmd, head_prev_d = w.prev_d;
+        uint32_t cut_ev = NONE, cut_skip = 0;     // the event the next block begins with, and how much of it is behind
+        if (full) { cut_ev = rem_ev; cut_skip = rem_all - (rem_l + rem_m); }
         if (!full) {
             // events [j, j2) fit completely: n_lmd + sum c <= 10 000 and n_lit + sum l <= 40 000
             const uint32_t base_c = j ? (c_base ? c_base_c : PC[j - 1]) : 0, base_l = j ? (c_base ? c_base_l : PL[j - 1]) : 0;
@@ -916,7 +957,12 @@ __global__ __launch_bounds__(SEGM_THREADS) void enc_segment_kernel(const EncStre
                 } else m = mt[j];
                 rem_l = m.l; rem_m = m.m; rem_d = m.d;
                 j++;
-                if (em_buffer_push(w, rem_l, rem_m, rem_d)) rem = false; else { rem = true; full = true; }
+                if (em_buffer_push(w, rem_l, rem_m, rem_d)) rem = false;
+                else {
+                    rem = true; full = true;
+                    rem_ev = j - 1; rem_all = m.l + m.m;
+                    cut_ev = rem_ev; cut_skip = rem_all - (rem_l + rem_m);
+                }
             }
         }
         if (!full && j >= E && !rem) more = false;  // final block (fse/backend.rs:92-95)
@@ -929,7 +975,7 @@ __global__ __launch_bounds__(SEGM_THREADS) void enc_segment_kernel(const EncStre
         b.stage_off = es.stage_base + stage_used;
         b.src_start = raw_pos;
         b.n_lmd = w.n_lmd; b.n_lit = w.n_lit; b.n_match = w.n_match;
-        b.hdr_len = 0; b.lit_len = 0; b.lmd_len = 0; b.pad = 0;
+        b.hdr_len = 0; b.lit_len = 0; b.lmd_len = 0; b.cut_ev = cut_ev; b.cut_skip = cut_skip; b.pad = 0;
         b.ev_begin = ev_begin; b.ev_end = ev_end; b.head_lmds = head_lmds; b.head_prev_d = head_prev_d;
         if (lane == 0) bk[n_blk] = b;
         n_blk++;
@@ -1067,7 +1113,19 @@ __global__ __launch_bounds__(64) void enc_segpar_kernel(const EncStream *__restr
         b.stage_off = stage_need(n_lit, n_lmd);   // (sizes; enc_segfin_kernel turns them into offsets)
         b.src_start = n_lit + n_match;
         b.n_lmd = n_lmd; b.n_lit = n_lit; b.n_match = n_match;
-        b.hdr_len = 0; b.lit_len = 0; b.lmd_len = 0; b.pad = 0;
+        b.hdr_len = 0; b.lit_len = 0; b.lmd_len = 0;
+        // what the next block begins with: the event after e_last when the block's last LMD is e_last's last, else e_last
+        // itself behind the bytes of its first B1 - before_last LMDs (315 literals each, then the rest of the literals with
+        // the first 2 359 match bytes, then 2 359 match bytes each: fse/buffer.rs:56-97)
+        b.cut_ev = NONE; b.cut_skip = 0; b.pad = 0;
+        if (pc_last == B1) { if (e_last + 1 < E) b.cut_ev = e_last + 1; }
+        else {
+            const MatchRec ev = mt[e_last];
+            const EvShape sh = ev_shape(ev.l, ev.m);
+            const uint32_t c = B1 - before_last;
+            b.cut_ev = e_last;
+            b.cut_skip = c <= sh.nL ? c * MAX_L_VALUE : ev.l + (c - sh.nL) * MAX_M_VALUE;
+        }
         b.ev_begin = ev_begin; b.ev_end = ev_end; b.head_lmds = head_lmds; b.head_prev_d = head_prev_d;
         blocks[slot] = b;
     }
@@ -1089,7 +1147,7 @@ __global__ __launch_bounds__(64) void enc_segfin_kernel(const EncStream *__restr
     EncBlock *bk = blocks + es.blk_base;
     const int lane = e_lane();
     uint64_t stage_used = 0;
-    uint32_t raw_pos = 0;
+    uint32_t raw_pos = es.start ? es.st_lit + es.st_skip : 0u;
     for (uint32_t b0 = 0; b0 < nb; b0 += 64) {
         const uint32_t b = b0 + (uint32_t)lane;
         const bool in = b < nb;
@@ -1152,6 +1210,77 @@ __global__ __launch_bounds__(256) void enc_lmd_kernel(const EncStream *__restric
     }
 }
 
+// ------------------------------------------------------------------------------------ cut of a window
+//
+// The stream encoder (lzfse_mi_estream_*, stream.hip) feeds a long input in windows. A window is encoded as if it were
+// the whole input -- n = the bytes on hand -- and the ring parse makes that sound: a position before t_last = ring_t_last(n)
+// is matched by match_long with a head and a tail that depend on the position alone (enc_common.h), and t_last only grows
+// with n, so the walk up to the first position >= t_last is the walk of ANY longer input with this prefix. The window is
+// cut behind the last bvx2 block that ends between two events, the later of which leaves the walk before t_last and
+// leaves it in a state it can be resumed from; blocks [0, n_blocks) are final and the next window starts from that state.
+// One lane per stream.
+__global__ __launch_bounds__(64) void enc_cut_kernel(const EncStream *__restrict__ streams, uint32_t n_streams,
+                                                     const EncStreamOut *__restrict__ outs, const EncBlock *__restrict__ blocks,
+                                                     const RangeRec *__restrict__ ranges, const SpecEvent *__restrict__ logs,
+                                                     const MatchRec *__restrict__ gaps, const uint4 *__restrict__ gstate,
+                                                     EncCut *__restrict__ cuts) {
+    const uint32_t si = blockIdx.x * blockDim.x + threadIdx.x;
+    if (si >= n_streams) return;
+    const EncStream &es = streams[si];
+    const EncStreamOut so = outs[si];
+    EncCut c;
+    c.found = 0; c.n_blocks = 0; c.index = 0; c.lit = 0; c.p_idx = 0; c.p_midx = 0; c.p_len = 0; c.skip = 0; c.out_len = 0;
+    if (!so.status && ring_rounds(es.ring, es.n) && so.n_blocks > 1) {
+        const uint32_t t_safe = ring_t_last(es.n);
+        const EncBlock *bk = blocks + es.blk_base;
+        const RangeRec *rg = ranges + es.range_base;
+        // the walk's state behind event `ord`: x = index | GS_NO_RESUME, y z w = pending; lit = the literal index there
+        auto state_after = [&](uint32_t ord, uint32_t &lit) -> uint4 {
+            uint32_t lo = 0, hi = so.n_ranges;   // the range that holds the event (ranges are in order of out_off)
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (rg[mid].out_off <= ord) lo = mid; else hi = mid;
+            }
+            const RangeRec r = rg[lo];
+            const uint64_t at = r.begin + (ord - r.out_off);
+            if (r.kind == 0) {
+                const SpecEvent ev = logs[at];
+                lit = ev.e_idx + ev.e_len;
+                return make_uint4(ev.index_after, ev.p_idx, ev.p_midx, ev.p_len);
+            }
+            const MatchRec m = (gaps + es.match_base)[at];
+            lit = m.lit_pos + m.l + m.m;
+            return gstate[es.match_base + at];
+        };
+        for (uint32_t b = so.n_blocks - 1; b-- > 0 && !c.found;) {
+            const uint32_t e = bk[b].cut_ev, skip = bk[b].cut_skip;
+            if (e == NONE || e >= so.n_matches) continue;
+            // the event the cut lies in must be one the walk made before t_safe (it is then an event of every longer input) ...
+            if (skip) {
+                uint32_t unused;
+                const uint4 se = state_after(e, unused);
+                if ((se.x & ~GS_NO_RESUME) >= t_safe) continue;
+            }
+            // ... and the walk is taken up in front of it
+            uint32_t index, lit, p_idx, p_midx, p_len;
+            if (e == 0) {
+                index = es.start ? es.st_index : 0u; lit = es.start ? es.st_lit : 0u;
+                p_idx = es.start ? es.st_pidx : 0u; p_midx = es.start ? es.st_pmidx : 0u; p_len = es.start ? es.st_plen : 0u;
+            } else {
+                const uint4 sp = state_after(e - 1, lit);
+                if ((sp.x & GS_NO_RESUME) || sp.x >= t_safe) continue;
+                index = sp.x; p_idx = sp.y; p_midx = sp.z; p_len = sp.w;
+            }
+            c.found = 1; c.n_blocks = b + 1;
+            c.index = index; c.lit = lit; c.p_idx = p_idx; c.p_midx = p_midx; c.p_len = p_len;
+            c.skip = (e == 0 ? es.st_skip : 0u) + skip;
+        }
+        if (c.found)
+            for (uint32_t b = 0; b < c.n_blocks; b++) c.out_len += (uint64_t)bk[b].hdr_len + bk[b].lit_len + bk[b].lmd_len;
+    }
+    cuts[si] = c;
+}
+
 // ------------------------------------------------------------------------------------ launchers
 
 void launch_enc_spec(const uint8_t *src, const EncStream *streams, const uint2 *segs, uint32_t n_segs, const uint32_t *prev,
@@ -1165,10 +1294,14 @@ void launch_enc_spec(const uint8_t *src, const EncStream *streams, const uint2 *
 }
 void launch_enc_stitch(const uint8_t *src, const EncStream *streams, uint32_t ns, const uint2 *segs, uint32_t n_segs, const uint32_t *prev,
                        const uint32_t *rec, const uint64_t *bitmap, const SpecEvent *logs, const SpecHeader *hdrs, uint4 *sync,
-                       RangeRec *ranges, MatchRec *gaps, EncStreamOut *outs, hipStream_t st) {
+                       RangeRec *ranges, MatchRec *gaps, uint4 *gstate, EncStreamOut *outs, hipStream_t st) {
     hipLaunchKernelGGL(enc_sync_kernel, dim3((n_segs + 63) / 64), dim3(64), 0, st, streams, segs, n_segs, logs, hdrs, sync);
     hipLaunchKernelGGL(enc_stitch_kernel, dim3(ns), dim3(64), 0, st, src, streams, ns, prev, rec, bitmap, logs, hdrs, sync, ranges, gaps,
-                       outs);
+                       gstate, outs);
+}
+void launch_enc_cut(const EncStream *streams, uint32_t ns, const EncStreamOut *outs, const EncBlock *blocks, const RangeRec *ranges,
+                    const SpecEvent *logs, const MatchRec *gaps, const uint4 *gstate, EncCut *cuts, hipStream_t st) {
+    hipLaunchKernelGGL(enc_cut_kernel, dim3((ns + 63) / 64), dim3(64), 0, st, streams, ns, outs, blocks, ranges, logs, gaps, gstate, cuts);
 }
 void launch_enc_compact(const EncStream *streams, const uint32_t *slot_stream, uint32_t n_slots, uint32_t ns, const EncStreamOut *outs,
                         const RangeRec *ranges, const SpecEvent *logs, const MatchRec *gaps, MatchRec *matches, uint32_t *pc,

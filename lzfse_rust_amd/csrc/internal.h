@@ -39,6 +39,19 @@ LaneGate *ctx_gate_in(lzfse_mi_ctx *c);
 LaneGate *ctx_gate_out(lzfse_mi_ctx *c);
 int ctx_diag_stats(lzfse_mi_ctx *c);  // LZFSE_MI_OPT_DIAG_STATS bits: 1 block encode, 2 parse, 4 LZ decode
 bool ctx_parse_ring(lzfse_mi_ctx *c);  // this call encodes with the ring / stream encoder's parse (lzfse_mi_encode_ring*, lzfse_mi_estream_*)
+// One window of a longer stream (the stream encoder, stream.hip): set on the context for the duration of ONE single-stream
+// lzfse_mi_encode_ring call. The stream's bytes are those of the window, positions relative to its first byte.
+struct EncWindow {
+    bool start = false;       // the parse goes on from `st` (the window before was cut there) instead of (0, 0, nothing pending)
+    bool beyond = false;      // the window's first byte is not the stream's: a multiple of 16 KiB beyond the first ring (RING_CONT, enc_common.h)
+    bool final = false;       // the input ends with this window: everything is emitted, bvx$ included
+    uint32_t st[5] = {};      // index, literal_index, pending (idx, match idx, len)
+    uint32_t skip = 0;        // bytes of the first event the parse will make from `st` that are in the stream already
+    // out (final = false): where the window was cut (as `st` and `skip` of the next one); found = 0: no block of it is final yet
+    uint32_t found = 0, index = 0, lit = 0, p_idx = 0, p_midx = 0, p_len = 0, skip_out = 0;
+};
+EncWindow *ctx_window(lzfse_mi_ctx *c);
+void ctx_set_window(lzfse_mi_ctx *c, EncWindow *w);
 int ctx_diag_chain(lzfse_mi_ctx *c);  // LZFSE_MI_OPT_DIAG_CHAIN: 1 = every chain tile through the ballot kernel
 
 // ---- decode.hip ----

@@ -9,7 +9,7 @@
 //
 // The encode half of the rank is at the end of this file (lzfse_mi_estream_*): the ring front end's parse
 // (encode/frontend_ring.rs) is done by the device kernels (encode_parse.hip, st_ring_find and the round ends of the
-// stitcher) once the input is complete; this file only collects the pieces and hands the stream out.
+// stitcher), a window of input at a time; this file collects the pieces, cuts the windows and hands the stream out.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "common.h"
+#include "internal.h"
 
 using namespace lzmi;
 
@@ -224,30 +225,122 @@ LZFSE_MI_API int lzfse_mi_dstream_feed(lzfse_mi_dstream *s, const uint8_t *src, 
 
 struct lzfse_mi_estream {
     lzfse_mi_ctx *ctx = nullptr;
-    std::vector<uint8_t> in;   // everything written so far (frontend_ring.rs:167-206 copies it into the ring; here it waits for finish)
-    int status = 0;            // sticky
+    size_t window = 0;            // new input bytes per device call
+    std::vector<uint8_t> buf;     // the input from position `base` on: what the parse may still look at, and what it has not seen yet
+    uint64_t base = 0;            // position of buf[0] in the stream, a multiple of 16 KiB
+    bool have_state = false;      // a window has been cut: the parse goes on from `st` (positions relative to base)
+    uint32_t st[5] = {};          // index, literal_index, pending (idx, match idx, len): encode/frontend_ring.rs' idx, literal_idx, pending
+    uint32_t skip = 0;            // bytes of the first event the parse makes from there that have left already (a block ended inside it)
+    size_t next_at = 0;           // buf.size() at which the next window is tried
+    uint8_t *out = nullptr;       // one window's bytes (malloc'd)
+    size_t out_cap = 0;
+    uint64_t total_in = 0, total_out = 0;
+    int status = 0;               // sticky
     bool finished = false;
+    ~lzfse_mi_estream() { std::free(out); }
 };
+
+namespace {
+
+// what a position of the parse may still reach back to: 262 139 bytes of match distance (fse/constants.rs:42) below the
+// literal index (a backward extension stops there on one side and moves the candidate down with it on the other), and a
+// compare that runs past the ring's tail reads one ring earlier, at most 272 KiB below the position
+constexpr size_t E_KEEP = 262139 + 65536;
+constexpr size_t E_MIN_WINDOW = (size_t)1 << 20;
+
+int es_out_room(lzfse_mi_estream *s, size_t cap) {
+    if (cap <= s->out_cap) return 0;
+    std::free(s->out);
+    s->out = (uint8_t *)std::malloc(cap);
+    s->out_cap = s->out ? cap : 0;
+    return s->out ? 0 : LZFSE_MI_IO;
+}
+
+int es_write(lzfse_mi_estream *s, lzfse_mi_write_fn write, void *user, size_t len) {
+    // the sink takes the stream in pieces, as the reference's 8 KiB output ring does (encode/constants.rs:36-48); larger here
+    for (size_t o = 0; o < len; o += (size_t)1 << 20)
+        if (write(user, s->out + o, len - o < ((size_t)1 << 20) ? len - o : (size_t)1 << 20)) return LZFSE_MI_IO;
+    s->total_out += len;
+    return 0;
+}
+
+// One device call over everything on hand. final: the input ends here. Otherwise the window is cut behind its last block
+// that no later byte can change (enc_cut_kernel, encode_parse.hip), those blocks leave through `write`, and the buffer
+// keeps what the parse still needs: E_KEEP bytes below the literal index of the cut, and everything from there on.
+int es_window(lzfse_mi_estream *s, bool final, lzfse_mi_write_fn write, void *user) {
+    const size_t n = s->buf.size();
+    if (final && !s->have_state) {
+        // the whole input in one call (all size classes)
+        const size_t cap = lzfse_mi_encode_bound(n);
+        if (es_out_room(s, cap ? cap : 1)) return LZFSE_MI_IO;
+        size_t len = 0;
+        const int st = lzfse_mi_encode_ring(s->ctx, s->buf.data(), n, s->out, cap, &len);
+        return st ? st : es_write(s, write, user, len);
+    }
+    if (n > (size_t)0x7FFFFFFFu) return LZFSE_MI_UNSUPPORTED;   // positions are 31 bits on the device
+    const size_t cap = lzfse_mi_encode_bound(n);
+    if (es_out_room(s, cap)) return LZFSE_MI_IO;
+    EncWindow w;
+    w.start = s->have_state; w.beyond = s->base != 0; w.final = final;
+    for (int k = 0; k < 5; k++) w.st[k] = s->st[k];
+    w.skip = s->skip;
+    size_t len = 0;
+    ctx_set_window(s->ctx, &w);
+    const int st = lzfse_mi_encode_ring(s->ctx, s->buf.data(), n, s->out, cap, &len);
+    ctx_set_window(s->ctx, nullptr);
+    if (st) return st;
+    if (final) return es_write(s, write, user, len);
+    if (!w.found) {
+        // no block of this window is final yet (few, very long matches: a block of 10 000 LMDs can span many MiB): more input first
+        s->next_at = n + (n > s->window ? n : s->window);
+        return 0;
+    }
+    if (const int e = es_write(s, write, user, len)) return e;
+    size_t keep = w.lit > E_KEEP ? (size_t)w.lit - E_KEEP : 0;
+    keep &= ~(size_t)(0x4000 - 1);
+    s->buf.erase(s->buf.begin(), s->buf.begin() + (ptrdiff_t)keep);
+    s->base += keep;
+    const uint32_t k32 = (uint32_t)keep;
+    s->st[0] = w.index - k32; s->st[1] = w.lit - k32;
+    s->st[2] = w.p_len ? w.p_idx - k32 : 0; s->st[3] = w.p_len ? w.p_midx - k32 : 0; s->st[4] = w.p_len;
+    s->skip = w.skip_out;
+    s->have_state = true;
+    s->next_at = s->buf.size() + s->window;
+    return 0;
+}
+
+}  // namespace
 
 extern "C" {
 
-int lzfse_mi_estream_create(lzfse_mi_ctx *ctx, lzfse_mi_estream **out) {
+int lzfse_mi_estream_create(lzfse_mi_ctx *ctx, size_t window, lzfse_mi_estream **out) {
     if (!ctx || !out) return LZFSE_MI_BAD_ARGUMENT;
     lzfse_mi_estream *s = new (std::nothrow) lzfse_mi_estream();
     if (!s) return LZFSE_MI_IO;
     s->ctx = ctx;
+    s->window = window ? window : (size_t)LZFSE_MI_STREAM_WINDOW;
+    if (s->window < E_MIN_WINDOW) s->window = E_MIN_WINDOW;
+    if (s->window > ((size_t)1 << 30)) s->window = (size_t)1 << 30;
+    s->next_at = s->window + ((size_t)1 << 19);   // (the last 256 KiB + 16 KiB of a window are never final: one ring on top)
     *out = s;
     return LZFSE_MI_OK;
 }
 
 void lzfse_mi_estream_destroy(lzfse_mi_estream *s) { delete s; }
 
-// Write::write of LzfseWriter (encode/writer.rs:59-63): takes all of buf
-int lzfse_mi_estream_feed(lzfse_mi_estream *s, const uint8_t *src, size_t n) {
-    if (!s || (!src && n) || s->finished) return LZFSE_MI_BAD_ARGUMENT;
+// Write::write of LzfseWriter (encode/writer.rs:59-63): takes all of buf; whenever a window's worth of input is on hand the
+// device encodes it and the blocks that are final leave through `write`
+int lzfse_mi_estream_feed(lzfse_mi_estream *s, const uint8_t *src, size_t n, lzfse_mi_write_fn write, void *user) {
+    if (!s || (!src && n) || !write || s->finished) return LZFSE_MI_BAD_ARGUMENT;
     if (s->status) return s->status;
-    if (s->in.size() + n > (size_t)0x7FFFFFFFu) return s->status = LZFSE_MI_UNSUPPORTED;   // as the slice path: positions are 31 bits on the device
-    try { s->in.insert(s->in.end(), src, src + n); } catch (...) { return s->status = LZFSE_MI_IO; }
+    while (n) {
+        const size_t room = s->next_at > s->buf.size() ? s->next_at - s->buf.size() : 0;
+        const size_t take = n < room ? n : room;
+        try { s->buf.insert(s->buf.end(), src, src + take); } catch (...) { return s->status = LZFSE_MI_IO; }
+        src += take; n -= take; s->total_in += take;
+        if (s->buf.size() >= s->next_at)
+            if (const int st = es_window(s, false, write, user)) return s->status = st;
+    }
     return LZFSE_MI_OK;
 }
 
@@ -256,18 +349,10 @@ int lzfse_mi_estream_finish(lzfse_mi_estream *s, lzfse_mi_write_fn write, void *
     if (!s || !write || s->finished) return LZFSE_MI_BAD_ARGUMENT;
     s->finished = true;
     if (s->status) return s->status;
-    const size_t n = s->in.size(), cap = lzfse_mi_encode_bound(n);
-    uint8_t *out = (uint8_t *)std::malloc(cap ? cap : 1);
-    if (!out) return s->status = LZFSE_MI_IO;
-    size_t len = 0;
-    int st = lzfse_mi_encode_ring(s->ctx, s->in.data(), n, out, cap, &len);
-    // the sink takes the stream in pieces, as the reference's 8 KiB output ring does (encode/constants.rs:36-48); larger here
-    for (size_t o = 0; !st && o < len; o += (size_t)1 << 20)
-        if (write(user, out + o, len - o < ((size_t)1 << 20) ? len - o : (size_t)1 << 20)) st = LZFSE_MI_IO;
-    std::free(out);
-    if (bytes_in) *bytes_in = n;
-    if (bytes_out) *bytes_out = st ? 0 : len;
-    std::vector<uint8_t>().swap(s->in);
+    const int st = es_window(s, true, write, user);
+    if (bytes_in) *bytes_in = s->total_in;
+    if (bytes_out) *bytes_out = st ? 0 : s->total_out;
+    std::vector<uint8_t>().swap(s->buf);
     return s->status = st;
 }
 

@@ -1,5 +1,8 @@
 """One-off randomised parity campaign on a GPU box (not part of the test-suite: the suite's cases are fixed):
-    python scripts/fuzz_gpu.py [ROUNDS] [SEED] [walk|pipe|big|ring]  (ring: the streams are ALSO encoded with the ring / stream encoder's parse and
+    python scripts/fuzz_gpu.py [ROUNDS] [SEED] [walk|pipe|big|ring|stream]  (stream: 3 to 6 inputs of 1.2 .. 12 MiB per round through LzfseWriter with
+                                                              windows of 1 .. 3 MiB and pieces of any size: the bytes are those of the restated ring
+                                                              encoder on the whole input, and the windows did leave early;
+                                                              ring: the streams are ALSO encoded with the ring / stream encoder's parse and
                                                               compared with the restated frontend_ring.rs; lengths reach across the 512 KiB ring;
                                                               walk: the diagnostic build, every stream through the parallel header walk first;
                                                               pipe: every stream of the tile kernel through the pipelined LZ kernel, K and tile size changing per round;
@@ -26,6 +29,7 @@ else:
 PIPE = len(sys.argv) > 3 and sys.argv[3] == "pipe"
 BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
 RING = len(sys.argv) > 3 and sys.argv[3] == "ring"
+STREAM = len(sys.argv) > 3 and sys.argv[3] == "stream"
 rng = np.random.default_rng(seed)
 words = [bytes(rng.integers(97, 123, size=int(rng.integers(1, 12)), dtype=np.uint8)) for _ in range(800)]
 TILE = 65472
@@ -72,7 +76,43 @@ def length():
     return int(rng.integers(600000, 3 << 20))
 
 t0 = time.time(); total = 0
+
+
+class Sink:
+    def __init__(self):
+        self.parts = []
+
+    def write(self, b):
+        self.parts.append(bytes(b))
+
+
+def stream_round(rd):
+    global total
+    for _ in range(int(rng.integers(3, 7))):
+        n = int(rng.integers(1_200_000, 12 << 20))
+        kind = int(rng.integers(0, 8))
+        raw = bytes(int(rng.integers(1, 4 << 20))) + gen(4, n // 2) if kind == 7 else gen(kind, n)
+        window = int(rng.integers(1 << 20, 3 << 20))
+        sink = Sink()
+        w = lz.LzfseRingEncoder(context=ctx, window=window).writer(sink)
+        o = 0
+        while o < len(raw):
+            k = int(rng.integers(1, 2_000_000)) if rng.random() < 0.8 else int(rng.integers(1, 5000))
+            w.write(raw[o:o + k]); o += k
+        early = sum(map(len, sink.parts))
+        w.finalize()
+        got = b"".join(sink.parts)
+        want = O.ring_encode(raw)
+        assert got == want, f"round {rd}: stream encode differs, {len(raw)} bytes of kind {kind}, window {window}"
+        total += len(raw)
+        print(f"  kind {kind} {len(raw)} B window {window}: {len(sink.parts)} pieces, {early} of {len(got)} B before finalize", flush=True)
+
+
 for rd in range(rounds):
+    if STREAM:
+        stream_round(rd)
+        print(f"round {rd}: ok, {time.time() - t0:.0f} s", flush=True)
+        continue
     if PIPE:
         ctx.set_option("decode_pipe", int(rng.integers(2, 12)) | (int(rng.integers(0, 2)) << 8))
     if BIG:

@@ -1,5 +1,7 @@
-"""Streaming decode (lzfse_mi_dstream_*) against the slice call on the same stream: host-pointer rates, PCIe included.
+"""Streaming decode (lzfse_mi_dstream_*) and streaming encode (lzfse_mi_estream_*) against the one-call forms on the same
+stream: host-pointer rates, PCIe included.
     python scripts/stream_bench.py [MB]"""
+import hashlib
 import io
 import os
 import sys
@@ -17,6 +19,15 @@ class Sink:
         self.n = 0
 
     def write(self, b):
+        self.n += len(b)
+
+
+class HashSink:
+    def __init__(self):
+        self.h, self.n = hashlib.sha256(), 0
+
+    def write(self, b):
+        self.h.update(b)
         self.n += len(b)
 
 
@@ -40,6 +51,21 @@ def main():
             dt = time.perf_counter() - t
         assert (u, v, s.n) == (len(enc), len(raw), len(raw))
         print(f"stream decode, window {window >> 20:3d} MiB: {len(raw) / dt / 1e6:9.1f} MB/s")
+    # ---- encode: the ring / stream encoder's bytes, whole input in one call against windows ----
+    for _ in range(2):
+        t = time.perf_counter()
+        outs, st = ctx.encode_batch([raw], ring=True)
+        dt = time.perf_counter() - t
+    want = outs[0].tobytes()
+    print(f"ring encode, one call (host pointers): {len(raw) / dt / 1e6:9.1f} MB/s")
+    for window in (4 << 20, 16 << 20, 64 << 20):
+        for _ in range(2):
+            s = HashSink()
+            t = time.perf_counter()
+            u, v = m.LzfseRingEncoder(context=ctx, window=window, read_size=1 << 20).encode(io.BytesIO(raw), s)
+            dt = time.perf_counter() - t
+        assert (u, v) == (len(raw), len(want)) and s.h.digest() == hashlib.sha256(want).digest()
+        print(f"stream encode, window {window >> 20:3d} MiB: {len(raw) / dt / 1e6:9.1f} MB/s")
 
 
 if __name__ == "__main__":

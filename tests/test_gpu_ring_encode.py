@@ -266,3 +266,117 @@ def test_ring_batch_device_resident(ctx, oracle, snappy_raw):
     finally:
         hip.free(d_src)
         hip.free(d_dst)
+
+
+# ---- the stream encoder feeds the device a window at a time: same bytes as the whole input in one call ----
+
+class _CountingSink:
+    """collects the stream and remembers how much of it had arrived before finalize()"""
+
+    def __init__(self):
+        self.parts, self.calls = [], 0
+
+    def write(self, b):
+        self.parts.append(bytes(b))
+        self.calls += 1
+
+    def value(self):
+        return b"".join(self.parts)
+
+
+def _windowed(ctx, data, window, piece):
+    import lzfse_rust_amd as m
+    sink = _CountingSink()
+    w = m.LzfseRingEncoder(context=ctx, window=window).writer(sink)
+    for o in range(0, len(data), piece):
+        w.write(data[o:o + piece])
+    early = sum(map(len, sink.parts))
+    w.finalize()
+    return sink.value(), early
+
+
+def _window_cases():
+    text = _text(7_000_000, seed=11)
+    yield "text_7M", text
+    yield "noise_3M", tk.seq(3_000_000, seed=13)                          # literal deserts: the overflow pushes of the round ends
+    yield "low_entropy_4M", tk.seq(4_000_000, seed=14, mask=0x01010101)
+    yield "low_entropy_bits_3M", tk.seq(3_000_000, seed=15, mask=0x00010001)
+    yield "zeros_6M", bytes(6_000_000)                                     # one block spans many MiB: windows without a final block
+    yield "mixed", text[:1_500_000] + bytes(900_000) + tk.seq(800_000, seed=16) + text[2_000_000:3_300_000] + tk.seq(700_000, seed=17, mask=0x01010101)
+    rep = np.tile(np.frombuffer(text[:70_001], dtype=np.uint8), 60).copy()
+    rep[::4099] ^= 1
+    yield "period_70001", rep.tobytes()
+
+
+@pytest.mark.parametrize("name,data", list(_window_cases()), ids=[n for n, _ in _window_cases()])
+def test_windows_give_the_bytes_of_the_whole_input(ctx, oracle, name, data):
+    want = oracle.ring_encode(data)
+    assert _ring(ctx, data) == want
+    for window, piece in ((1 << 20, 300_001), (2 << 20, 1 << 20), (1 << 20, 4_000_000)):
+        got, early = _windowed(ctx, data, window, piece)
+        assert got == want, (name, window, piece)
+        if name == "text_7M":
+            assert early > len(want) // 2, "most of the stream must have left before finalize()"
+
+
+def test_window_sizes_around_the_cut_rules(ctx, oracle):
+    """lengths around a window's end and the ring's rounds (multiples of 16 KiB): the last 256 KiB + 16 KiB of a window
+    are never final, and the very last window may be hardly longer than what was kept"""
+    text = _text(3_300_000, seed=19)
+    for n in (1 << 20, (1 << 20) + (1 << 19), (1 << 20) + (1 << 19) + 1, 2_097_152 - 1, 2_097_152, 2_097_152 + BLK, 2_097_152 + RING // 2 + BLK + 5,
+              2_621_440, 2_621_441, 3_145_728 - BLK - 1, 3_300_000):
+        data = text[:n]
+        got, _ = _windowed(ctx, data, 1 << 20, 1 << 18)
+        assert got == oracle.ring_encode(data), n
+
+
+def test_windowed_stream_decodes_back(ctx):
+    """32 MiB of text through 4 MiB windows: round trip, and the windows did leave early"""
+    import lzfse_rust_amd as m
+    data = _text(32 << 20, seed=23)
+    got, early = _windowed(ctx, data, 4 << 20, 1 << 20)
+    assert got == _ring(ctx, data)
+    assert early > len(got) * 3 // 4
+    out, st = ctx.decode_batch([got])
+    assert st == [0] and out[0].tobytes() == data
+
+
+def test_windows_cut_inside_long_matches(ctx, oracle):
+    """Inputs whose bvx2 blocks span tens of MiB and end INSIDE an event: zeros (every event is a match of LONG_MATCH_LEN =
+    105 LMDs, 10 000 is no multiple of that, so every block ends in the middle of a match) and runs of 2 400 .. 7 000 equal
+    bytes (two to three LMDs per run). The window is cut inside the event: what is left of it opens the next window's first
+    block, as the remainder opens the next block in Buffer::push (fse/buffer.rs:45-97)."""
+    rng = np.random.default_rng(29)
+    zeros = bytes(56_000_000)
+    runs = np.repeat(rng.integers(0, 256, size=9000, dtype=np.uint8), rng.integers(2400, 7000, size=9000)).tobytes()
+    for name, data in (("zeros", zeros), ("runs", runs)):
+        want = oracle.ring_encode(data)
+        got, early = _windowed(ctx, data, 4 << 20, 3_000_000)
+        assert got == want, name
+        assert early > 0, name
+
+
+def test_windowed_writer_sink_failure_and_reuse(ctx, oracle):
+    """a sink that fails in the middle of write(): its exception comes back from write() (io::Error of the inner writer),
+    the handle stays failed, and the context encodes the next stream as if nothing had happened"""
+    import lzfse_rust_amd as m
+    data = _text(5_000_000, seed=31)
+
+    class Bad:
+        def __init__(self):
+            self.n = 0
+
+        def write(self, b):
+            self.n += len(b)
+            if self.n > 200_000:
+                raise OSError("disk full")
+
+    enc = m.LzfseRingEncoder(context=ctx, window=1 << 20)
+    w = enc.writer(Bad())
+    with pytest.raises(OSError):
+        for o in range(0, len(data), 1 << 18):
+            w.write(data[o:o + (1 << 18)])
+    with pytest.raises(m.LzfseError):
+        w.write(b"more")
+    got, _ = _windowed(ctx, data, 1 << 20, 1 << 18)
+    assert got == oracle.ring_encode(data)
