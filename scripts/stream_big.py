@@ -1,0 +1,55 @@
+"""A stream of more than 2^31 (or 2^32) bytes through the windowed stream encoder against the restated ring encoder (SHA-256 of
+both streams): the slice calls refuse such inputs (positions are 31 bits on the device), a window's positions are relative.
+    python scripts/stream_big.py [GiB]        (about 15 s of oracle time per GiB; profiles/r03_stream_big.txt)"""
+import hashlib, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+import lzfse_rust_amd as m
+import oracle_py
+from bench import synth_text
+
+gib = float(sys.argv[1]) if len(sys.argv) > 1 else 2.2
+base = np.frombuffer(synth_text(64 << 20, seed=3), dtype=np.uint8)
+copies = int(gib * 16) + 1
+raw = np.empty(copies * base.size, dtype=np.uint8)
+for c in range(copies):
+    a = raw[c * base.size:(c + 1) * base.size]
+    a[:] = base
+    a[c % 251::251] ^= np.uint8(1 + c % 200)
+print(f"{raw.size} bytes", flush=True)
+O = oracle_py.Oracle()
+t = time.time()
+want = hashlib.sha256()
+mv = memoryview(raw)
+# the oracle through its handle API, 16 MiB per write; its output is hashed and dropped
+h = O.lib.lzo_ring_new(0, 0, 0, None)
+import ctypes as C
+for o in range(0, raw.size, 16 << 20):
+    a = raw[o:o + (16 << 20)]
+    assert O.lib.lzo_ring_write(h, a.ctypes.data, a.size) == 0
+ptr, n = C.c_void_p(), C.c_size_t(0)
+assert O.lib.lzo_ring_finish(h, C.byref(ptr), C.byref(n)) == 0
+want.update(C.string_at(ptr, n.value)); want_len = n.value
+O.lib.lzo_ring_free(h)
+print(f"oracle: {want_len} bytes, {time.time() - t:.0f} s", flush=True)
+
+
+class Sink:
+    def __init__(self):
+        self.h, self.n = hashlib.sha256(), 0
+
+    def write(self, b):
+        self.h.update(b); self.n += len(b)
+
+
+ctx = m.Context(0)
+t = time.time()
+s = Sink()
+w = m.LzfseRingEncoder(context=ctx).writer(s)
+for o in range(0, raw.size, 8 << 20):
+    w.write(mv[o:o + (8 << 20)])
+w.finalize()
+print(f"device: {s.n} bytes, {time.time() - t:.1f} s", flush=True)
+assert s.n == want_len and s.h.digest() == want.digest()
+print("equal")
