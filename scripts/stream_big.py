@@ -36,16 +36,18 @@ print(f"oracle: {want_len} bytes, {time.time() - t:.0f} s", flush=True)
 
 
 class Sink:
-    def __init__(self):
-        self.h, self.n = hashlib.sha256(), 0
+    def __init__(self, keep=False):
+        self.h, self.n, self.parts = hashlib.sha256(), 0, [] if keep else None
 
     def write(self, b):
         self.h.update(b); self.n += len(b)
+        if self.parts is not None:
+            self.parts.append(bytes(b))
 
 
 ctx = m.Context(0)
 t = time.time()
-s = Sink()
+s = Sink(keep=True)
 w = m.LzfseRingEncoder(context=ctx).writer(s)
 for o in range(0, raw.size, 8 << 20):
     w.write(mv[o:o + (8 << 20)])
@@ -53,3 +55,12 @@ w.finalize()
 print(f"device: {s.n} bytes, {time.time() - t:.1f} s", flush=True)
 assert s.n == want_len and s.h.digest() == want.digest()
 print("equal")
+# ... and back through the stream decoder
+import io
+enc = b"".join(s.parts)
+t = time.time()
+d = Sink()
+u, v = m.LzfseRingDecoder(context=ctx, read_size=8 << 20).decode(io.BytesIO(enc), d)
+print(f"stream decode: {v} bytes, {time.time() - t:.1f} s", flush=True)
+assert (u, v) == (len(enc), raw.size) and d.h.digest() == hashlib.sha256(mv).digest()
+print("round trip equal")
