@@ -612,7 +612,9 @@ __device__ int fse_build_tables(FseLds &lds, uint32_t kind, const FseHeader &h, 
             else { kk = k - 1; delta = (int32_t)((j - x) << (k - 1)); }
             uint32_t vb = which == 0 ? l_extra_bits(lo) : which == 1 ? m_extra_bits(lo) : d_extra_bits(lo);
             uint32_t vv = which == 0 ? l_base_value(lo) : which == 1 ? m_base_value(lo) : d_base_value(lo);
-            e.x = kk | (vb << 8) | ((uint32_t)(delta & 0xFFFF) << 16);
+            // k | value bits << 8 | delta << 16 (0 <= delta < states <= 256: (w + j) << k >= states by the choice of k) | -(k + value bits) << 24
+            // (a signed byte: the step's prefix sum over L, M, D runs on it and IS the window shift, no negation)
+            e.x = kk | (vb << 8) | ((uint32_t)(delta & 0xFF) << 16) | (((0u - (kk + vb)) & 0xFFu) << 24);
             e.y = vv;
         } else {
             e.x = (ts << 16);
@@ -714,7 +716,7 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
                 pre += dpp_shr<2>(pre);  // inclusive prefix over lanes 0..3
                 const uint32_t x = (uint32_t)(win >> ((0u - pre) & 63));   // pre == 0 only with k == 0
                 const uint32_t bits = __builtin_amdgcn_ubfe(x, 0u, k);
-                state = (bits + (ent & 0xFFFFu)) & 1023u;   // (delta is a 16-bit two's complement: the mask takes the carry away)
+                state = bits + (ent & 0xFFFFu);   // (0 <= delta, and delta + the k bits read < 1024 by the construction of the table: no mask)
                 stg_lit[sidx + slot_off] = (uint8_t)(ent >> 16);
                 ent = u_tab[state];
                 r2 = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)(r2 - (int32_t)read_lane(pre, 3)));   // (scalar: the address arithmetic below stays off the vector pipe)
@@ -754,7 +756,6 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
         const int li = lane < 2 ? lane : 2;
         uint32_t state = li == 0 ? h.lmd_state[0] : li == 1 ? h.lmd_state[1] : h.lmd_state[2];
         const uint32_t tbase = li == 0 ? 0u : (li == 1 ? 64u : 128u);
-        const uint32_t smask = li == 2 ? 255u : 63u;
         LmdRec *out = lmd_out + d.lmd_base;
         const uint32_t n = e ? 0u : h.lmd_num;
         // The three values of a step go to LDS (idle lanes write a dump slot: no exec masking); every 64 steps the
@@ -792,18 +793,21 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
             const int32_t low57 = w.base_bit + 57 - r2_bias;
             auto lmd_step = [&](auto safe_tag, uint32_t slot_off) {
                 constexpr bool SAFE = decltype(safe_tag)::value;
-                const uint32_t k = ent.x & 0xFF, vb = __builtin_amdgcn_ubfe(ent.x, 8u, 8u);
-                const uint32_t tot = k + vb;
-                uint32_t pre = tot + dpp_shr<1>(tot);
-                pre += dpp_shr<2>(tot);   // (both moves read `tot`: no wait between them)
+                // (v_bfe_u32 takes its width from bits 4:0 of the operand: the entry itself serves as k <= 10)
+                const uint32_t k = ent.x, vb = __builtin_amdgcn_ubfe(ent.x, 8u, 8u);
+                const uint32_t ntot = (uint32_t)((int32_t)ent.x >> 24);   // -(k + vb)
+                uint32_t npre = ntot + dpp_shr<1>(ntot);
+                npre += dpp_shr<2>(ntot);   // (both moves read `ntot`: no wait between them) minus the bits of lanes 0 .. this one
                 // a lane's field (state bits above value bits) is at most 10 + 15 bits: one 64-bit shift, two bit-field extracts
-                const uint32_t x = (uint32_t)(win >> ((0u - pre) & 63));  // pre == 0 only when k = vb = 0 below
+                const uint32_t x = (uint32_t)(win >> (npre & 63));  // npre == 0 only when k = vb = 0 below
                 const uint32_t extra = __builtin_amdgcn_ubfe(x, 0u, vb);
                 const uint32_t sb = __builtin_amdgcn_ubfe(x, vb, k);
-                state = (sb + (ent.x >> 16)) & smask;
+                // (no mask: delta + the k bits read stay below the number of states by the construction of the table, decoder.rs:244-335)
+                state = sb + ((ent.x >> 16) & 0xFFu);
+                asm volatile("" : "+v"(state));   // (one SDWA add; left alone the compiler scales both terms by 8 first: one instruction more)
                 stg_lmd[sidx + slot_off] = ent.y + extra;
                 ent = vt[state];
-                r2 = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)(r2 - (int32_t)read_lane(pre, 2)));
+                r2 = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)(r2 + (int32_t)read_lane(npre, 2)));
                 const int32_t di = r2 >> 5;
                 const uint32_t d0 = ringw[di], d1 = ringw[di + 1], d2 = ringw[di + 2];
                 const uint32_t x0 = __builtin_amdgcn_alignbit(d1, d0, (uint32_t)r2), x1 = __builtin_amdgcn_alignbit(d2, d1, (uint32_t)r2);
