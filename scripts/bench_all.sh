@@ -8,7 +8,7 @@ for w in text64m chunks4m chunks1g; do
   timeout -k 10 400 python bench.py --workload $w --steps 5 --warmup 1 > $OUT/bench_$w.json 2> $OUT/bench_$w.err || exit 1
   echo "$w done" >> $OUT/progress.txt
 done
-timeout -k 10 300 python bench.py --replicas 64 --steps 5 --warmup 1 > $OUT/bench_snappy_r64.json 2> $OUT/bench_snappy_r64.err || exit 1
+timeout -k 10 300 python bench.py --replicas 64 --steps 20 --warmup 3 > $OUT/bench_snappy_r64.json 2> $OUT/bench_snappy_r64.err || exit 1
 timeout -k 10 300 python bench.py --per-file 256 > $OUT/snappy_table.json 2> $OUT/snappy_table.err || exit 1
 timeout -k 10 300 python bench.py --per-file 64 > $OUT/snappy_table_r64.json 2> $OUT/snappy_table_r64.err || exit 1
 timeout -k 10 300 python bench.py --per-file 16 > $OUT/snappy_table_r16.json 2> $OUT/snappy_table_r16.err || exit 1
