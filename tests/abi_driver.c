@@ -1,6 +1,6 @@
 /* A C caller of include/lzfse_mi.h (plain gcc, no C++ / Python / torch anywhere): proves the header is C and that the
  * boundary works as the reference's lzfse_sys-style binding would use it (lzfse_sys/src/lib.rs:29-56 is the template:
- * caller-owned buffers, sizes in, size out). Exit codes: 0 = round trip ok, 3 = no HIP device (LZFSE_MI_NO_DEVICE from
+ * caller-owned buffers, sizes in, size out), the streaming entry points included. Exit codes: 0 = round trip ok, 3 = no HIP device (LZFSE_MI_NO_DEVICE from
  * lzfse_mi_create: the product never falls back to a CPU codec), anything else = failure.
  *
  *   gcc -std=c11 -Wall -Wextra -Werror -I include tests/abi_driver.c -L lzfse_rust_amd -llzfse_mi -o abi_driver
@@ -12,6 +12,16 @@
 #include "lzfse_mi.h"
 
 static unsigned lcg(unsigned *s) { *s = *s * 1103515245u + 12345u; return *s >> 8; }
+
+/* what a binding's Write / Vec<u8> sink is to the streaming entry points */
+struct sink { uint8_t *p; size_t len, cap; };
+static int sink_write(void *user, const uint8_t *bytes, size_t n) {
+    struct sink *s = user;
+    if (s->len + n > s->cap) return 1;
+    memcpy(s->p + s->len, bytes, n);
+    s->len += n;
+    return 0;
+}
 
 int main(void) {
     printf("%s\n", lzfse_mi_version());
@@ -65,6 +75,39 @@ int main(void) {
     if (sts[0] != LZFSE_MI_OK || sts[1] != LZFSE_MI_BUFFER_OVERFLOW || outs[0] == 0 || outs[1] != 0) return 29;
     if (lzfse_mi_set_option(ctx, LZFSE_MI_OPT_ENCODE_LANES, 1) != LZFSE_MI_OK) return 30;
     if (lzfse_mi_set_option(ctx, LZFSE_MI_OPT_DIAG_LZ_PATH, 1) != LZFSE_MI_UNSUPPORTED) return 31;
+
+    /* the streaming surface from C: 3 MiB through the stream encoder in 1 MiB windows and odd pieces -- the bytes of the
+     * ring encoder's one-call form -- and back through the stream decoder */
+    {
+        const size_t big = 3u << 20;
+        uint8_t *raw = malloc(big), *one = malloc(lzfse_mi_encode_bound(big));
+        for (size_t i = 0; i < big; i++) raw[i] = src[(i * 7 + (i >> 12)) % n];
+        size_t one_len = 0;
+        if (lzfse_mi_encode_ring(ctx, raw, big, one, lzfse_mi_encode_bound(big), &one_len) != LZFSE_MI_OK) return 40;
+        struct sink es = {malloc(lzfse_mi_encode_bound(big)), 0, lzfse_mi_encode_bound(big)}, ds = {malloc(big), 0, big};
+        lzfse_mi_estream *e = NULL;
+        if (lzfse_mi_estream_create(ctx, 1u << 20, &e) != LZFSE_MI_OK) return 41;
+        for (size_t o = 0; o < big;) {
+            size_t k = 100000 + o % 7777; if (k > big - o) k = big - o;
+            if (lzfse_mi_estream_feed(e, raw + o, k, sink_write, &es) != LZFSE_MI_OK) return 42;
+            o += k;
+        }
+        const size_t early = es.len;
+        uint64_t u = 0, v = 0;
+        if (lzfse_mi_estream_finish(e, sink_write, &es, &u, &v) != LZFSE_MI_OK || u != big || v != es.len) return 43;
+        lzfse_mi_estream_destroy(e);
+        if (es.len != one_len || memcmp(es.p, one, one_len) != 0 || early == 0) return 44;
+        lzfse_mi_dstream *d = NULL;
+        if (lzfse_mi_dstream_create(ctx, 1u << 20, &d) != LZFSE_MI_OK) return 45;
+        for (size_t o = 0; o < es.len;) {
+            size_t k = 65536; if (k > es.len - o) k = es.len - o;
+            if (lzfse_mi_dstream_feed(d, es.p + o, k, o + k == es.len, sink_write, &ds) != LZFSE_MI_OK) return 46;
+            o += k;
+        }
+        lzfse_mi_dstream_destroy(d);
+        if (ds.len != big || memcmp(ds.p, raw, big) != 0) return 47;
+        free(raw); free(one); free(es.p); free(ds.p);
+    }
 
     lzfse_mi_destroy(ctx);
     free(src); free(enc); free(dec);

@@ -176,7 +176,8 @@ def test_header_is_c_and_c_driver_links(tmp_path):
 
 @pytest.mark.gpu
 def test_c_driver_round_trip_on_gpu(tmp_path):
-    """create / encode / decode_size / decode / error detail / batch / destroy from C, no Python in the data path."""
+    """create / encode / decode_size / decode / error detail / batch / stream encode in windows / stream decode / destroy from C,
+    no Python in the data path."""
     import subprocess
     exe = _build_c_driver(tmp_path)
     rc = subprocess.run([exe], capture_output=True, text=True)
