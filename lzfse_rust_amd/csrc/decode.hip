@@ -982,23 +982,29 @@ __device__ int vn_decode_serial(const uint8_t *p, uint64_t avail, uint32_t n_raw
 }
 
 constexpr uint32_t SHORT_COPY = 24;
+// LMDs per thread of the tile kernels (measured, dec_lz ms on Snappy x 256 / x 64 / 256 x 4 MiB: 1 per thread 2.47 / 0.94 / 5.94,
+// 2 per thread 2.17 / 0.81 / 5.07; 3 per thread, or 512 threads with a 16 KiB tile: slower again -- the tile overflows more often)
+constexpr int LZ_LPT = 2;
 constexpr int JUMP_SWEEPS = 3;   // jumping sweeps over a thread's unresolved bytes per workgroup barrier  // copies up to this many bytes are done by the owning lane
 
-template <int NT, int TILE>
+// LPT = LMDs per thread (consecutive slots): what a group costs is mostly its barriers and the latency of its dependent
+// loads, and both serve twice the bytes with two LMDs per thread (round 3)
+template <int NT, int TILE, int LPT>
 __global__ __launch_bounds__(NT) void dec_lz_kernel(
     const uint8_t *__restrict__ src, const StreamIn *__restrict__ streams, const StreamPlan *__restrict__ plan,
     const BlockDesc *__restrict__ blocks, const BlockResult *__restrict__ bres,
     const LmdRec *__restrict__ lmds, const uint8_t *__restrict__ lits, uint8_t *dst_all,
     StreamResult *__restrict__ sres) {
     constexpr int NW = NT / 64;
+    constexpr int NS = NT * LPT;     // LMDs (slots) per group
     __shared__ __attribute__((aligned(16))) uint8_t tile[TILE + 32];
-    __shared__ uint32_t s_off[NT];   // tile-relative output offset of the LMD (literals first)
-    __shared__ uint32_t s_lm[NT];    // l | m << 16
-    __shared__ uint32_t s_d[NT];
-    __shared__ uint32_t s_lit[NT];   // literal offset inside the block's literal buffer
+    __shared__ uint32_t s_off[NS];   // tile-relative output offset of the LMD (literals first)
+    __shared__ uint32_t s_lm[NS];    // l | m << 16
+    __shared__ uint32_t s_d[NS];
+    __shared__ uint32_t s_lit[NS];   // literal offset inside the block's literal buffer
     __shared__ uint16_t s_org[TILE];  // per-byte origin inside the tile (pointer jumping)
     __shared__ uint32_t s_dm[NT];     // bit k of s_dm[x]: tile byte x + k * NT is produced by an in-tile match
-    __shared__ uint32_t s_long[2 * NT];
+    __shared__ uint32_t s_long[2 * NS];
     __shared__ uint32_t s_scan[2 * NW + 4];
     __shared__ uint32_t s_cnt[4];
     __shared__ int s_status;
@@ -1056,72 +1062,108 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
         uint32_t lit_run = 0;
         for (uint32_t g0 = 0; g0 < d.n_lmd && !status;) {
             const uint64_t ta = __builtin_amdgcn_s_memtime();
-            const uint32_t idx = g0 + tid;
-            const bool valid = idx < d.n_lmd;
-            LmdRec r = valid ? bl[idx] : make_uint2(0, 0);
-            uint32_t l = r.x & 0xFFFF, m = r.x >> 16, dd = r.y;
-            uint32_t span = l + m;
-            uint32_t ex_l, ex_s, tot_l, tot_s;
-            block_excl_scan2<NT>(l, span, ex_l, ex_s, tot_l, tot_s, s_scan);
+            // slots tid * LPT + h, h = 0 .. LPT - 1: consecutive LMDs of one thread
+            const uint32_t idx0 = g0 + (uint32_t)tid * LPT;
+            bool valid[LPT];
+            uint32_t rx[LPT], l[LPT], m[LPT], dd[LPT], span[LPT];
+            uint32_t sum_l = 0, sum_s = 0;
+#pragma unroll
+            for (int h = 0; h < LPT; h++) {
+                valid[h] = idx0 + h < d.n_lmd;
+                const LmdRec r = valid[h] ? bl[idx0 + h] : make_uint2(0, 0);
+                rx[h] = r.x; l[h] = r.x & 0xFFFF; m[h] = r.x >> 16; dd[h] = r.y;
+                span[h] = l[h] + m[h];
+                sum_l += l[h]; sum_s += span[h];
+            }
+            uint32_t ex_l0, ex_s0, tot_l, tot_s;
+            block_excl_scan2<NT>(sum_l, sum_s, ex_l0, ex_s0, tot_l, tot_s, s_scan);
+            uint32_t ex_l[LPT], ex_s[LPT];
+#pragma unroll
+            for (int h = 0; h < LPT; h++) { ex_l[h] = ex_l0; ex_s[h] = ex_s0; ex_l0 += l[h]; ex_s0 += span[h]; }
             // participants: the longest prefix of LMDs whose output fits the tile
-            const bool part = valid && (ex_s + span <= (uint32_t)TILE);
+            bool part[LPT];
+            uint32_t my_parts = 0;
+#pragma unroll
+            for (int h = 0; h < LPT; h++) { part[h] = valid[h] && (ex_s[h] + span[h] <= (uint32_t)TILE); my_parts += part[h] ? 1u : 0u; }
             if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; s_cnt[2] = 0; s_cnt[3] = 0; }
             __syncthreads();
-            unsigned long long pb = __ballot(part);
-            if (lane == 0 && pb) atomicAdd(&s_cnt[0], (uint32_t)__popcll(pb));
+            {
+                const uint32_t wsum = wave_incl_scan(my_parts);
+                if (lane == 63 && wsum) atomicAdd(&s_cnt[0], wsum);
+            }
             __syncthreads();
             const uint32_t cnt = s_cnt[0];
-            // tile length = exclusive sum at slot cnt (or total if everyone participates)
-            if (tid == (int)cnt - 1) s_cnt[1] = ex_s + span;
+            // tile length = end of slot cnt - 1; the literals the participants consume
+            if (cnt) {
+                const uint32_t last = cnt - 1;
+                if ((uint32_t)tid == last / LPT) {
+#pragma unroll
+                    for (int h = 0; h < LPT; h++)
+                        if ((uint32_t)h == last % LPT) { s_cnt[1] = ex_s[h] + span[h]; s_cnt[2] = ex_l[h] + l[h]; }
+                }
+            }
             __syncthreads();
-            const uint32_t tile_len = s_cnt[1];
+            const uint32_t tile_len = s_cnt[1], lit_used = s_cnt[2];
             const uint64_t tile_base = out_pos;                       // stream-relative
             const uint32_t pad = (uint32_t)((uintptr_t)(dst + tile_base) & 15);  // LDS/global co-alignment
             uint8_t *t = tile + pad;
 
             const uint64_t tb = __builtin_amdgcn_s_memtime();
             // ---- classify + short copies by the owning lane ----
-            const uint64_t p_match = tile_base + ex_s + l;  // stream-relative position of the match
-            bool bad_d = part && m != 0 && (dd == 0 || (uint64_t)dd > p_match);  // lz/writer.rs:156-178
-            bool dep = false, far_long = false, lit_long = false;
-            if (part && !bad_d) {
-                s_off[tid] = ex_s; s_lm[tid] = r.x; s_d[tid] = dd; s_lit[tid] = lit_run + ex_l;
-                if (l) {
-                    if (l <= SHORT_COPY) {
-                        // three 8-byte loads in flight, then byte stores into the tile (the literal
-                        // scratch has 256 bytes of slack behind its last byte)
-                        const uint8_t *ls = blit + lit_run + ex_l;
-                        const uint64_t w0 = ld_u64(ls), w1 = l > 8 ? ld_u64(ls + 8) : 0, w2 = l > 16 ? ld_u64(ls + 16) : 0;
-                        lds_put24(t + ex_s, l, w0, w1, w2);
-                    } else lit_long = true;
+            bool dep[LPT], far_long[LPT], lit_long[LPT];
+            bool bad_any = false;
+            uint32_t n_dep = 0, n_long = 0;
+#pragma unroll
+            for (int h = 0; h < LPT; h++) {
+                const uint32_t slot = (uint32_t)tid * LPT + h;
+                const uint64_t p_match = tile_base + ex_s[h] + l[h];  // stream-relative position of the match
+                const bool bad_d = part[h] && m[h] != 0 && (dd[h] == 0 || (uint64_t)dd[h] > p_match);  // lz/writer.rs:156-178
+                bad_any |= bad_d;
+                dep[h] = false; far_long[h] = false; lit_long[h] = false;
+                if (part[h] && !bad_d) {
+                    s_off[slot] = ex_s[h]; s_lm[slot] = rx[h]; s_d[slot] = dd[h]; s_lit[slot] = lit_run + ex_l[h];
+                    if (l[h]) {
+                        if (l[h] <= SHORT_COPY) {
+                            // three 8-byte loads in flight, then byte stores into the tile (the literal
+                            // scratch has 256 bytes of slack behind its last byte)
+                            const uint8_t *ls = blit + lit_run + ex_l[h];
+                            const uint64_t w0 = ld_u64(ls), w1 = l[h] > 8 ? ld_u64(ls + 8) : 0, w2 = l[h] > 16 ? ld_u64(ls + 16) : 0;
+                            lds_put24(t + ex_s[h], l[h], w0, w1, w2);
+                        } else lit_long[h] = true;
+                    }
+                    if (m[h]) {
+                        // source [p - d, p - d + min(m, d)) ; far when it ends at or before the tile
+                        const uint32_t slen = m[h] < dd[h] ? m[h] : dd[h];
+                        if (dd[h] >= m[h] && p_match - dd[h] + slen <= tile_base) {
+                            if (m[h] <= SHORT_COPY) {
+                                const uint8_t *ms = dst + (p_match - dd[h]);
+                                // (24 bytes are read wherever they lie inside the stream's output INCLUDING this tile's own place, which is
+                                // allocated and not yet written: only the first m are used. Byte by byte such a copy is a round trip per
+                                // byte, and a tile's first matches often start a few bytes before it.)
+                                if (p_match - dd[h] + 24 <= tile_base + tile_len) {
+                                    const uint64_t w0 = ld_u64(ms), w1 = m[h] > 8 ? ld_u64(ms + 8) : 0, w2 = m[h] > 16 ? ld_u64(ms + 16) : 0;
+                                    lds_put24(t + ex_s[h] + l[h], m[h], w0, w1, w2);
+                                } else {
+                                    for (uint32_t k = 0; k < m[h]; k++) t[ex_s[h] + l[h] + k] = ms[k];
+                                }
+                            } else far_long[h] = true;
+                        } else dep[h] = true;
+                    }
                 }
-                if (m) {
-                    // source [p - d, p - d + min(m, d)) ; far when it ends at or before the tile
-                    uint32_t slen = m < dd ? m : dd;
-                    if (dd >= m && p_match - dd + slen <= tile_base) {
-                        if (m <= SHORT_COPY) {
-                            const uint8_t *ms = dst + (p_match - dd);
-                            // (24 bytes are read wherever they lie inside the stream's output INCLUDING this tile's own place, which is
-                            // allocated and not yet written: only the first m are used. Byte by byte such a copy is a round trip per
-                            // byte, and a tile's first matches often start a few bytes before it.)
-                            if (p_match - dd + 24 <= tile_base + tile_len) {
-                                const uint64_t w0 = ld_u64(ms), w1 = m > 8 ? ld_u64(ms + 8) : 0, w2 = m > 16 ? ld_u64(ms + 16) : 0;
-                                lds_put24(t + ex_s + l, m, w0, w1, w2);
-                            } else {
-                                for (uint32_t k = 0; k < m; k++) t[ex_s + l + k] = ms[k];
-                            }
-                        } else far_long = true;
-                    } else dep = true;
-                }
+                n_dep += dep[h] ? 1u : 0u;
+                n_long += (lit_long[h] ? 1u : 0u) + (far_long[h] ? 1u : 0u);
             }
-            unsigned long long bb = __ballot(bad_d);
+            unsigned long long bb = __ballot(bad_any);
             if (bb && lane == 0) atomicOr((int *)&s_status, LZFSE_MI_BAD_D_VALUE);
-            // compaction of the long copies; s_dep becomes the per-slot "match not written yet" flag
-            uint32_t nl = (lit_long ? 1u : 0u) + (far_long ? 1u : 0u);
+            // compaction of the long copies
             uint32_t ex_dep, ex_long, tot_dep, tot_long;
-            block_excl_scan2<NT>(dep ? 1u : 0u, nl, ex_dep, ex_long, tot_dep, tot_long, s_scan);
-            if (lit_long) s_long[ex_long++] = tid * 2;
-            if (far_long) s_long[ex_long] = tid * 2 + 1;
+            block_excl_scan2<NT>(n_dep, n_long, ex_dep, ex_long, tot_dep, tot_long, s_scan);
+#pragma unroll
+            for (int h = 0; h < LPT; h++) {
+                const uint32_t slot = (uint32_t)tid * LPT + h;
+                if (lit_long[h]) s_long[ex_long++] = slot * 2;
+                if (far_long[h]) s_long[ex_long++] = slot * 2 + 1;
+            }
             __syncthreads();
             if (s_status) { status = s_status; break; }
             const uint64_t tc = __builtin_amdgcn_s_memtime();
@@ -1144,8 +1186,6 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
             //      overlap allowed): byte-level pointer jumping inside LDS. Every byte of the tile gets an
             //      origin (itself when it is already final); origin <- origin[origin] until all origins are
             //      final bytes, then one gather. Chains of any length collapse in O(log) rounds.
-            const uint32_t mo = ex_s + l;                              // tile offset of the match
-            const int64_t so = (int64_t)mo - (int64_t)dd;              // tile offset of its source (may be < 0)
             if (tot_dep) {
                 // s_dm: one bit per tile byte that is produced by an in-tile match (its origin s_org[] is meaningful);
                 // thread x owns bytes x, x + NT, ... and finds their bits in s_dm[x], so it needs no sweep over the
@@ -1155,12 +1195,16 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
                 s_dm[tid] = 0;
                 if (tid == 0) s_cnt[3] = 0;
                 __syncthreads();
-                if (dep) {
-                    if (m <= SHORT_COPY) {
+#pragma unroll
+                for (int h = 0; h < LPT; h++) {
+                    if (!dep[h]) continue;
+                    const uint32_t mo = ex_s[h] + l[h];                              // tile offset of the match
+                    const int64_t so = (int64_t)mo - (int64_t)dd[h];              // tile offset of its source (may be < 0)
+                    if (m[h] <= SHORT_COPY) {
                         // the part of the source that lies before the tile: finished output of earlier tiles (one wide read)
                         uint32_t k0 = 0;
                         if (so < 0) {
-                            k0 = (uint32_t)min((int64_t)m, -so);
+                            k0 = (uint32_t)min((int64_t)m[h], -so);
                             const uint8_t *ms = dst + ((int64_t)tile_base + so);
                             if (so + 24 <= (int64_t)tile_len) {
                                 const uint64_t w0 = ld_u64(ms), w1 = k0 > 8 ? ld_u64(ms + 8) : 0, w2 = k0 > 16 ? ld_u64(ms + 16) : 0;
@@ -1169,13 +1213,13 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
                                 for (uint32_t k = 0; k < k0; k++) t[mo + k] = ms[k];
                             }
                         }
-                        for (uint32_t k = k0; k < m; k++) {
+                        for (uint32_t k = k0; k < m[h]; k++) {
                             const uint32_t sp = (uint32_t)(so + k);
                             const uint32_t q = mo + k;
                             s_org[q] = (uint16_t)sp; atomicOr(&s_dm[q & (NT - 1)], 1u << (q >> NTS));
                         }
                     } else {
-                        s_long[atomicAdd(&s_cnt[3], 1u)] = tid;
+                        s_long[atomicAdd(&s_cnt[3], 1u)] = (uint32_t)tid * LPT + h;
                     }
                 }
                 __syncthreads();
@@ -1232,9 +1276,7 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
             }
             out_pos += tile_len;
             // lit_run advances by the literals of the participants only
-            if (tid == (int)cnt - 1) s_cnt[2] = ex_l + l;
-            __syncthreads();
-            lit_run += s_cnt[2];
+            lit_run += lit_used;
             g0 += cnt;
             __syncthreads();
             const uint64_t tf = __builtin_amdgcn_s_memtime();
@@ -1362,7 +1404,7 @@ __global__ __launch_bounds__(256) void dec_ck_kernel(const StreamPlan *__restric
     }
 }
 
-template <int NT, int TILE>
+template <int NT, int TILE, int LPT>
 __global__ __launch_bounds__(NT) void dec_lzp_kernel(
     const uint8_t *__restrict__ src, const StreamIn *__restrict__ streams, const StreamPlan *__restrict__ plan,
     const uint32_t *__restrict__ mlist, uint32_t n_multi, uint32_t K,
@@ -1370,15 +1412,16 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
     const LmdRec *__restrict__ lmds, const uint8_t *__restrict__ lits, const uint2 *__restrict__ ck, uint8_t *dst_all,
     StreamResult *__restrict__ sres, uint32_t *__restrict__ state, uint32_t scatter /* diagnostic: pretend the workgroups of a stream sit on different XCDs */) {
     constexpr int NW = NT / 64;
+    constexpr int NS = NT * LPT;     // LMDs (slots) of a ticket: LPT consecutive ones per thread (see dec_lz_kernel)
     __shared__ __attribute__((aligned(16))) uint8_t tile[TILE + 32];
-    __shared__ uint32_t s_off[NT];
-    __shared__ uint32_t s_lm[NT];
-    __shared__ uint32_t s_d[NT];
-    __shared__ uint32_t s_lit[NT];
+    __shared__ uint32_t s_off[NS];
+    __shared__ uint32_t s_lm[NS];
+    __shared__ uint32_t s_d[NS];
+    __shared__ uint32_t s_lit[NS];
     __shared__ uint16_t s_org[TILE];
     __shared__ uint32_t s_dm[NT];
-    __shared__ uint32_t s_long[2 * NT];   // slot * 4 + kind: 0 long literal run, 1 long match from earlier output, 2 long match that reads the tile, 3 = 1 but its source is final already
-    __shared__ uint32_t s_turn[NT];       // what has to wait for the turn: slot * 2 + (0: kind 1, 1: the part of a kind 2 match that lies before the tile)
+    __shared__ uint32_t s_long[2 * NS];   // slot * 4 + kind: 0 long literal run, 1 long match from earlier output, 2 long match that reads the tile, 3 = 1 but its source is final already
+    __shared__ uint32_t s_turn[NS];       // what has to wait for the turn: slot * 2 + (0: kind 1, 1: the part of a kind 2 match that lies before the tile)
     __shared__ uint32_t s_scan[2 * NW + 4];
     __shared__ uint32_t s_cnt[4];
     __shared__ uint32_t s_tk[2];
@@ -1403,7 +1446,7 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
     }
     auto n_tickets = [](const BlockDesc &bd) -> uint32_t {
         if (bd.kind != KIND_VX1 && bd.kind != KIND_VX2) return 1u;
-        return bd.n_lmd ? (bd.n_lmd + NT - 1) / NT : 1u;
+        return bd.n_lmd ? (bd.n_lmd + NS - 1) / NS : 1u;
     };
     // all threads: false when the stream has failed (or the wait gave up) -- leave
     auto wait_turn = [&](uint32_t T) -> bool {
@@ -1513,86 +1556,124 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
             break;
         }
         const uint8_t *blit = lits + d.lit_base;
-        const uint2 c0 = d.n_lmd ? ck[(d.lmd_base >> 8) + (pl.blk_base + bi) + ((g * NT) >> 8)] : make_uint2(0, 0);
+        const uint2 c0 = d.n_lmd ? ck[(d.lmd_base >> 8) + (pl.blk_base + bi) + ((g * NS) >> 8)] : make_uint2(0, 0);
         uint32_t lit_run = c0.x;
         uint64_t out_pos = d.dst_rel + c0.y;
-        const uint32_t g_end = min(d.n_lmd, (g + 1) * (uint32_t)NT);
+        const uint32_t g_end = min(d.n_lmd, (g + 1) * (uint32_t)NS);
         bool have_turn = false, gone = false;
         uint64_t t1 = __builtin_amdgcn_s_memtime(), t2 = t1, t3 = t1, t3b = t1;
         cy_setup += t1 - t0; n_tk++;
-        for (uint32_t g0 = g * NT; g0 < g_end;) {
-            const uint32_t idx = g0 + tid;
-            const bool valid = idx < g_end;
-            LmdRec r = valid ? bl[idx] : make_uint2(0, 0);
-            const uint32_t l = r.x & 0xFFFF, m = r.x >> 16, dd = r.y;
-            const uint32_t span = l + m;
-            uint32_t ex_l, ex_s, tot_l, tot_s;
-            block_excl_scan2<NT>(l, span, ex_l, ex_s, tot_l, tot_s, s_scan);
-            const bool part = valid && (ex_s + span <= (uint32_t)TILE);
+        for (uint32_t g0 = g * NS; g0 < g_end;) {
+            const uint32_t idx0 = g0 + (uint32_t)tid * LPT;
+            bool valid[LPT];
+            uint32_t rx[LPT], l[LPT], m[LPT], dd[LPT], span[LPT];
+            uint32_t sum_l = 0, sum_s = 0;
+#pragma unroll
+            for (int h = 0; h < LPT; h++) {
+                valid[h] = idx0 + h < g_end;
+                const LmdRec r = valid[h] ? bl[idx0 + h] : make_uint2(0, 0);
+                rx[h] = r.x; l[h] = r.x & 0xFFFF; m[h] = r.x >> 16; dd[h] = r.y;
+                span[h] = l[h] + m[h];
+                sum_l += l[h]; sum_s += span[h];
+            }
+            uint32_t ex_l0, ex_s0, tot_l, tot_s;
+            block_excl_scan2<NT>(sum_l, sum_s, ex_l0, ex_s0, tot_l, tot_s, s_scan);
+            uint32_t ex_l[LPT], ex_s[LPT];
+#pragma unroll
+            for (int h = 0; h < LPT; h++) { ex_l[h] = ex_l0; ex_s[h] = ex_s0; ex_l0 += l[h]; ex_s0 += span[h]; }
+            bool part[LPT];
+            uint32_t my_parts = 0;
+#pragma unroll
+            for (int h = 0; h < LPT; h++) { part[h] = valid[h] && (ex_s[h] + span[h] <= (uint32_t)TILE); my_parts += part[h] ? 1u : 0u; }
             if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; s_cnt[2] = 0; s_cnt[3] = 0; }
             __syncthreads();
-            unsigned long long pb = __ballot(part);
-            if (lane == 0 && pb) atomicAdd(&s_cnt[0], (uint32_t)__popcll(pb));
+            {
+                const uint32_t wsum = wave_incl_scan(my_parts);
+                if (lane == 63 && wsum) atomicAdd(&s_cnt[0], wsum);
+            }
             __syncthreads();
             const uint32_t cnt = s_cnt[0];
-            if (tid == (int)cnt - 1) s_cnt[1] = ex_s + span;
+            if (cnt) {
+                const uint32_t last = cnt - 1;
+                if ((uint32_t)tid == last / LPT) {
+#pragma unroll
+                    for (int h = 0; h < LPT; h++)
+                        if ((uint32_t)h == last % LPT) { s_cnt[1] = ex_s[h] + span[h]; s_cnt[2] = ex_l[h] + l[h]; }
+                }
+            }
             __syncthreads();
-            const uint32_t tile_len = s_cnt[1];
+            const uint32_t tile_len = s_cnt[1], lit_used = s_cnt[2];
             const uint64_t tile_base = out_pos;
             const uint32_t pad = (uint32_t)((uintptr_t)(dst + tile_base) & 15);
             uint8_t *t = tile + pad;
 
             // ---- independent part: classification, literals, origins of the matches that read the tile ----
-            const uint64_t p_match = tile_base + ex_s + l;
-            const bool bad_d = part && m != 0 && (dd == 0 || (uint64_t)dd > p_match);
-            bool dep = false, far = false, lit_long = false, early = false;
-            if (part && !bad_d) {
-                s_off[tid] = ex_s; s_lm[tid] = r.x; s_d[tid] = dd; s_lit[tid] = lit_run + ex_l;
-                if (l) {
-                    if (l <= SHORT_COPY) {
-                        const uint8_t *ls = blit + lit_run + ex_l;
-                        const uint64_t w0 = ld_u64(ls), w1 = l > 8 ? ld_u64(ls + 8) : 0, w2 = l > 16 ? ld_u64(ls + 16) : 0;
-                        lds_put24(t + ex_s, l, w0, w1, w2);
-                    } else lit_long = true;
+            bool dep[LPT], far[LPT], early[LPT], m_long[LPT], lit_long[LPT];
+            bool bad_any = false;
+            uint32_t n_dep = 0, n_long = 0;
+#pragma unroll
+            for (int h = 0; h < LPT; h++) {
+                const uint32_t slot = (uint32_t)tid * LPT + h;
+                const uint64_t p_match = tile_base + ex_s[h] + l[h];
+                const bool bad_d = part[h] && m[h] != 0 && (dd[h] == 0 || (uint64_t)dd[h] > p_match);
+                bad_any |= bad_d;
+                dep[h] = false; far[h] = false; lit_long[h] = false; early[h] = false;
+                if (part[h] && !bad_d) {
+                    s_off[slot] = ex_s[h]; s_lm[slot] = rx[h]; s_d[slot] = dd[h]; s_lit[slot] = lit_run + ex_l[h];
+                    if (l[h]) {
+                        if (l[h] <= SHORT_COPY) {
+                            const uint8_t *ls = blit + lit_run + ex_l[h];
+                            const uint64_t w0 = ld_u64(ls), w1 = l[h] > 8 ? ld_u64(ls + 8) : 0, w2 = l[h] > 16 ? ld_u64(ls + 16) : 0;
+                            lds_put24(t + ex_s[h], l[h], w0, w1, w2);
+                        } else lit_long[h] = true;
+                    }
+                    if (m[h]) {
+                        const uint32_t slen = m[h] < dd[h] ? m[h] : dd[h];
+                        if (dd[h] >= m[h] && p_match - dd[h] + slen <= tile_base) {
+                            far[h] = true;
+                            early[h] = p_match - dd[h] + 24 <= prev_end;    // 24 readable bytes of final output
+                            if (early[h] && m[h] <= SHORT_COPY) {
+                                const uint8_t *ms = dst + (p_match - dd[h]);
+                                const uint64_t w0 = ld_u64_l2(ms), w1 = m[h] > 8 ? ld_u64_l2(ms + 8) : 0, w2 = m[h] > 16 ? ld_u64_l2(ms + 16) : 0;
+                                lds_put24(t + ex_s[h] + l[h], m[h], w0, w1, w2);
+                            }
+                            if (early[h] && m[h] > SHORT_COPY) early[h] = p_match - dd[h] + m[h] <= prev_end;   // the whole source
+                        } else dep[h] = true;
+                    }
                 }
-                if (m) {
-                    const uint32_t slen = m < dd ? m : dd;
-                    if (dd >= m && p_match - dd + slen <= tile_base) {
-                        far = true;
-                        early = p_match - dd + 24 <= prev_end;    // 24 readable bytes of final output
-                        if (early && m <= SHORT_COPY) {
-                            const uint8_t *ms = dst + (p_match - dd);
-                            const uint64_t w0 = ld_u64_l2(ms), w1 = m > 8 ? ld_u64_l2(ms + 8) : 0, w2 = m > 16 ? ld_u64_l2(ms + 16) : 0;
-                            lds_put24(t + ex_s + l, m, w0, w1, w2);
-                        }
-                        if (early && m > SHORT_COPY) early = p_match - dd + m <= prev_end;   // the whole source
-                    } else dep = true;
-                }
+                m_long[h] = (far[h] || dep[h]) && m[h] > SHORT_COPY;
+                n_dep += dep[h] ? 1u : 0u;
+                n_long += (lit_long[h] ? 1u : 0u) + (m_long[h] ? 1u : 0u);
             }
-            const bool m_long = (far || dep) && m > SHORT_COPY;
-            unsigned long long bb = __ballot(bad_d);
+            unsigned long long bb = __ballot(bad_any);
             if (bb && lane == 0) atomicOr((int *)&s_status, LZFSE_MI_BAD_D_VALUE);
-            const uint32_t nl = (lit_long ? 1u : 0u) + (m_long ? 1u : 0u);
             uint32_t ex_dep, ex_long, tot_dep, tot_long;
-            block_excl_scan2<NT>(dep ? 1u : 0u, nl, ex_dep, ex_long, tot_dep, tot_long, s_scan);
-            if (lit_long) s_long[ex_long++] = tid * 4;
-            if (m_long) s_long[ex_long] = tid * 4 + (far ? (early ? 3 : 1) : 2);
-            const uint32_t mo = ex_s + l;
-            const int64_t so = (int64_t)mo - (int64_t)dd;
-            if (m_long && ((far && !early) || (dep && so < 0))) s_turn[atomicAdd(&s_cnt[3], 1u)] = tid * 2 + (far ? 0u : 1u);
+            block_excl_scan2<NT>(n_dep, n_long, ex_dep, ex_long, tot_dep, tot_long, s_scan);
+#pragma unroll
+            for (int h = 0; h < LPT; h++) {
+                const uint32_t slot = (uint32_t)tid * LPT + h;
+                if (lit_long[h]) s_long[ex_long++] = slot * 4;
+                if (m_long[h]) s_long[ex_long++] = slot * 4 + (far[h] ? (early[h] ? 3 : 1) : 2);
+                const int64_t so = (int64_t)(ex_s[h] + l[h]) - (int64_t)dd[h];
+                if (m_long[h] && ((far[h] && !early[h]) || (dep[h] && so < 0))) s_turn[atomicAdd(&s_cnt[3], 1u)] = slot * 2 + (far[h] ? 0u : 1u);
+            }
             static_assert(TILE / NT <= 32 && (NT & (NT - 1)) == 0, "one mask bit per owned byte");
             constexpr uint32_t NTS = 31 - __builtin_clz((unsigned)NT);
             s_dm[tid] = 0;
             __syncthreads();
             const bool tile_bad = s_status != 0;
             if (!tile_bad) {
-                if (dep && m <= SHORT_COPY) {
-                    for (uint32_t k = 0; k < m; k++) {
-                        const int64_t sp = so + k;
-                        const uint32_t q = mo + k;
-                        if (sp >= 0) { s_org[q] = (uint16_t)sp; atomicOr(&s_dm[q & (NT - 1)], 1u << (q >> NTS)); }
+#pragma unroll
+                for (int h = 0; h < LPT; h++)
+                    if (dep[h] && m[h] <= SHORT_COPY) {
+                        const uint32_t mo = ex_s[h] + l[h];
+                        const int64_t so = (int64_t)mo - (int64_t)dd[h];
+                        for (uint32_t k = 0; k < m[h]; k++) {
+                            const int64_t sp = so + k;
+                            const uint32_t q = mo + k;
+                            if (sp >= 0) { s_org[q] = (uint16_t)sp; atomicOr(&s_dm[q & (NT - 1)], 1u << (q >> NTS)); }
+                        }
                     }
-                }
                 for (uint32_t q = wave; q < tot_long; q += NW) {
                     const uint32_t e = s_long[q], slot = e >> 2, kind = e & 3;
                     const uint32_t o = s_off[slot], lm = s_lm[slot];
@@ -1685,20 +1766,25 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
                     if (lane * 8u < mm && src_pos + lane * 8u + 8 <= tile_base + tile_len) { w_first = ld_u64_l2(dst + src_pos + lane * 8u); pre_first = true; }
                 }
             }
-            if (part && m && !m_long && !early) {
+#pragma unroll
+            for (int h = 0; h < LPT; h++) {
+                if (!(part[h] && m[h] && !m_long[h] && !early[h])) continue;
                 // (24 bytes are read wherever they lie inside this stream's output so far INCLUDING this tile's own place,
                 // which is allocated and not yet written: only the first m of them are used. Byte by byte these copies are one
                 // round trip each, and a tile's first matches often start a few bytes before it.)
-                if (far) {
-                    const uint8_t *ms = dst + (p_match - dd);
-                    if (p_match - dd + 24 <= tile_base + tile_len) {
-                        const uint64_t w0 = ld_u64_l2(ms), w1 = m > 8 ? ld_u64_l2(ms + 8) : 0, w2 = m > 16 ? ld_u64_l2(ms + 16) : 0;
-                        lds_put24(t + mo, m, w0, w1, w2);
+                const uint32_t mo = ex_s[h] + l[h];
+                const int64_t so = (int64_t)mo - (int64_t)dd[h];
+                const uint64_t p_match = tile_base + mo;
+                if (far[h]) {
+                    const uint8_t *ms = dst + (p_match - dd[h]);
+                    if (p_match - dd[h] + 24 <= tile_base + tile_len) {
+                        const uint64_t w0 = ld_u64_l2(ms), w1 = m[h] > 8 ? ld_u64_l2(ms + 8) : 0, w2 = m[h] > 16 ? ld_u64_l2(ms + 16) : 0;
+                        lds_put24(t + mo, m[h], w0, w1, w2);
                     } else {
-                        for (uint32_t k = 0; k < m; k++) t[mo + k] = ld_u8_l2(ms + k);
+                        for (uint32_t k = 0; k < m[h]; k++) t[mo + k] = ld_u8_l2(ms + k);
                     }
                 } else if (so < 0) {
-                    const uint32_t nb = (uint32_t)min((int64_t)m, -so);
+                    const uint32_t nb = (uint32_t)min((int64_t)m[h], -so);
                     const uint8_t *ms = dst + ((int64_t)tile_base + so);
                     if (so + 24 <= (int64_t)tile_len) {
                         const uint64_t w0 = ld_u64_l2(ms), w1 = nb > 8 ? ld_u64_l2(ms + 8) : 0, w2 = nb > 16 ? ld_u64_l2(ms + 16) : 0;
@@ -1733,9 +1819,7 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
                 if (tail0 + tid < tile_len && tid < 16) gp[tail0 + tid] = t[tail0 + tid];
             }
             out_pos += tile_len;
-            if (tid == (int)cnt - 1) s_cnt[2] = ex_l + l;
-            __syncthreads();
-            lit_run += s_cnt[2];
+            lit_run += lit_used;
             g0 += cnt;
             // (a group that did not fit one tile goes on: what was just written must have reached the L2 before the next
             // part reads it past the L1)
@@ -1993,10 +2077,10 @@ void launch_dec_lz(int variant, const uint8_t *src, const StreamIn *streams, con
                    const uint8_t *lits, uint8_t *dst, StreamResult *sres, hipStream_t st) {
     if (!n_streams) return;
     if (variant == 0)
-        hipLaunchKernelGGL((dec_lz_kernel<256, 8192>), dim3(n_streams), dim3(256), 0, st, src, streams, plan,
+        hipLaunchKernelGGL((dec_lz_kernel<256, 8192, LZ_LPT>), dim3(n_streams), dim3(256), 0, st, src, streams, plan,
                            blocks, bres, lmds, lits, dst, sres);
     else
-        hipLaunchKernelGGL((dec_lz_kernel<1024, 32768>), dim3(n_streams), dim3(1024), 0, st, src, streams, plan,
+        hipLaunchKernelGGL((dec_lz_kernel<1024, 32768, LZ_LPT>), dim3(n_streams), dim3(1024), 0, st, src, streams, plan,
                            blocks, bres, lmds, lits, dst, sres);
 }
 
@@ -2008,10 +2092,10 @@ void launch_dec_lzp(int variant, uint32_t K, const uint8_t *src, const StreamIn 
     hipLaunchKernelGGL(dec_ck_kernel, dim3(n_blocks), dim3(256), 0, st, plan, blocks, n_blocks, bres, lmds, ck);
     const uint32_t grid = ((n_multi + 7) / 8) * 8 * K;
     if (variant == 0)
-        hipLaunchKernelGGL((dec_lzp_kernel<256, 8192>), dim3(grid), dim3(256), 0, st, src, streams, plan, mlist, n_multi, K,
+        hipLaunchKernelGGL((dec_lzp_kernel<256, 8192, LZ_LPT>), dim3(grid), dim3(256), 0, st, src, streams, plan, mlist, n_multi, K,
                            blocks, bres, lmds, lits, ck, dst, sres, state, scatter ? 1u : 0u);
     else
-        hipLaunchKernelGGL((dec_lzp_kernel<1024, 32768>), dim3(grid), dim3(1024), 0, st, src, streams, plan, mlist, n_multi, K,
+        hipLaunchKernelGGL((dec_lzp_kernel<1024, 32768, LZ_LPT>), dim3(grid), dim3(1024), 0, st, src, streams, plan, mlist, n_multi, K,
                            blocks, bres, lmds, lits, ck, dst, sres, state, scatter ? 1u : 0u);
 }
 
