@@ -5,8 +5,11 @@
 
 Without -i / -o it reads standard input / writes standard output, like lzfoo. -encode writes this build's chunked
 container ("LZMC": independent 4 MiB LZFSE streams, chunk c on device c mod g), or with --plain ONE
-ordinary LZFSE stream that any LZFSE decoder reads (the reference's own output format). -decode takes either.
--v prints lzfoo's statistics block (sizes, ratio, ns/B, MB/s of raw bytes) on standard error.
+ordinary LZFSE stream: byte for byte what lzfoo itself writes (lzfoo/main.rs:89 encodes with LzfseRingEncoder::encode,
+the ring / stream encoder's parse), streamed from the input to the output a window at a time in bounded memory, as
+lzfoo's 512 KiB ring does. -decode takes either; a plain stream is decoded through LzfseRingDecoder::decode
+(lzfoo/main.rs:104), streamed as well. -v prints lzfoo's statistics block (sizes, ratio, ns/B, MB/s of raw bytes) on
+standard error.
 """
 import argparse
 import sys
@@ -45,35 +48,55 @@ def main(argv=None):
     a = ap.parse_args(argv)
 
     import lzfse_rust_amd as lz
-    data = open(a.input, "rb").read() if a.input else sys.stdin.buffer.read()
+
+    class _Counting:
+        """the output side: counts what goes through"""
+
+        def __init__(self, f):
+            self.f, self.n = f, 0
+
+        def write(self, b):
+            self.f.write(b)
+            self.n += len(b)
+
+    fin = open(a.input, "rb") if a.input else sys.stdin.buffer
     t0 = time.perf_counter()
+    n_in = n_out = 0
     try:
         ctxs = [lz.Context(int(d)) for d in a.devices.split(",")]
-        if mode == "encode":
-            if a.plain:
-                dst = bytearray()
-                lz.LzfseEncoder(context=ctxs[0]).encode_bytes(data, dst)
-                out = bytes(dst)
-            else:
-                out = lz.encode_chunked(ctxs, data, a.chunk).tobytes()
-        elif data[:4] == b"LZMC":
-            out = lz.decode_chunked(ctxs, data).tobytes()
+        head = fin.peek(4)[:4] if mode == "decode" and hasattr(fin, "peek") else b""
+        streamed = (mode == "encode" and a.plain) or (mode == "decode" and head != b"LZMC")
+        if streamed:
+            # one LZFSE stream, reader -> writer (lzfoo/main.rs:86-107)
+            fout = open(a.output, "wb") if a.output else sys.stdout.buffer
+            sink = _Counting(fout)
+            try:
+                if mode == "encode":
+                    n_in, n_out = lz.LzfseRingEncoder(context=ctxs[0]).encode(fin, sink)
+                else:
+                    n_in, n_out = lz.LzfseRingDecoder(context=ctxs[0]).decode(fin, sink)
+                fout.flush()
+            except BrokenPipeError:
+                return 0
+            finally:
+                if a.output:
+                    fout.close()
         else:
-            dst = bytearray()
-            lz.LzfseDecoder(context=ctxs[0]).decode_bytes(data, dst)
-            out = bytes(dst)
+            data = fin.read()
+            out = lz.encode_chunked(ctxs, data, a.chunk).tobytes() if mode == "encode" else lz.decode_chunked(ctxs, data).tobytes()
+            n_in, n_out = len(data), len(out)
+            if a.output:
+                open(a.output, "wb").write(out)
+            else:
+                try:
+                    sys.stdout.buffer.write(out)
+                except BrokenPipeError:
+                    return 0
     except lz.LzfseError as e:
         print(f"Error: {'Decode' if mode == 'decode' else 'Encode'}: {e}", file=sys.stderr)
         return 1
-    if a.output:
-        open(a.output, "wb").write(out)
-    else:
-        try:
-            sys.stdout.buffer.write(out)
-        except BrokenPipeError:
-            return 0
     if a.v:
-        _stats(t0, len(data), len(out), a.input or "stdin", a.output or "stdout", mode)
+        _stats(t0, n_in, n_out, a.input or "stdin", a.output or "stdout", mode)
     return 0
 
 

@@ -597,11 +597,16 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
                       (const StreamPlan *)c->d_plan.p, ns, (const BlockDesc *)c->d_blocks.p,
                       (const BlockResult *)c->d_bres.p, (const LmdRec *)c->d_lmds.p, (const uint8_t *)c->d_lits.p,
                       (uint8_t *)d_dst, (StreamResult *)c->d_sres.p, st);
-        if (!mlist.empty())
-            launch_dec_lzp(pipe_variant, pipe_k, (const uint8_t *)d_src, (const StreamIn *)c->d_streams.p,
+        if (!mlist.empty()) {
+            // (tickets of two LMDs per thread when the streams are long enough to keep their workgroups in tickets: dec_lzp_kernel)
+            uint64_t pipe_raw = 0;
+            for (uint32_t i : mlist) pipe_raw += h_walk[i].raw_total;
+            const int pipe_lpt = pipe_raw >= ((uint64_t)mlist.size() << 20) ? 2 : 1;
+            launch_dec_lzp(pipe_variant, pipe_k, pipe_lpt, (const uint8_t *)d_src, (const StreamIn *)c->d_streams.p,
                            (const StreamPlan *)c->d_plan.p, d_mlist, (uint32_t)mlist.size(), (const BlockDesc *)c->d_blocks.p,
                            (uint32_t)nb, (const BlockResult *)c->d_bres.p, (const LmdRec *)c->d_lmds.p, (const uint8_t *)c->d_lits.p,
                            (uint2 *)c->d_ck.p, (uint8_t *)d_dst, (StreamResult *)c->d_sres.p, d_lzp_state, c->diag_pipe_scatter != 0, st);
+        }
     }
     if (nj) {
         launch_dec_jump((const uint8_t *)d_src, (const StreamIn *)c->d_streams.p, (const StreamPlan *)c->d_plan.p,

@@ -2084,19 +2084,30 @@ void launch_dec_lz(int variant, const uint8_t *src, const StreamIn *streams, con
                            blocks, bres, lmds, lits, dst, sres);
 }
 
-void launch_dec_lzp(int variant, uint32_t K, const uint8_t *src, const StreamIn *streams, const StreamPlan *plan,
+void launch_dec_lzp(int variant, uint32_t K, int lpt, const uint8_t *src, const StreamIn *streams, const StreamPlan *plan,
                     const uint32_t *mlist, uint32_t n_multi, const BlockDesc *blocks, uint32_t n_blocks, const BlockResult *bres,
                     const LmdRec *lmds, const uint8_t *lits, uint2 *ck, uint8_t *dst, StreamResult *sres, uint32_t *state,
                     bool scatter, hipStream_t st) {
     if (!n_multi || !K) return;
     hipLaunchKernelGGL(dec_ck_kernel, dim3(n_blocks), dim3(256), 0, st, plan, blocks, n_blocks, bres, lmds, ck);
     const uint32_t grid = ((n_multi + 7) / 8) * 8 * K;
-    if (variant == 0)
-        hipLaunchKernelGGL((dec_lzp_kernel<256, 8192, LZ_LPT>), dim3(grid), dim3(256), 0, st, src, streams, plan, mlist, n_multi, K,
-                           blocks, bres, lmds, lits, ck, dst, sres, state, scatter ? 1u : 0u);
-    else
-        hipLaunchKernelGGL((dec_lzp_kernel<1024, 32768, LZ_LPT>), dim3(grid), dim3(1024), 0, st, src, streams, plan, mlist, n_multi, K,
-                           blocks, bres, lmds, lits, ck, dst, sres, state, scatter ? 1u : 0u);
+    // lpt: LMDs per thread = tickets of NT or 2 NT LMDs. Two halve a large stream's hand-overs; a stream of a few thousand
+    // LMDs would be left with fewer tickets than workgroups (html, 3 691 LMDs: 4 tickets of 1 024 keep K = 4 busy, 2 of 2 048 do not)
+    if (variant == 0) {
+        if (lpt == 2)
+            hipLaunchKernelGGL((dec_lzp_kernel<256, 8192, 2>), dim3(grid), dim3(256), 0, st, src, streams, plan, mlist, n_multi, K,
+                               blocks, bres, lmds, lits, ck, dst, sres, state, scatter ? 1u : 0u);
+        else
+            hipLaunchKernelGGL((dec_lzp_kernel<256, 8192, 1>), dim3(grid), dim3(256), 0, st, src, streams, plan, mlist, n_multi, K,
+                               blocks, bres, lmds, lits, ck, dst, sres, state, scatter ? 1u : 0u);
+    } else {
+        if (lpt == 2)
+            hipLaunchKernelGGL((dec_lzp_kernel<1024, 32768, 2>), dim3(grid), dim3(1024), 0, st, src, streams, plan, mlist, n_multi, K,
+                               blocks, bres, lmds, lits, ck, dst, sres, state, scatter ? 1u : 0u);
+        else
+            hipLaunchKernelGGL((dec_lzp_kernel<1024, 32768, 1>), dim3(grid), dim3(1024), 0, st, src, streams, plan, mlist, n_multi, K,
+                               blocks, bres, lmds, lits, ck, dst, sres, state, scatter ? 1u : 0u);
+    }
 }
 
 void launch_dec_jump(const uint8_t *src, const StreamIn *streams, const StreamPlan *plan, const StreamWalk *walk, uint32_t n_streams,

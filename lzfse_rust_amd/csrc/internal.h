@@ -73,7 +73,7 @@ void launch_dec_lz(int variant, const uint8_t *src, const StreamIn *streams, con
 // in that XCD's L2), [LZP_BAD] the word a workgroup on ANOTHER XCD raises through memory (nobody near writes its line, so
 // device-scope loads of it are not served from a dirty local copy), [LZP_DIAG ..] eight u64 cycle counters.
 constexpr uint32_t LZP_STATE_WORDS = 160, LZP_NEXT = 0, LZP_HOME = 1, LZP_DONE = 32, LZP_BAD = 64, LZP_DIAG = 96;
-void launch_dec_lzp(int variant, uint32_t K, const uint8_t *src, const StreamIn *streams, const StreamPlan *plan,
+void launch_dec_lzp(int variant, uint32_t K, int lpt, const uint8_t *src, const StreamIn *streams, const StreamPlan *plan,
                     const uint32_t *mlist, uint32_t n_multi, const BlockDesc *blocks, uint32_t n_blocks, const BlockResult *bres,
                     const LmdRec *lmds, const uint8_t *lits, uint2 *ck, uint8_t *dst, StreamResult *sres, uint32_t *state,
                     bool scatter, hipStream_t st);

@@ -65,7 +65,7 @@ def test_chunked_round_trip_and_chunk_streams_are_plain_lzfse(oracle, snappy_raw
 
 
 @pytest.mark.gpu
-def test_cli_like_lzfoo(tmp_path, snappy_raw):
+def test_cli_like_lzfoo(tmp_path, snappy_raw, oracle):
     raw = snappy_raw["alice29.txt"] * 40
     src, enc, dec, plain = (tmp_path / n for n in ("in", "enc", "dec", "plain"))
     src.write_bytes(raw)
@@ -77,10 +77,16 @@ def test_cli_like_lzfoo(tmp_path, snappy_raw):
     assert enc.read_bytes()[:4] == b"LZMC" and enc.stat().st_size < len(raw) // 2
     r = run("-decode", "-i", str(enc), "-o", str(dec))
     assert r.returncode == 0 and dec.read_bytes() == raw and r.stderr == b""
-    # stdin -> stdout, one ordinary LZFSE stream
+    # stdin -> stdout, one ordinary LZFSE stream: lzfoo's own bytes (lzfoo/main.rs:89: LzfseRingEncoder::encode)
     r = run("-encode", "--plain", input=raw)
     assert r.returncode == 0 and r.stdout[:4] == b"bvx2" and r.stdout[-4:] == b"bvx$"
-    r2 = run("decode", input=r.stdout)
+    assert r.stdout == oracle.ring_encode(raw)
+    piped = r.stdout
+    r = run("-encode", "--plain", "-i", str(src), "-o", str(plain), "-v")
+    assert r.returncode == 0 and plain.read_bytes() == oracle.ring_encode(raw) and f"Input size: {len(raw)} B".encode() in r.stderr
+    r = run("-decode", "-i", str(plain), "-o", str(dec), "-v")
+    assert r.returncode == 0 and dec.read_bytes() == raw and f"Output size: {len(raw)} B".encode() in r.stderr
+    r2 = run("decode", input=piped)
     assert r2.returncode == 0 and hashlib.sha256(r2.stdout).digest() == hashlib.sha256(raw).digest()
     r = run("-decode", input=b"bvx2garbage")
     assert r.returncode == 1 and b"Error: Decode" in r.stderr
