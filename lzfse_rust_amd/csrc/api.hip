@@ -605,7 +605,7 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
             launch_dec_lzp(pipe_variant, pipe_k, pipe_lpt, (const uint8_t *)d_src, (const StreamIn *)c->d_streams.p,
                            (const StreamPlan *)c->d_plan.p, d_mlist, (uint32_t)mlist.size(), (const BlockDesc *)c->d_blocks.p,
                            (uint32_t)nb, (const BlockResult *)c->d_bres.p, (const LmdRec *)c->d_lmds.p, (const uint8_t *)c->d_lits.p,
-                           (uint2 *)c->d_ck.p, (uint8_t *)d_dst, (StreamResult *)c->d_sres.p, d_lzp_state, c->diag_pipe_scatter != 0, st);
+                           (uint2 *)c->d_ck.p, (uint8_t *)d_dst, (StreamResult *)c->d_sres.p, d_lzp_state, (uint32_t)c->diag_pipe_scatter, st);
         }
     }
     if (nj) {

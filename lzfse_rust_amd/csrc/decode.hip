@@ -1426,6 +1426,9 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
     __shared__ uint32_t s_cnt[4];
     __shared__ uint32_t s_tk[2];
     __shared__ int s_status;
+#ifdef LZFSE_MI_DIAG
+    __shared__ uint32_t s_sum;   // checksum of what this ticket wrote / of what the one before it wrote, as this workgroup reads it
+#endif
 
     // the K workgroups of a stream on one XCD (workgroups go to the XCDs round robin): what one writes the next one
     // finds in the same L2
@@ -1477,7 +1480,41 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
         }
     };
     // all threads, at the end of the ticket's turn: everything this workgroup stored is at L2 before the flag moves
+#ifdef LZFSE_MI_DIAG
+    // Diagnostic build: the hand-over is CHECKED. A ticket leaves a checksum of the bytes it wrote (position-weighted, from
+    // its LDS tile) beside `done`; the next ticket, at its turn, reads those bytes back the way it reads all earlier output
+    // (sc0 sc1 loads through the L2) and compares. A difference means the protocol does not hold on this device: the
+    // stream is flagged (LZP_BAD = 3), the host decodes the launch's streams again with the one-workgroup kernel and the
+    // context gives the pipelined kernel up (scripts/fuzz_gpu.py pipeck runs whole campaigns this way).
+    uint32_t my_sum = 0, my_start = 0, my_len = 0;
+    auto sum_of = [](uint32_t pos, uint32_t byte) -> uint32_t { return (byte + 1u) * ((pos & 0xFFFFu) + 1u); };
+    auto check_prev = [&](uint32_t T) {
+        if (T == 0) return;
+        const uint32_t *pc = sw + LZP_SUMS + 4 * ((T - 1) & 1);
+        const uint32_t want = ld_u32_l2(pc), start = ld_u32_l2(pc + 1), len = ld_u32_l2(pc + 2);
+        if (tid == 0) s_sum = 0;
+        __syncthreads();
+        uint32_t acc = 0;
+        for (uint32_t i = tid; i < len; i += NT) acc += sum_of(start + i, ld_u8_l2(dst + start + i));
+        atomicAdd(&s_sum, acc);
+        __syncthreads();
+        if (tid == 0 && len && s_sum != want) __hip_atomic_store(bad, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+    };
+#endif
     auto publish = [&](uint32_t T, bool last, uint64_t out_len) {
+#ifdef LZFSE_MI_DIAG
+        if (tid == 0) s_sum = 0;
+        __syncthreads();
+        atomicAdd(&s_sum, my_sum);
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t *pc = sw + LZP_SUMS + 4 * (T & 1);
+            pc[0] = s_sum + (scatter == 2 ? 1u : 0u);   // (scatter = 2: a deliberately wrong sum, to see the check fire)
+            pc[1] = my_start; pc[2] = my_len;
+        }
+        my_sum = 0; my_len = 0;
+#endif
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         if (tid == 0) {
@@ -1512,7 +1549,7 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
         if (!placed) {
             // the hand-over below relies on one L2: every workgroup that works on the stream must be on the same XCD
             if (tid == 0) {
-                const uint32_t mine = xcc_id() + 1 + (scatter ? (wq % K) * 16 : 0);
+                const uint32_t mine = xcc_id() + 1 + (scatter == 1 ? (wq % K) * 16 : 0);
                 const uint32_t was = atomicCAS(home, 0u, mine);
                 s_tk[1] = (was == 0 || was == mine) ? 1u : 0u;
             }
@@ -1724,6 +1761,10 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
                 t2 = __builtin_amdgcn_s_memtime();
                 if (!wait_turn(T)) { gone = true; break; }
                 have_turn = true;
+#ifdef LZFSE_MI_DIAG
+                check_prev(T);
+                my_start = (uint32_t)tile_base;
+#endif
                 t3 = __builtin_amdgcn_s_memtime();
             }
             if (tile_bad) { fail(LZFSE_MI_BAD_D_VALUE, tile_base); gone = true; break; }
@@ -1806,6 +1847,10 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
             __syncthreads();
             const uint64_t u2 = __builtin_amdgcn_s_memtime();
             cy_far += u1 - t3; cy_gat += u2 - u1; t3b = u2;
+#ifdef LZFSE_MI_DIAG
+            for (uint32_t i = tid; i < tile_len; i += NT) my_sum += sum_of((uint32_t)tile_base + i, t[i]);
+            my_len += tile_len;
+#endif
             {
                 uint8_t *gp = dst + tile_base;
                 uint32_t head = pad ? (16 - pad) : 0;
@@ -2087,7 +2132,7 @@ void launch_dec_lz(int variant, const uint8_t *src, const StreamIn *streams, con
 void launch_dec_lzp(int variant, uint32_t K, int lpt, const uint8_t *src, const StreamIn *streams, const StreamPlan *plan,
                     const uint32_t *mlist, uint32_t n_multi, const BlockDesc *blocks, uint32_t n_blocks, const BlockResult *bres,
                     const LmdRec *lmds, const uint8_t *lits, uint2 *ck, uint8_t *dst, StreamResult *sres, uint32_t *state,
-                    bool scatter, hipStream_t st) {
+                    uint32_t scatter, hipStream_t st) {
     if (!n_multi || !K) return;
     hipLaunchKernelGGL(dec_ck_kernel, dim3(n_blocks), dim3(256), 0, st, plan, blocks, n_blocks, bres, lmds, ck);
     const uint32_t grid = ((n_multi + 7) / 8) * 8 * K;
@@ -2096,17 +2141,17 @@ void launch_dec_lzp(int variant, uint32_t K, int lpt, const uint8_t *src, const 
     if (variant == 0) {
         if (lpt == 2)
             hipLaunchKernelGGL((dec_lzp_kernel<256, 8192, 2>), dim3(grid), dim3(256), 0, st, src, streams, plan, mlist, n_multi, K,
-                               blocks, bres, lmds, lits, ck, dst, sres, state, scatter ? 1u : 0u);
+                               blocks, bres, lmds, lits, ck, dst, sres, state, scatter);
         else
             hipLaunchKernelGGL((dec_lzp_kernel<256, 8192, 1>), dim3(grid), dim3(256), 0, st, src, streams, plan, mlist, n_multi, K,
-                               blocks, bres, lmds, lits, ck, dst, sres, state, scatter ? 1u : 0u);
+                               blocks, bres, lmds, lits, ck, dst, sres, state, scatter);
     } else {
         if (lpt == 2)
             hipLaunchKernelGGL((dec_lzp_kernel<1024, 32768, 2>), dim3(grid), dim3(1024), 0, st, src, streams, plan, mlist, n_multi, K,
-                               blocks, bres, lmds, lits, ck, dst, sres, state, scatter ? 1u : 0u);
+                               blocks, bres, lmds, lits, ck, dst, sres, state, scatter);
         else
             hipLaunchKernelGGL((dec_lzp_kernel<1024, 32768, 1>), dim3(grid), dim3(1024), 0, st, src, streams, plan, mlist, n_multi, K,
-                               blocks, bres, lmds, lits, ck, dst, sres, state, scatter ? 1u : 0u);
+                               blocks, bres, lmds, lits, ck, dst, sres, state, scatter);
     }
 }
 

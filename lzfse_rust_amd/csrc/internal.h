@@ -73,10 +73,12 @@ void launch_dec_lz(int variant, const uint8_t *src, const StreamIn *streams, con
 // in that XCD's L2), [LZP_BAD] the word a workgroup on ANOTHER XCD raises through memory (nobody near writes its line, so
 // device-scope loads of it are not served from a dirty local copy), [LZP_DIAG ..] eight u64 cycle counters.
 constexpr uint32_t LZP_STATE_WORDS = 160, LZP_NEXT = 0, LZP_HOME = 1, LZP_DONE = 32, LZP_BAD = 64, LZP_DIAG = 96;
+// (diagnostic build) [LZP_SUMS + 4 * (ticket & 1) ..]: checksum, first position (low 32 bits) and length of what the ticket wrote
+constexpr uint32_t LZP_SUMS = 128;
 void launch_dec_lzp(int variant, uint32_t K, int lpt, const uint8_t *src, const StreamIn *streams, const StreamPlan *plan,
                     const uint32_t *mlist, uint32_t n_multi, const BlockDesc *blocks, uint32_t n_blocks, const BlockResult *bres,
                     const LmdRec *lmds, const uint8_t *lits, uint2 *ck, uint8_t *dst, StreamResult *sres, uint32_t *state,
-                    bool scatter, hipStream_t st);
+                    uint32_t scatter, hipStream_t st);
 void launch_dec_lzp_selftest(uint32_t *buf, uint32_t *out, hipStream_t st);   // buf: 1088 zeroed dwords, out: 2 zeroed dwords
 void launch_dec_jump(const uint8_t *src, const StreamIn *streams, const StreamPlan *plan, const StreamWalk *walk, uint32_t n_streams,
                      const BlockDesc *blocks, uint32_t n_blocks, const BlockResult *bres, const LmdRec *lmds, const uint8_t *lits,

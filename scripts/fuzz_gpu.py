@@ -1,11 +1,13 @@
 """One-off randomised parity campaign on a GPU box (not part of the test-suite: the suite's cases are fixed):
-    python scripts/fuzz_gpu.py [ROUNDS] [SEED] [walk|pipe|big|ring|stream]  (stream: 3 to 6 inputs of 1.2 .. 12 MiB per round through LzfseWriter with
+    python scripts/fuzz_gpu.py [ROUNDS] [SEED] [walk|pipe|pipeck|big|ring|stream]  (stream: 3 to 6 inputs of 1.2 .. 12 MiB per round through LzfseWriter with
                                                               windows of 1 .. 3 MiB and pieces of any size: the bytes are those of the restated ring
                                                               encoder on the whole input, and the windows did leave early;
                                                               ring: the streams are ALSO encoded with the ring / stream encoder's parse and
                                                               compared with the restated frontend_ring.rs; lengths reach across the 512 KiB ring;
                                                               walk: the diagnostic build, every stream through the parallel header walk first;
                                                               pipe: every stream of the tile kernel through the pipelined LZ kernel, K and tile size changing per round;
+                                                              pipeck: the same in the diagnostic build, where every ticket's bytes are checksummed by their writer and
+                                                              checked by the next ticket as it reads them (no hand-over may ever be refused);
                                                               big: 2 to 9 streams of 2 .. 24 MiB per round: pointer jumping, the parallel header walk and several
                                                               workgroups per stream, as the cost model mixes them)
 Every round: ~120 streams of random structure and length (4 097 B .. 3 MiB, some at tile edges) are encoded by the device
@@ -24,9 +26,11 @@ O = oracle_py.Oracle()
 if len(sys.argv) > 3 and sys.argv[3] == "walk":
     ctx = lz.Context(0, diag=True)
     ctx.set_option("diag_walk", 1)
+elif len(sys.argv) > 3 and sys.argv[3] == "pipeck":
+    ctx = lz.Context(0, diag=True)
 else:
     ctx = lz.Context(0)
-PIPE = len(sys.argv) > 3 and sys.argv[3] == "pipe"
+PIPE = len(sys.argv) > 3 and sys.argv[3] in ("pipe", "pipeck")
 BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
 RING = len(sys.argv) > 3 and sys.argv[3] == "ring"
 STREAM = len(sys.argv) > 3 and sys.argv[3] == "stream"
@@ -157,4 +161,5 @@ for rd in range(rounds):
         if s == 0:
             assert g.tobytes() == O.decode(b, cap=cap)
     print(f"round {rd}: {len(raws)} streams ok ({sum(map(len, raws)) / 1e6:.0f} MB), {time.time() - t0:.0f} s", flush=True)
+assert ctx.pipe_refusals() == 0, "a hand-over of the pipelined LZ kernel was refused"
 print(f"fuzz ok: {rounds} rounds, {total / 1e6:.0f} MB")

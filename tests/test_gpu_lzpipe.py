@@ -125,3 +125,24 @@ def test_pipe_refuses_streams_spread_over_xcds(oracle, snappy_raw):
         diag_ctx.set_option("diag_pipe_scatter", 0)
         diag_ctx.set_option("decode_pipe", 0)
         diag_ctx.enable_timing(False)
+
+
+def test_hand_over_is_checked_in_the_diagnostic_build(oracle, snappy_raw):
+    """Diagnostic build: every ticket leaves a checksum of the bytes it wrote beside `done`, and the next ticket reads
+    those bytes back the way it reads all earlier output and compares. On sound hardware nothing is ever refused; a
+    deliberately wrong sum (diag_pipe_scatter = 2) must be caught: the launch is thrown away, the streams are decoded again
+    by the one-workgroup kernel and the context gives the pipelined kernel up."""
+    import lzfse_rust_amd as m
+    ctx = m.Context(0, diag=True)
+    raws = [snappy_raw["lcet10.txt"] * 3, snappy_raw["plrabn12.txt"] * 2, snappy_raw["urls.10K"] * 2, snappy_raw["kppkn.gtb"]]
+    encs = [oracle.encode(r) for r in raws]
+    ctx.enable_timing(True)
+    for pipe in (0x104, 0x102, 0x004):      # K = 4 and 2 with 1 024-thread tickets, K = 4 with 256-thread tickets
+        ctx.set_option("decode_pipe", pipe)
+        outs, st = ctx.decode_batch(encs)
+        assert list(st) == [0] * len(encs) and all(o.tobytes() == r for o, r in zip(outs, raws))
+        assert "dec_lz_again" not in ctx.timings() and ctx.pipe_refusals() == 0
+    ctx.set_option("diag_pipe_scatter", 2)
+    outs, st = ctx.decode_batch(encs)
+    assert ctx.timings()["dec_lz_again"][1] == 1 and ctx.pipe_refusals() == 1
+    assert list(st) == [0] * len(encs) and all(o.tobytes() == r for o, r in zip(outs, raws))
