@@ -26,6 +26,8 @@ struct lzfse_mi_dstream {
     size_t window = 0;
     std::vector<uint8_t> in;       // bytes fed; in[in_pos..] are not yet decoded
     size_t in_pos = 0;
+    size_t scan_span = 0;          // the blocks in[in_pos .. in_pos + scan_span) are known to be complete (the scan goes on from there) ...
+    uint64_t scan_raw = 0;         // ... and hold this many raw bytes
     std::vector<uint8_t> hist;     // the last <= MAX_D_VALUE bytes of output
     std::vector<uint8_t> tmp_src;
     uint8_t *tmp_dst = nullptr;    // malloc'd, never zero-filled: a damaged header may promise gigabytes that are never written
@@ -79,39 +81,82 @@ bool grow_dst(lzfse_mi_dstream *s, uint64_t cap) {
     if (s->tmp_dst_cap >= cap + 64) return true;
     std::free(s->tmp_dst);
     s->tmp_dst_cap = 0;
-    s->tmp_dst = (uint8_t *)std::malloc((size_t)cap + 64);
-    if (!s->tmp_dst) return false;
-    s->tmp_dst_cap = (size_t)cap + 64;
+    // (with room to spare: windows end at block boundaries, so their sizes differ by a block or two, and a buffer that fits
+    // the largest one so far exactly is thrown away by every window that is a little larger -- fresh pages cost more than the decode)
+    const uint64_t want = cap + cap / 8 + ((uint64_t)1 << 20);
+    s->tmp_dst = (uint8_t *)std::malloc((size_t)want + 64);
+    if (!s->tmp_dst) {
+        s->tmp_dst = (uint8_t *)std::malloc((size_t)cap + 64);
+        if (!s->tmp_dst) return false;
+        s->tmp_dst_cap = (size_t)cap + 64;
+        return true;
+    }
+    s->tmp_dst_cap = (size_t)want + 64;
     return true;
 }
 
 // decode in[0 .. span) as one stream behind the history block; with_eos: the span's blocks are complete and bvx$ is added
 int decode_span(lzfse_mi_dstream *s, size_t span, uint64_t raw, bool with_eos, lzfse_mi_write_fn write, void *user) {
     const size_t nh = s->hist.size();
-    s->tmp_src.clear();
-    if (nh) {
-        uint8_t hd[8];
-        const uint32_t m = MAGIC_RAW, n32 = (uint32_t)nh;
-        std::memcpy(hd, &m, 4); std::memcpy(hd + 4, &n32, 4);
-        s->tmp_src.insert(s->tmp_src.end(), hd, hd + 8);
-        s->tmp_src.insert(s->tmp_src.end(), s->hist.begin(), s->hist.end());
+    s->scan_span = 0; s->scan_raw = 0;
+    const uint8_t *src = nullptr;
+    size_t src_len = 0;
+    // A window of complete blocks is decoded where it lies: the history block (bvx- header + the last 262 139 bytes of
+    // output) is written over the consumed input in front of it, bvx$ over the 4 bytes behind it (put back afterwards).
+    // Only a tail that could not be delimited is assembled in a buffer of its own.
+    const size_t head = nh ? nh + 8 : 0;
+    const bool in_place = with_eos && s->in_pos >= head;
+    uint8_t saved[4] = {0, 0, 0, 0};
+    size_t old_size = 0, eos_at = 0;
+    if (in_place) {
+        old_size = s->in.size();
+        eos_at = s->in_pos + span;
+        if (old_size < eos_at + 4) {
+            try { s->in.resize(eos_at + 4); } catch (...) { return LZFSE_MI_IO; }
+        }
+        uint8_t *p0 = s->in.data() + s->in_pos - head;
+        if (nh) {
+            const uint32_t m = MAGIC_RAW, n32 = (uint32_t)nh;
+            std::memcpy(p0, &m, 4); std::memcpy(p0 + 4, &n32, 4);
+            std::memcpy(p0 + 8, s->hist.data(), nh);
+        }
+        std::memcpy(saved, s->in.data() + eos_at, 4);
+        const uint32_t m = MAGIC_EOS;
+        std::memcpy(s->in.data() + eos_at, &m, 4);
+        src = p0; src_len = head + span + 4;
+    } else {
+        s->tmp_src.clear();
+        if (nh) {
+            uint8_t hd[8];
+            const uint32_t m = MAGIC_RAW, n32 = (uint32_t)nh;
+            std::memcpy(hd, &m, 4); std::memcpy(hd + 4, &n32, 4);
+            s->tmp_src.insert(s->tmp_src.end(), hd, hd + 8);
+            s->tmp_src.insert(s->tmp_src.end(), s->hist.begin(), s->hist.end());
+        }
+        s->tmp_src.insert(s->tmp_src.end(), s->in.begin() + s->in_pos, s->in.begin() + s->in_pos + span);
+        if (with_eos) { const uint32_t m = MAGIC_EOS; const uint8_t *q = (const uint8_t *)&m; s->tmp_src.insert(s->tmp_src.end(), q, q + 4); }
+        src = s->tmp_src.data(); src_len = s->tmp_src.size();
     }
-    s->tmp_src.insert(s->tmp_src.end(), s->in.begin() + s->in_pos, s->in.begin() + s->in_pos + span);
-    if (with_eos) { const uint32_t m = MAGIC_EOS; const uint8_t *q = (const uint8_t *)&m; s->tmp_src.insert(s->tmp_src.end(), q, q + 4); }
+    auto put_back = [&] {
+        if (!in_place) return;
+        std::memcpy(s->in.data() + eos_at, saved, 4);
+        if (s->in.size() != old_size) s->in.resize(old_size);
+    };
     uint64_t cap64 = nh + raw;
     if (!with_eos) {   // a tail the parser could not delimit: what its headers promise, as the slice path's caller would size it
         uint64_t promised = 0;
-        (void)lzfse_mi_decode_size(s->tmp_src.data(), s->tmp_src.size(), &promised);
+        (void)lzfse_mi_decode_size(src, src_len, &promised);
         cap64 = std::max<uint64_t>(cap64, promised);
     }
-    if (!grow_dst(s, cap64)) return LZFSE_MI_IO;
+    if (!grow_dst(s, cap64)) { put_back(); return LZFSE_MI_IO; }
     size_t got = 0;
-    int st = lzfse_mi_decode(s->ctx, s->tmp_src.data(), s->tmp_src.size(), s->tmp_dst, (size_t)cap64, &got);
+    int st = lzfse_mi_decode(s->ctx, src, src_len, s->tmp_dst, (size_t)cap64, &got);
     if (st == LZFSE_MI_BUFFER_OVERFLOW) {   // the sink is unbounded: find the error the reference's Vec would have met
-        cap64 += lzfse_mi_decode_headroom(s->tmp_src.data(), s->tmp_src.size());
-        if (!grow_dst(s, cap64)) return LZFSE_MI_IO;
-        st = lzfse_mi_decode(s->ctx, s->tmp_src.data(), s->tmp_src.size(), s->tmp_dst, (size_t)cap64, &got);
+        cap64 += lzfse_mi_decode_headroom(src, src_len);
+        if (!grow_dst(s, cap64)) { put_back(); return LZFSE_MI_IO; }
+        st = lzfse_mi_decode(s->ctx, src, src_len, s->tmp_dst, (size_t)cap64, &got);
     }
+    put_back();
     if (st) return st;
     if (got < nh) return LZFSE_MI_IO;
     const size_t fresh = got - nh;
@@ -172,7 +217,10 @@ LZFSE_MI_API int lzfse_mi_dstream_feed(lzfse_mi_dstream *s, const uint8_t *src, 
     if (!s || (!src && n)) return LZFSE_MI_BAD_ARGUMENT;
     if (s->status) return s->status;
     if (n) {
-        if (s->in_pos && s->in_pos >= s->in.size() / 2) { s->in.erase(s->in.begin(), s->in.begin() + s->in_pos); s->in_pos = 0; }
+        // (consumed input is dropped now and then; MAX_D_VALUE + 8 bytes of it stay in front of the rest: the next window's
+        // history block is written there, decode_span)
+        constexpr size_t KEEP = (size_t)MAX_D_VALUE + 8;
+        if (s->in_pos > KEEP && s->in_pos - KEEP >= s->in.size() / 2) { s->in.erase(s->in.begin(), s->in.begin() + (s->in_pos - KEEP)); s->in_pos = KEEP; }
         s->in.insert(s->in.end(), src, src + n);
     }
     for (;;) {
@@ -181,8 +229,8 @@ LZFSE_MI_API int lzfse_mi_dstream_feed(lzfse_mi_dstream *s, const uint8_t *src, 
             return LZFSE_MI_OK;
         }
         // the longest run of complete blocks at the front of the input, up to a window of raw bytes
-        size_t span = 0;
-        uint64_t raw = 0;
+        size_t span = s->scan_span;      // (what earlier feeds have scanned is not scanned again)
+        uint64_t raw = s->scan_raw;
         int why = 1;   // why the run ended: 0 bvx$, 1 input exhausted, 2 undecidable block, 3 window full
         while (true) {
             uint64_t len, nr; bool eos;
@@ -202,8 +250,8 @@ LZFSE_MI_API int lzfse_mi_dstream_feed(lzfse_mi_dstream *s, const uint8_t *src, 
         }
         if (why == 3) { const int st = decode_span(s, span, raw, true, write, user); if (st) return s->status = st; continue; }
         if (why == 1 && !finish) {
-            // wait for more input; decode what is complete if it is worth a launch
-            if (raw >= s->window / 2 && span) { const int st = decode_span(s, span, raw, true, write, user); if (st) return s->status = st; }
+            // wait for more input (a window is decoded when it is full, or when the input ends)
+            s->scan_span = span; s->scan_raw = raw;
             return LZFSE_MI_OK;
         }
         // the input ends inside a block, or a block cannot be delimited: the rest goes to the device as it is, which
