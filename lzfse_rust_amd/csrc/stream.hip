@@ -384,7 +384,12 @@ int lzfse_mi_estream_feed(lzfse_mi_estream *s, const uint8_t *src, size_t n, lzf
     while (n) {
         const size_t room = s->next_at > s->buf.size() ? s->next_at - s->buf.size() : 0;
         const size_t take = n < room ? n : room;
-        try { s->buf.insert(s->buf.end(), src, src + take); } catch (...) { return s->status = LZFSE_MI_IO; }
+        try {
+            // (room for the whole window at once, as soon as the input shows that it will be needed: growing by doubling copies
+            // the window's bytes once more and touches twice the pages)
+            if (s->buf.capacity() < s->next_at && s->buf.size() + take > ((size_t)4 << 20)) s->buf.reserve(s->next_at + ((size_t)1 << 16));
+            s->buf.insert(s->buf.end(), src, src + take);
+        } catch (...) { return s->status = LZFSE_MI_IO; }
         src += take; n -= take; s->total_in += take;
         if (s->buf.size() >= s->next_at)
             if (const int st = es_window(s, false, write, user)) return s->status = st;
