@@ -5,9 +5,19 @@
 namespace lzmi {
 
 constexpr uint32_t TILE_POS = 65472;        // positions per chain tile: multiple of 64 and of CAND_P, offset + 1 fits u16
-constexpr uint32_t SEG = 2048;              // positions per speculative-parse segment
+constexpr uint32_t SEG = 2048;              // positions per speculative-parse segment of a large batch (small ones: 1024 or 512, seg_for)
 constexpr uint32_t OVER = 512;              // overrun of a segment walker into the next segment
 constexpr uint32_t SEG_EV_CAP = (SEG + OVER) / 4 + 4;  // every emit advances literal_index by >= 4
+__host__ __device__ __forceinline__ uint32_t seg_ev_cap(uint32_t seg) { return (seg + OVER) / 4 + 4; }   // events a walker of `seg` positions can log
+// Segment length of a batch (one value for all its streams). A walker's time goes with its segment, and a small batch is one
+// round of resident walkers whose longest walk sets enc_spec's time: quarter segments, four times the walkers (html x 16:
+// enc_spec 0.30 -> 0.13 ms, encode 2.55 -> 3.2 GB/s). Not for large streams: the stitcher is one wave per stream and pays per
+// boundary (one 64 MiB stream with 1 024-position segments: enc_spec 0.64 -> 0.49 ms but enc_stitch 0.33 -> 0.73); not for
+// large batches: they are bound by the traffic of their records and events, to which more walkers (each overrunning by OVER)
+// only add (188 MB in 768 streams: no difference).
+__host__ __forceinline__ uint32_t seg_for(uint64_t positions, uint64_t longest) {
+    return (positions <= ((uint64_t)24 << 20) && longest <= ((uint64_t)2 << 20)) ? 512u : SEG;
+}
 constexpr uint32_t NONE = 0xFFFFFFFFu;      // no previous position
 constexpr uint32_t NONE_TILE = 0xFFFFFFFEu; // no previous position inside the tile (link pending)
 constexpr uint32_t FCAP = 1023;             // cap of the forward length computed per position (>= GOOD_MATCH_LEN); 10 bits of a record
@@ -185,9 +195,9 @@ void launch_enc_cand(const uint8_t *src, const EncStream *streams, const EncTile
                      uint64_t *bitmap, hipStream_t st);
 
 // encode_parse.hip
-void launch_enc_spec(const uint8_t *src, const EncStream *streams, const uint2 *segs, uint32_t n_segs, const uint32_t *prev,
+void launch_enc_spec(const uint8_t *src, const EncStream *streams, const uint2 *segs, uint32_t n_segs, uint32_t seg, const uint32_t *prev,
                      const uint32_t *rec, const uint64_t *bitmap, SpecEvent *logs, SpecHeader *hdrs, hipStream_t st);
-void launch_enc_stitch(const uint8_t *src, const EncStream *streams, uint32_t ns, const uint2 *segs, uint32_t n_segs, const uint32_t *prev,
+void launch_enc_stitch(const uint8_t *src, const EncStream *streams, uint32_t ns, const uint2 *segs, uint32_t n_segs, uint32_t seg, const uint32_t *prev,
                        const uint32_t *rec, const uint64_t *bitmap, const SpecEvent *logs, const SpecHeader *hdrs, uint4 *sync,
                        RangeRec *ranges, MatchRec *gaps, uint4 *gstate /* may be null */, EncStreamOut *outs, hipStream_t st);
 void launch_enc_cut(const EncStream *streams, uint32_t ns, const EncStreamOut *outs, const EncBlock *blocks, const RangeRec *ranges,

@@ -749,6 +749,10 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     std::vector<uint2> hsegs;
     uint64_t pos_total = 0, lmd_total = 0, stage_total = 0, match_total = 0;
     uint32_t blk_total = 0, range_total = 0;
+    // segment length of the speculative parse: one value for the batch (seg_for, enc_common.h)
+    uint64_t batch_pos = 0;
+    for (uint32_t si = 0; si < ns; si++) batch_pos += hs[si].n;
+    const uint32_t seg = seg_for(batch_pos, hs[0].n /* sorted: the longest */), ev_cap = seg_ev_cap(seg);
     for (uint32_t si = 0; si < ns; si++) {
         EncStream &e = hs[si];
         e.pos_base = pos_total;
@@ -764,7 +768,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         e.stage_cap = (uint64_t)e.n + e.n / 2 + e.n / 4 + (uint64_t)e.blk_cap * 1024 + 4096;
         e.stage_cap = (e.stage_cap + 255) & ~255ull;
         e.seg_base = (uint32_t)hsegs.size();
-        e.n_seg = (n_pos + SEG - 1) / SEG;
+        e.n_seg = (n_pos + seg - 1) / seg;
         for (uint32_t k = 0; k < e.n_seg; k++) hsegs.push_back(make_uint2(si, k));
         e.range_base = range_total;
         // (ring parse: up to one more event and range per 16 KiB block, the literals a round pushes when they pass the head)
@@ -789,7 +793,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         !eb_ensure(S, EB_STAGE, stage_total + 256) || !eb_ensure(S, EB_SLOTS, (size_t)blk_total * 4) ||
         !eb_ensure(S, EB_BITMAP, pos_total / 8 + 64))
         return LZFSE_MI_IO;
-    if (!eb_ensure(S, EB_SEGS, (size_t)nseg * sizeof(uint2)) || !eb_ensure(S, EB_LOGS, (size_t)nseg * SEG_EV_CAP * sizeof(SpecEvent)) ||
+    if (!eb_ensure(S, EB_SEGS, (size_t)nseg * sizeof(uint2)) || !eb_ensure(S, EB_LOGS, (size_t)nseg * ev_cap * sizeof(SpecEvent)) ||
         !eb_ensure(S, EB_HDRS, (size_t)nseg * sizeof(SpecHeader)) || !eb_ensure(S, EB_RANGES, (size_t)range_total * sizeof(RangeRec)) ||
         !eb_ensure(S, EB_GAPS, match_total * sizeof(MatchRec)) || !eb_ensure(S, EB_MATCHES, match_total * sizeof(MatchRec)) ||
         !eb_ensure(S, EB_PC, match_total * 4) || !eb_ensure(S, EB_PL, match_total * 4) ||
@@ -841,7 +845,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         E_TRY(hipMemcpyAsync(d_rslots, hrslots.data(), (size_t)range_total * 4, hipMemcpyHostToDevice, stq));
         {
             StageTimer t(c, "enc_spec");
-            launch_enc_spec(d_src, d_streams, d_segs, nseg, d_prev, d_rec, d_bitmap, d_logs, d_hdrs, stq);
+            launch_enc_spec(d_src, d_streams, d_segs, nseg, seg, d_prev, d_rec, d_bitmap, d_logs, d_hdrs, stq);
         }
         uint4 *d_gstate = nullptr;
         if (win && !win->final) {
@@ -850,7 +854,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         }
         {
             StageTimer t(c, "enc_stitch");
-            launch_enc_stitch(d_src, d_streams, ns, d_segs, nseg, d_prev, d_rec, d_bitmap, d_logs, d_hdrs, (uint4 *)S.bufs[EB_SYNC], d_ranges, d_gaps,
+            launch_enc_stitch(d_src, d_streams, ns, d_segs, nseg, seg, d_prev, d_rec, d_bitmap, d_logs, d_hdrs, (uint4 *)S.bufs[EB_SYNC], d_ranges, d_gaps,
                               d_gstate, d_outs, stq);
         }
         {

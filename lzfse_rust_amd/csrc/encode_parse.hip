@@ -190,7 +190,7 @@ __device__ void st_ring_find(const uint8_t *s, const uint32_t *pv, uint32_t ring
 // record is capped can have its exact lengths computed by the whole wave (one request at a time).
 template <bool STAGED>
 __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
-                                                      const uint2 *__restrict__ segs, uint32_t n_segs,
+                                                      const uint2 *__restrict__ segs, uint32_t n_segs, uint32_t seg,
                                                       const uint32_t *__restrict__ prev, const uint32_t *__restrict__ rec,
                                                       const uint64_t *__restrict__ bitmap, SpecEvent *__restrict__ logs,
                                                       SpecHeader *__restrict__ hdrs) {
@@ -200,11 +200,11 @@ __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict_
     const EncStream &es = streams[sg.x];
     const uint32_t end = es.n - 3;
     const uint32_t ring = exists ? es.ring : 0u, n_own = es.n;
-    const uint32_t S = sg.y * SEG;
-    const uint32_t stop = exists ? ((S + SEG + OVER < end) ? S + SEG + OVER : end) : 0;
+    const uint32_t S = sg.y * seg, ev_cap = seg_ev_cap(seg);
+    const uint32_t stop = exists ? ((S + seg + OVER < end) ? S + seg + OVER : end) : 0;
     const uint32_t *r = rec + es.pos_base;
     const uint64_t *bm = bitmap + (es.pos_base >> 6);
-    SpecEvent *ev = logs + (uint64_t)g * SEG_EV_CAP;
+    SpecEvent *ev = logs + (uint64_t)g * ev_cap;
     const int lane = e_lane();
     WState st;
     st.index = exists ? S : 0; st.lit = S; st.p_idx = 0; st.p_midx = 0; st.p_len = 0;
@@ -314,13 +314,13 @@ __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict_
                 if (select40(st, p - b, midx - b, fwd + b, e_idx, e_midx, e_len)) {
                     st.lit = e_idx + e_len;
                     st.index = (p + 1 > st.lit) ? p + 1 : st.lit;
-                    if (nev < SEG_EV_CAP) {
+                    if (nev < ev_cap) {
                         const uint4 h0 = make_uint4(e_idx, e_len, e_idx - e_midx, lit_before);   // SpecEvent, first half
                         const uint4 h1 = make_uint4(st.index, st.p_len ? st.p_idx : 0, st.p_len ? st.p_midx : 0, st.p_len);
                         if (STAGED) { s_stage[n_staged][lane][0] = h0; s_stage[n_staged][lane][1] = h1; n_staged++; }
                         else { uint4 *de = reinterpret_cast<uint4 *>(ev + nev); de[0] = h0; de[1] = h1; }
                         nev++;
-                    } else nev = SEG_EV_CAP + 1;   // (log overflow: cannot happen, reported below)
+                    } else nev = ev_cap + 1;   // (log overflow: cannot happen, reported below)
                 } else {
                     st.index = p + 1;
                 }
@@ -347,8 +347,8 @@ __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict_
     }
     if (!exists) return;
     SpecHeader h;
-    h.n_events = nev < SEG_EV_CAP ? nev : SEG_EV_CAP;
-    h.status = nev > SEG_EV_CAP ? 2u : status;  // 2: log overflow (cannot happen: every emit advances lit by >= 4)
+    h.n_events = nev < ev_cap ? nev : ev_cap;
+    h.status = nev > ev_cap ? 2u : status;  // 2: log overflow (cannot happen: every emit advances lit by >= 4)
     h.f_index = st.index; h.f_lit = st.lit;
     h.f_pidx = st.p_len ? st.p_idx : 0; h.f_pmidx = st.p_len ? st.p_midx : 0; h.f_plen = st.p_len;
     h.pad = 0;
@@ -375,7 +375,7 @@ __device__ __forceinline__ uint32_t ev_lower_bound(const SpecEvent *ev, uint32_t
 // One thread per segment boundary: the first pair of events of log k (from the start of segment
 // k + 1 on) and log k + 1 whose state-after is identical. Independent of every other boundary.
 __global__ __launch_bounds__(64) void enc_sync_kernel(const EncStream *__restrict__ streams, const uint2 *__restrict__ segs,
-                                                      uint32_t n_segs, const SpecEvent *__restrict__ logs,
+                                                      uint32_t n_segs, uint32_t seg, const SpecEvent *__restrict__ logs,
                                                       const SpecHeader *__restrict__ hdrs, uint4 *__restrict__ sync) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_segs) return;
@@ -383,8 +383,8 @@ __global__ __launch_bounds__(64) void enc_sync_kernel(const EncStream *__restric
     uint4 out = make_uint4(0, 0, 0, 0);
     if (sg.y + 1 < streams[sg.x].n_seg) {
         const uint32_t nk = hdrs[g].n_events, nk1 = hdrs[g + 1].n_events;
-        const SpecEvent *Lk = logs + (uint64_t)g * SEG_EV_CAP, *Lk1 = Lk + SEG_EV_CAP;
-        uint32_t i = ev_lower_bound(Lk, nk, (sg.y + 1) * SEG), j = 0;
+        const SpecEvent *Lk = logs + (uint64_t)g * seg_ev_cap(seg), *Lk1 = Lk + seg_ev_cap(seg);
+        uint32_t i = ev_lower_bound(Lk, nk, (sg.y + 1) * seg), j = 0;
         while (i < nk && j < nk1) {
             const uint32_t ia = Lk[i].index_after, ja = Lk1[j].index_after;
             if (ia < ja) i++;
@@ -459,7 +459,7 @@ __device__ __forceinline__ void sx_mark_round(Stitch &x, uint32_t B) {
 
 // One wave per stream; control flow and values are wave-uniform.
 __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
-                                                        uint32_t n_streams, const uint32_t *__restrict__ prev,
+                                                        uint32_t n_streams, uint32_t seg, const uint32_t *__restrict__ prev,
                                                         const uint32_t *__restrict__ rec, const uint64_t *__restrict__ bitmap,
                                                         const SpecEvent *__restrict__ logs, const SpecHeader *__restrict__ hdrs,
                                                         const uint4 *__restrict__ sync, RangeRec *__restrict__ ranges,
@@ -477,7 +477,8 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
     const uint32_t ring = es.ring;
     const bool rounds = ring_rounds(ring, n);
     const uint32_t t_last = rounds ? ring_t_last(n) : 0u;
-    const SpecEvent *L0 = logs + (uint64_t)es.seg_base * SEG_EV_CAP;
+    const uint32_t ev_cap = seg_ev_cap(seg);
+    const SpecEvent *L0 = logs + (uint64_t)es.seg_base * ev_cap;
     const SpecHeader *H0 = hdrs + es.seg_base;
     Stitch x;
     x.ranges = ranges + es.range_base; x.n_ranges = 0; x.range_cap = es.range_cap;
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
         // a window that continues a stream: the true walk goes on from the state the window before was cut at, until a log agrees
         T.index = es.st_index; T.lit = es.st_lit; T.p_idx = es.st_pidx; T.p_midx = es.st_pmidx; T.p_len = es.st_plen;
         walking = true;
-        k = T.index / SEG < K ? T.index / SEG : K - 1;
+        k = T.index / seg < K ? T.index / seg : K - 1;
     }
     while (!done && !x.status) {
         if (!walking) {
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
                 else {
                     if (cnt) {
                         RangeRec r;
-                        r.begin = (uint64_t)(es.seg_base + k + lane) * SEG_EV_CAP + (uint32_t)a_in;
+                        r.begin = (uint64_t)(es.seg_base + k + lane) * ev_cap + (uint32_t)a_in;
                         r.count = cnt; r.out_off = x.out_count + inc - cnt; r.kind = 0;
                         x.ranges[x.n_ranges + (uint32_t)__popcll(hm & lt)] = r;
                     }
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
             if (nb < 64 && !x.status) {
                 // no sync point at boundary k: adopt the rest of log k and continue from its final state
                 const SpecHeader hk = H0[k];
-                if (hk.n_events > a) sx_add_range(x, 0, (uint64_t)(es.seg_base + k) * SEG_EV_CAP + a, hk.n_events - a);
+                if (hk.n_events > a) sx_add_range(x, 0, (uint64_t)(es.seg_base + k) * ev_cap + a, hk.n_events - a);
                 T.index = hk.f_index; T.lit = hk.f_lit; T.p_idx = hk.f_pidx; T.p_midx = hk.f_pmidx; T.p_len = hk.f_plen;
                 walking = true;
                 st_fallbacks++;
@@ -632,11 +633,11 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
         sx_mark_state(x, T);
         if (emitted) {
             // does the log of the segment we are in agree with this state?
-            uint32_t kk = T.index / SEG;
+            uint32_t kk = T.index / seg;
             if (kk >= K) kk = K - 1;
             if (kk > k || (kk == k && false)) {
                 const SpecHeader hh = H0[kk];
-                const SpecEvent *Lkk = L0 + (uint64_t)kk * SEG_EV_CAP;
+                const SpecEvent *Lkk = L0 + (uint64_t)kk * ev_cap;
                 uint32_t j = ev_lower_bound(Lkk, hh.n_events, T.index);
                 if (j < hh.n_events) {
                     SpecEvent t;
@@ -1283,20 +1284,18 @@ __global__ __launch_bounds__(64) void enc_cut_kernel(const EncStream *__restrict
 
 // ------------------------------------------------------------------------------------ launchers
 
-void launch_enc_spec(const uint8_t *src, const EncStream *streams, const uint2 *segs, uint32_t n_segs, const uint32_t *prev,
+void launch_enc_spec(const uint8_t *src, const EncStream *streams, const uint2 *segs, uint32_t n_segs, uint32_t seg, const uint32_t *prev,
                      const uint32_t *rec, const uint64_t *bitmap, SpecEvent *logs, SpecHeader *hdrs, hipStream_t st) {
     if (!n_segs) return;
-    // staged event stores pay when the launch is bound by its store rate: more segments than the chip holds walkers at once
-    if (n_segs > 98304) hipLaunchKernelGGL(enc_spec_kernel<true>, dim3((n_segs + 63) / 64), dim3(64), 0, st, src, streams, segs, n_segs, prev, rec, bitmap, logs,
-                       hdrs);
-    else hipLaunchKernelGGL(enc_spec_kernel<false>, dim3((n_segs + 63) / 64), dim3(64), 0, st, src, streams, segs, n_segs, prev, rec, bitmap, logs,
-                       hdrs);
+    if (n_segs > 98304) hipLaunchKernelGGL(enc_spec_kernel<true>, dim3((n_segs + 63) / 64), dim3(64), 0, st, src, streams, segs, n_segs, seg, prev, rec, bitmap,
+                                           logs, hdrs);
+    else hipLaunchKernelGGL(enc_spec_kernel<false>, dim3((n_segs + 63) / 64), dim3(64), 0, st, src, streams, segs, n_segs, seg, prev, rec, bitmap, logs, hdrs);
 }
-void launch_enc_stitch(const uint8_t *src, const EncStream *streams, uint32_t ns, const uint2 *segs, uint32_t n_segs, const uint32_t *prev,
+void launch_enc_stitch(const uint8_t *src, const EncStream *streams, uint32_t ns, const uint2 *segs, uint32_t n_segs, uint32_t seg, const uint32_t *prev,
                        const uint32_t *rec, const uint64_t *bitmap, const SpecEvent *logs, const SpecHeader *hdrs, uint4 *sync,
                        RangeRec *ranges, MatchRec *gaps, uint4 *gstate, EncStreamOut *outs, hipStream_t st) {
-    hipLaunchKernelGGL(enc_sync_kernel, dim3((n_segs + 63) / 64), dim3(64), 0, st, streams, segs, n_segs, logs, hdrs, sync);
-    hipLaunchKernelGGL(enc_stitch_kernel, dim3(ns), dim3(64), 0, st, src, streams, ns, prev, rec, bitmap, logs, hdrs, sync, ranges, gaps,
+    hipLaunchKernelGGL(enc_sync_kernel, dim3((n_segs + 63) / 64), dim3(64), 0, st, streams, segs, n_segs, seg, logs, hdrs, sync);
+    hipLaunchKernelGGL(enc_stitch_kernel, dim3(ns), dim3(64), 0, st, src, streams, ns, seg, prev, rec, bitmap, logs, hdrs, sync, ranges, gaps,
                        gstate, outs);
 }
 void launch_enc_cut(const EncStream *streams, uint32_t ns, const EncStreamOut *outs, const EncBlock *blocks, const RangeRec *ranges,

@@ -129,6 +129,11 @@ for rd in range(rounds):
     assert all(e == 0 for e in st), st
     for i, (r, o, w) in enumerate(zip(raws, outs, want)):
         assert o.tobytes() == w, f"round {rd}: encode differs, stream {i} of {len(r)} bytes"
+    # a few of them again as a batch of their own: small batches of small streams are parsed in shorter segments (seg_for)
+    pick = [int(x) for x in rng.choice(len(raws), size=min(6, len(raws)), replace=False)]
+    souts, sst = ctx.encode_batch([raws[i] for i in pick], ring=bool(RING and rd & 1))
+    for i, o in zip(pick, souts):
+        assert o.tobytes() == (O.ring_encode(raws[i]) if (RING and rd & 1) else want[i]), f"round {rd}: small-batch encode differs, stream {i} of {len(raws[i])} bytes"
     if RING:
         rwant = [O.ring_encode(r) for r in raws]
         routs, rst = ctx.encode_batch(raws, ring=True)
