@@ -1229,8 +1229,12 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
                     const uint32_t lm = s_lm[slot], ddq = s_d[slot];
                     const uint32_t mq = s_off[slot] + (lm & 0xFFFF), mm = lm >> 16;
                     const int64_t sq = (int64_t)mq - (int64_t)ddq;
+                    // A match that overlaps itself (d < m: a run, or a short period) repeats its first d source bytes: byte k
+                    // is a copy of byte k mod d of the source. Pointing every origin there instead of d bytes back keeps
+                    // the chain one hop long where it would be m / d hops (a run of zeros: 2 359, a dozen jumping rounds).
+                    const bool wrap = ddq < mm && sq >= 0;
                     for (uint32_t k = lane; k < mm; k += 64) {
-                        const int64_t sp = sq + k;
+                        const int64_t sp = sq + (wrap ? k % ddq : k);
                         const uint32_t qq = mq + k;
                         if (sp >= 0) { s_org[qq] = (uint16_t)sp; atomicOr(&s_dm[qq & (NT - 1)], 1u << (qq >> NTS)); }
                         else t[qq] = dst[(int64_t)tile_base + sp];
@@ -1729,8 +1733,10 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
                     } else if (kind == 2) {
                         const uint32_t mq = o + ll;
                         const int64_t sq = (int64_t)mq - (int64_t)s_d[slot];
+                        const uint32_t ddq = s_d[slot];
+                        const bool wrap = ddq < mm && sq >= 0;   // (a match that overlaps itself: origins into its first d source bytes, dec_lz_kernel)
                         for (uint32_t k = lane; k < mm; k += 64) {
-                            const int64_t sp = sq + k;
+                            const int64_t sp = sq + (wrap ? k % ddq : k);
                             const uint32_t qq = mq + k;
                             if (sp >= 0) { s_org[qq] = (uint16_t)sp; atomicOr(&s_dm[qq & (NT - 1)], 1u << (qq >> NTS)); }
                         }
