@@ -90,26 +90,43 @@ class Context:
 
     # -- host-pointer batch --
     def _host_batch(self, fn, srcs, caps):
+        """One call of a host-pointer batch entry point. The outputs are views into ONE buffer, and the pointer arrays are made
+        by numpy: with tens of thousands of small streams a Python-level array per stream costs more than the device call."""
         n = len(srcs)
-        arrs = [np.frombuffer(bytes(s) if not isinstance(s, np.ndarray) else s, dtype=np.uint8) for s in srcs]
-        outs = [np.empty(max(int(c), 1), dtype=np.uint8) for c in caps]
-        sp = (C.c_void_p * n)(*[a.ctypes.data if a.size else None for a in arrs])
-        sl = (C.c_size_t * n)(*[a.size for a in arrs])
-        dp = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
-        dc = (C.c_size_t * n)(*[int(c) for c in caps])
-        ol = (C.c_size_t * n)()
-        st = (C.c_int * n)()
-        _check(fn(self._h, n, sp, sl, dp, dc, ol, st))
-        return [outs[i][: ol[i]] for i in range(n)], list(st)
+        arrs = [s if (isinstance(s, np.ndarray) and s.dtype == np.uint8 and s.ndim == 1 and s.flags.c_contiguous)
+                else np.frombuffer(s if isinstance(s, (bytes, bytearray, memoryview, np.ndarray)) else bytes(s), dtype=np.uint8) for s in srcs]
+        lens = np.fromiter((a.size for a in arrs), dtype=np.uint64, count=n)
+        sp = np.fromiter((a.__array_interface__["data"][0] if a.size else 0 for a in arrs), dtype=np.uint64, count=n)
+        dc = np.asarray(caps, dtype=np.uint64).reshape(n)
+        room = np.maximum(dc, 1)
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum((room + np.uint64(63)) & ~np.uint64(63), out=offs[1:])
+        big = np.empty(int(offs[n]) + 64, dtype=np.uint8)
+        dp = np.uint64(big.ctypes.data) + offs[:n]
+        ol = np.zeros(n, dtype=np.uint64)
+        st = np.zeros(n, dtype=np.int32)
+        vpp, szp, ip = C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int)
+        _check(fn(self._h, n, sp.ctypes.data_as(vpp), lens.ctypes.data_as(szp), dp.ctypes.data_as(vpp), dc.ctypes.data_as(szp),
+                  ol.ctypes.data_as(szp), st.ctypes.data_as(ip)))
+        o, e = offs.tolist(), ol.tolist()
+        return [big[o[i]: o[i] + e[i]] for i in range(n)], st.tolist()
 
     def encode_batch(self, srcs, ring=False):
         """ring=True: the streams LzfseRingEncoder::encode / LzfseWriter produce (encode/frontend_ring.rs: another parse)."""
-        caps = [self._lib.lzfse_mi_encode_bound(len(s)) for s in srcs]
+        caps = [self._lib.lzfse_mi_encode_bound(len(s)) for s in srcs] if len(srcs) < 64 else _encode_bounds(self._lib, srcs)
         return self._host_batch(self._lib.lzfse_mi_encode_ring_batch if ring else self._lib.lzfse_mi_encode_batch, srcs, caps)
 
     def decode_batch(self, srcs, caps=None):
         if caps is None:
-            caps = [decode_size(s, partial=True) for s in srcs]
+            if len(srcs) < 64:
+                caps = [decode_size(s, partial=True) for s in srcs]
+            else:   # (many streams: no numpy / ctypes object per header walk)
+                srcs = [s if isinstance(s, (bytes, np.ndarray)) else bytes(s) for s in srcs]
+                v, size_of, caps = C.c_uint64(0), self._lib.lzfse_mi_decode_size, []
+                ref = C.byref(v)
+                for s in srcs:
+                    size_of(s if isinstance(s, bytes) else s.ctypes.data, len(s), ref)
+                    caps.append(v.value)
         return self._host_batch(self._lib.lzfse_mi_decode_batch, srcs, caps)
 
     # -- device-resident batch: raw device pointers (e.g. torch tensor.data_ptr()) --
@@ -134,6 +151,14 @@ class Context:
     def encode_batch_device(self, d_src, src_off, src_len, d_dst, dst_off, dst_cap, ring=False):
         fn = self._lib.lzfse_mi_encode_ring_batch_device if ring else self._lib.lzfse_mi_encode_batch_device
         return self._device_batch(fn, d_src, src_off, src_len, d_dst, dst_off, dst_cap)
+
+
+def _encode_bounds(lib, srcs):
+    """lzfse_mi_encode_bound for many inputs at once (the library's formula, checked against the library on one of them)"""
+    n = np.fromiter((len(s) for s in srcs), dtype=np.uint64, count=len(srcs))
+    caps = n + n // np.uint64(2) + n // np.uint64(4) + np.uint64(4096)
+    assert int(caps[0]) == lib.lzfse_mi_encode_bound(int(n[0]))
+    return caps
 
 
 def encode_small(src):
