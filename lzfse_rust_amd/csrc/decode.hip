@@ -987,6 +987,46 @@ constexpr uint32_t SHORT_COPY = 24;
 constexpr int LZ_LPT = 2;
 constexpr int JUMP_SWEEPS = 3;   // jumping sweeps over a thread's unresolved bytes per workgroup barrier  // copies up to this many bytes are done by the owning lane
 
+// ---- runs and short periods inside a tile (matches that overlap themselves: d < m) ----
+// Byte k >= d of such a match is a copy of byte k mod d of the match itself. Its origin entry says so and carries
+// ORG_WRAP: the entry is never swept (it is one hop from a byte that is), other chains pass through it, and the gather takes
+// the resolved origin of the byte it names. A tile of zeros is ALL such bytes: swept like the rest they cost ~190
+// instructions each (a 32 KiB pass 134 k cycles), now the match's first d bytes carry the chain and the rest ~15.
+constexpr uint32_t ORG_WRAP = 0x8000u, ORG_OFF = 0x7FFFu;
+
+// the sweeps of the pointer jumping when the tile holds ORG_WRAP entries (all threads; see the plain loop at the call sites)
+template <int NT, int TILE>
+__device__ __forceinline__ void tile_jump_wrap(uint16_t *s_org, const uint32_t *s_dm, uint32_t dm, int tid) {
+    static_assert(TILE <= 32768, "15-bit tile offsets");
+    constexpr uint32_t NTS = 31 - __builtin_clz((unsigned)NT);
+    uint32_t um = dm;
+    for (;;) {
+#pragma unroll 1
+        for (int sweep = 0; sweep < JUMP_SWEEPS && um; sweep++)
+            for (uint32_t m2 = um; m2; m2 &= m2 - 1) {
+                const uint32_t k = (uint32_t)__builtin_ctz(m2), b = tid + (k << NTS);
+                const uint32_t o = s_org[b];
+                if (o & ORG_WRAP) { um &= ~(1u << k); continue; }   // (static: resolved by the gather)
+                if (!((s_dm[o & (NT - 1)] >> (o >> NTS)) & 1u)) { um &= ~(1u << k); continue; }
+                const uint32_t o1 = s_org[o] & ORG_OFF;
+                if (!((s_dm[o1 & (NT - 1)] >> (o1 >> NTS)) & 1u)) { s_org[b] = (uint16_t)o1; um &= ~(1u << k); continue; }
+                s_org[b] = (uint16_t)(s_org[o1] & ORG_OFF);
+            }
+        if (!__syncthreads_or(um != 0)) break;
+    }
+}
+
+template <int NT, int TILE>
+__device__ __forceinline__ void tile_gather_wrap(uint8_t *t, const uint16_t *s_org, uint32_t dm, int tid) {
+    constexpr uint32_t NTS = 31 - __builtin_clz((unsigned)NT);
+    for (uint32_t m2 = dm; m2; m2 &= m2 - 1) {
+        const uint32_t b2 = tid + ((uint32_t)__builtin_ctz(m2) << NTS);
+        uint32_t o = s_org[b2];
+        if (o & ORG_WRAP) o = s_org[o & ORG_OFF];   // (the byte of the match's first d that this one repeats: its origin is final and plain)
+        t[b2] = t[o];
+    }
+}
+
 // LPT = LMDs per thread (consecutive slots): what a group costs is mostly its barriers and the latency of its dependent
 // loads, and both serve twice the bytes with two LMDs per thread (round 3)
 template <int NT, int TILE, int LPT>
@@ -1006,7 +1046,7 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
     __shared__ uint32_t s_dm[NT];     // bit k of s_dm[x]: tile byte x + k * NT is produced by an in-tile match
     __shared__ uint32_t s_long[2 * NS];
     __shared__ uint32_t s_scan[2 * NW + 4];
-    __shared__ uint32_t s_cnt[4];
+    __shared__ uint32_t s_cnt[8];   // [4]: the tile holds ORG_WRAP entries
     __shared__ int s_status;
 
     // one workgroup per stream, and a stream's time goes with its size (14 KB .. 700 KB in one Snappy batch): the
@@ -1085,7 +1125,7 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
             uint32_t my_parts = 0;
 #pragma unroll
             for (int h = 0; h < LPT; h++) { part[h] = valid[h] && (ex_s[h] + span[h] <= (uint32_t)TILE); my_parts += part[h] ? 1u : 0u; }
-            if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; s_cnt[2] = 0; s_cnt[3] = 0; }
+            if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; s_cnt[2] = 0; s_cnt[3] = 0; s_cnt[4] = 0; }
             __syncthreads();
             {
                 const uint32_t wsum = wave_incl_scan(my_parts);
@@ -1233,15 +1273,21 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
                     // is a copy of byte k mod d of the source. Pointing every origin there instead of d bytes back keeps
                     // the chain one hop long where it would be m / d hops (a run of zeros: 2 359, a dozen jumping rounds).
                     const bool wrap = ddq < mm && sq >= 0;
+                    if (wrap && lane == 0) s_cnt[4] = 1u;
                     for (uint32_t k = lane; k < mm; k += 64) {
-                        const int64_t sp = sq + (wrap ? k % ddq : k);
+                        const int64_t sp = sq + k;
                         const uint32_t qq = mq + k;
-                        if (sp >= 0) { s_org[qq] = (uint16_t)sp; atomicOr(&s_dm[qq & (NT - 1)], 1u << (qq >> NTS)); }
+                        if (wrap && k >= ddq) { s_org[qq] = (uint16_t)((mq + k % ddq) | ORG_WRAP); atomicOr(&s_dm[qq & (NT - 1)], 1u << (qq >> NTS)); }
+                        else if (sp >= 0) { s_org[qq] = (uint16_t)sp; atomicOr(&s_dm[qq & (NT - 1)], 1u << (qq >> NTS)); }
                         else t[qq] = dst[(int64_t)tile_base + sp];
                     }
                 }
                 __syncthreads();
                 const uint32_t dm = s_dm[tid];
+                if (s_cnt[4]) {   // (uniform) runs / short periods in the tile
+                    tile_jump_wrap<NT, TILE>(s_org, s_dm, dm, tid);
+                    tile_gather_wrap<NT, TILE>(t, s_org, dm, tid);
+                } else {
                 uint32_t um = dm;  // owned bytes whose origin is not known to be final yet
                 for (;;) {
                     // several sweeps per barrier: a sweep may already see what other threads resolved in this round (every
@@ -1261,6 +1307,7 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
                 for (uint32_t m2 = dm; m2; m2 &= m2 - 1) {
                     const uint32_t b2 = tid + ((uint32_t)__builtin_ctz(m2) << NTS);
                     t[b2] = t[s_org[b2]];
+                }
                 }
             }
             __syncthreads();
@@ -1427,7 +1474,7 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
     __shared__ uint32_t s_long[2 * NS];   // slot * 4 + kind: 0 long literal run, 1 long match from earlier output, 2 long match that reads the tile, 3 = 1 but its source is final already
     __shared__ uint32_t s_turn[NS];       // what has to wait for the turn: slot * 2 + (0: kind 1, 1: the part of a kind 2 match that lies before the tile)
     __shared__ uint32_t s_scan[2 * NW + 4];
-    __shared__ uint32_t s_cnt[4];
+    __shared__ uint32_t s_cnt[8];   // [4]: the tile holds ORG_WRAP entries
     __shared__ uint32_t s_tk[2];
     __shared__ int s_status;
 #ifdef LZFSE_MI_DIAG
@@ -1626,7 +1673,7 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
             uint32_t my_parts = 0;
 #pragma unroll
             for (int h = 0; h < LPT; h++) { part[h] = valid[h] && (ex_s[h] + span[h] <= (uint32_t)TILE); my_parts += part[h] ? 1u : 0u; }
-            if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; s_cnt[2] = 0; s_cnt[3] = 0; }
+            if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; s_cnt[2] = 0; s_cnt[3] = 0; s_cnt[4] = 0; }
             __syncthreads();
             {
                 const uint32_t wsum = wave_incl_scan(my_parts);
@@ -1734,18 +1781,22 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
                         const uint32_t mq = o + ll;
                         const int64_t sq = (int64_t)mq - (int64_t)s_d[slot];
                         const uint32_t ddq = s_d[slot];
-                        const bool wrap = ddq < mm && sq >= 0;   // (a match that overlaps itself: origins into its first d source bytes, dec_lz_kernel)
+                        const bool wrap = ddq < mm && sq >= 0;   // (a match that overlaps itself: ORG_WRAP entries, see above)
+                        if (wrap && lane == 0) s_cnt[4] = 1u;
                         for (uint32_t k = lane; k < mm; k += 64) {
-                            const int64_t sp = sq + (wrap ? k % ddq : k);
+                            const int64_t sp = sq + k;
                             const uint32_t qq = mq + k;
-                            if (sp >= 0) { s_org[qq] = (uint16_t)sp; atomicOr(&s_dm[qq & (NT - 1)], 1u << (qq >> NTS)); }
+                            if (wrap && k >= ddq) { s_org[qq] = (uint16_t)((mq + k % ddq) | ORG_WRAP); atomicOr(&s_dm[qq & (NT - 1)], 1u << (qq >> NTS)); }
+                            else if (sp >= 0) { s_org[qq] = (uint16_t)sp; atomicOr(&s_dm[qq & (NT - 1)], 1u << (qq >> NTS)); }
                         }
                     }
                 }
             }
             __syncthreads();
             const uint32_t dm = s_dm[tid];
-            if (!tile_bad && tot_dep) {
+            const bool any_wrap = s_cnt[4] != 0;   // (uniform; stable until the next tile's reset, which lies behind a barrier)
+            if (!tile_bad && tot_dep && any_wrap) tile_jump_wrap<NT, TILE>(s_org, s_dm, dm, tid);
+            else if (!tile_bad && tot_dep) {
                 uint32_t um = dm;
                 for (;;) {
 #pragma unroll 1
@@ -1845,7 +1896,8 @@ __global__ __launch_bounds__(NT) void dec_lzp_kernel(
             for (uint32_t q = wave + NW; q < n_turn; q += NW) turn_copy(s_turn[q], false, 0);
             __syncthreads();
             const uint64_t u1 = __builtin_amdgcn_s_memtime();
-            if (tot_dep)
+            if (tot_dep && any_wrap) tile_gather_wrap<NT, TILE>(t, s_org, dm, tid);
+            else if (tot_dep)
                 for (uint32_t m2 = dm; m2; m2 &= m2 - 1) {
                     const uint32_t b2 = tid + ((uint32_t)__builtin_ctz(m2) << NTS);
                     t[b2] = t[s_org[b2]];
