@@ -1,5 +1,6 @@
-"""Encode throughput on highly repetitive inputs (device-resident batches): the inputs on which capped candidate records
-make the segment walkers ask for exact lengths most often.   python scripts/repetitive_bench.py"""
+"""Encode and decode throughput on highly repetitive inputs (device-resident batches of 256 x 1 MiB): the inputs on which
+capped candidate records make the segment walkers ask for exact lengths most often, and on which a tile of the LZ stage is
+mostly matches that overlap themselves.   python scripts/repetitive_bench.py      (profiles/r03_repetitive.txt)"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,6 +20,9 @@ def periodic(per, n, mut):
 cases = [("period 300", lambda: periodic(300, 1 << 20, 0)), ("period 1100", lambda: periodic(1100, 1 << 20, 0)),
          ("period 1100, 1 change per 700 B", lambda: periodic(1100, 1 << 20, 700)), ("period 40, 1 change per 60 B", lambda: periodic(40, 1 << 20, 60)),
          ("period 5000, 1 change per 300 B", lambda: periodic(5000, 1 << 20, 300)), ("period 250000", lambda: periodic(250000, 1 << 20, 0)),
+         ("period 7", lambda: periodic(7, 1 << 20, 0)),
+         ("runs of 3 .. 400 equal bytes", lambda: np.repeat(rng.integers(0, 256, size=12000, dtype=np.uint8), rng.integers(3, 400, size=12000))[:1 << 20].copy()),
+         ("runs of 2 400 .. 7 000 equal bytes", lambda: np.repeat(rng.integers(0, 256, size=900, dtype=np.uint8), rng.integers(2400, 7000, size=900))[:1 << 20].copy()),
          ("zeros", lambda: np.zeros(1 << 20, dtype=np.uint8))]
 for name, gen in cases:
     parts = [gen() for _ in range(4)] * 64          # 256 streams of 1 MiB
@@ -36,4 +40,12 @@ for name, gen in cases:
     ol, st = ctx.encode_batch_device(src.data_ptr(), so, sl, dst.data_ptr(), do, dc)
     t1 = time.perf_counter()
     assert all(int(e) == 0 for e in st)
-    print(f"{name:34s} encode {src.numel() / (t1 - t0) / 1e9:6.2f} GB/s, ratio {src.numel() / float(sum(int(x) for x in ol)):.0f}")
+    back = torch.empty(n * len(parts), dtype=torch.uint8, device=dev)
+    el = np.asarray([int(x) for x in ol], dtype=np.uint64)
+    ctx.decode_batch_device(dst.data_ptr(), do, el, back.data_ptr(), so, sl)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    ol2, st2 = ctx.decode_batch_device(dst.data_ptr(), do, el, back.data_ptr(), so, sl)
+    t3 = time.perf_counter()
+    assert all(int(e) == 0 for e in st2) and torch.equal(back, src)
+    print(f"{name:34s} encode {src.numel() / (t1 - t0) / 1e9:6.2f} GB/s, decode {src.numel() / (t3 - t2) / 1e9:6.2f} GB/s, ratio {src.numel() / float(sum(int(x) for x in ol)):.0f}")
