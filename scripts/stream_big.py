@@ -10,13 +10,26 @@ import oracle_py
 from bench import synth_text
 
 gib = float(sys.argv[1]) if len(sys.argv) > 1 else 2.2
+kind = sys.argv[2] if len(sys.argv) > 2 else "text"      # text | mixed (text, low-entropy noise, noise, zeros, runs in turn)
 base = np.frombuffer(synth_text(64 << 20, seed=3), dtype=np.uint8)
 copies = int(gib * 16) + 1
 raw = np.empty(copies * base.size, dtype=np.uint8)
+rng = np.random.default_rng(5)
 for c in range(copies):
     a = raw[c * base.size:(c + 1) * base.size]
     a[:] = base
     a[c % 251::251] ^= np.uint8(1 + c % 200)
+    if kind == "mixed":
+        k = c % 5
+        if k == 1:
+            a[:] = rng.integers(0, 4, size=a.size, dtype=np.uint8) * 85
+        elif k == 2:
+            a[: a.size // 2] = rng.integers(0, 256, size=a.size // 2, dtype=np.uint8)
+        elif k == 3:
+            a[a.size // 4: a.size // 4 * 3] = 0
+        elif k == 4:
+            r = np.repeat(rng.integers(0, 256, size=a.size // 600, dtype=np.uint8), rng.integers(3, 1200, size=a.size // 600))
+            a[: min(a.size, r.size)] = r[: a.size]
 print(f"{raw.size} bytes", flush=True)
 O = oracle_py.Oracle()
 t = time.time()
