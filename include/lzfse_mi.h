@@ -200,10 +200,11 @@ LZFSE_MI_API size_t lzfse_mi_decode_headroom(const uint8_t *src, size_t n);
  * pieces; the result is the slice path's: the same bytes, and for a damaged stream the same status at the feed call
  * that completes the evidence (sticky afterwards). finish != 0 marks the end of the input: a stream that does not end
  * with bvx$ in its last 4 bytes is an error (decode/decoder.rs:93-95). `window` (0 = LZFSE_MI_STREAM_WINDOW) is the
- * number of raw bytes decoded per device call. `write` returns 0 to go on. */
+ * number of raw bytes decoded per device call: a window's blocks are decoded when they are all there (or the input
+ * ends), so output follows input by up to a window. `write` returns 0 to go on. */
 /* (a window is ONE stream on the device, and one stream costs its latency floors -- a block's entropy chain, the header
- * walk -- whatever its size: 64 MiB windows decode 256 MiB of text at 4.5 GB/s where 16 MiB windows reach 2.7 and the slice
- * call 7.5, host pointers on both sides) */
+ * walk -- whatever its size: 64 MiB windows decode 256 MiB of text at 8 GB/s (4.6 through the Python mirror, where 16 MiB
+ * windows reach 3.8) against 15 for the slice call, host pointers on both sides, reused buffers: profiles/r03_stream_bench.txt) */
 #define LZFSE_MI_STREAM_WINDOW ((size_t)64 << 20)
 typedef struct lzfse_mi_dstream lzfse_mi_dstream;
 typedef int (*lzfse_mi_write_fn)(void *user, const uint8_t *bytes, size_t n);
