@@ -203,8 +203,8 @@ LZFSE_MI_API size_t lzfse_mi_decode_headroom(const uint8_t *src, size_t n);
  * number of raw bytes decoded per device call: a window's blocks are decoded when they are all there (or the input
  * ends), so output follows input by up to a window. `write` returns 0 to go on. */
 /* (a window is ONE stream on the device, and one stream costs its latency floors -- a block's entropy chain, the header
- * walk -- whatever its size: 64 MiB windows decode 256 MiB of text at 8 GB/s (4.6 through the Python mirror, where 16 MiB
- * windows reach 3.8) against 15 for the slice call, host pointers on both sides, reused buffers: profiles/r03_stream_bench.txt) */
+ * walk -- whatever its size: through the Python mirror 64 MiB windows decode 256 MiB of text at 9.4 GB/s, 16 MiB windows at 5.5,
+ * 4 MiB windows at 2.2; the slice call into a reused buffer reaches 15: profiles/r03_stream_bench.txt) */
 #define LZFSE_MI_STREAM_WINDOW ((size_t)64 << 20)
 typedef struct lzfse_mi_dstream lzfse_mi_dstream;
 typedef int (*lzfse_mi_write_fn)(void *user, const uint8_t *bytes, size_t n);

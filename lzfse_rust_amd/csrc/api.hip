@@ -144,6 +144,7 @@ struct lzfse_mi_ctx {
     bool pipe_tested = false;   // the hand-over self-test (dec_lzp_selftest_kernel) has run on this context
     uint32_t pipe_refusals = 0; // times the pipelined LZ kernel was given up (self-test failed / a launch refused): lzfse_mi_get_info
     int lane_share = 1;    // sub-batches running side by side with this one (split_batch)
+    lzmi::StreamSpare spare;             // buffers a finished stream object leaves for the next one (stream.hip)
     lzmi::EncWindow *window = nullptr;   // set for the duration of one window of a stream encode (stream.hip)
     bool parse_ring = false;   // set for the duration of a ring / stream encode call (lzfse_mi_encode_ring*, lzfse_mi_estream_*)
     int diag_lz_jump = -1, diag_lz_variant = -1, diag_stats = 0, diag_chain = 0, diag_walk = 0, diag_pipe_scatter = 0;  // diagnostic build only
@@ -178,6 +179,7 @@ LaneGate *ctx_gate_out(lzfse_mi_ctx *c) { return c->gate_out; }
 int ctx_diag_stats(lzfse_mi_ctx *c) { return c->diag_stats; }
 bool ctx_parse_ring(lzfse_mi_ctx *c) { return c->parse_ring; }
 EncWindow *ctx_window(lzfse_mi_ctx *c) { return c->window; }
+StreamSpare &ctx_spare(lzfse_mi_ctx *c) { return c->spare; }
 void ctx_set_window(lzfse_mi_ctx *c, EncWindow *w) { c->window = w; }
 int ctx_diag_chain(lzfse_mi_ctx *c) { return c->diag_chain; }
 }  // namespace lzmi
@@ -307,6 +309,7 @@ void lzfse_mi_destroy(lzfse_mi_ctx *c) {
     c->h_in.release();
     c->h_out.release();
     c->h_small.release();
+    std::free(c->spare.p[0]); std::free(c->spare.p[1]);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;

@@ -5,6 +5,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <vector>
 
 struct lzfse_mi_ctx;
 
@@ -51,6 +52,15 @@ struct EncWindow {
     uint32_t found = 0, index = 0, lit = 0, p_idx = 0, p_midx = 0, p_len = 0, skip_out = 0;
 };
 EncWindow *ctx_window(lzfse_mi_ctx *c);
+// Host buffers of the stream objects (stream.hip) that outlive them: a stream object's window buffers are tens of MiB, and
+// pages touched for the first time cost more than the window's decode -- the next stream object of the context takes over
+// what the last one left (slot 0: decode output, 1: encode output; malloc'd) and the vectors (0: decoder input, 1: encoder input).
+struct StreamSpare {
+    uint8_t *p[2] = {nullptr, nullptr};
+    size_t cap[2] = {0, 0};
+    std::vector<uint8_t> v[2];
+};
+StreamSpare &ctx_spare(lzfse_mi_ctx *c);
 void ctx_set_window(lzfse_mi_ctx *c, EncWindow *w);
 int ctx_diag_chain(lzfse_mi_ctx *c);  // LZFSE_MI_OPT_DIAG_CHAIN: 1 = every chain tile through the ballot kernel
 

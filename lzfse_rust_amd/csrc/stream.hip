@@ -32,7 +32,12 @@ struct lzfse_mi_dstream {
     std::vector<uint8_t> tmp_src;
     uint8_t *tmp_dst = nullptr;    // malloc'd, never zero-filled: a damaged header may promise gigabytes that are never written
     size_t tmp_dst_cap = 0;
-    ~lzfse_mi_dstream() { std::free(tmp_dst); }
+    ~lzfse_mi_dstream() {
+        // (what this object's windows grew stays with the context for the next stream object)
+        StreamSpare &sp = ctx_spare(ctx);
+        if (tmp_dst_cap > sp.cap[0]) { std::free(sp.p[0]); sp.p[0] = tmp_dst; sp.cap[0] = tmp_dst_cap; } else std::free(tmp_dst);
+        if (in.capacity() > sp.v[0].capacity()) { in.clear(); sp.v[0].swap(in); }
+    }
     uint64_t total_in = 0, total_out = 0;
     int status = 0;                // sticky
     bool eos_seen = false;         // bvx$ consumed: any further byte is PayloadOverflow (decoder.rs:93-95)
@@ -200,6 +205,12 @@ LZFSE_MI_API int lzfse_mi_dstream_create(lzfse_mi_ctx *ctx, size_t window, lzfse
     if (!s) return LZFSE_MI_IO;
     s->ctx = ctx;
     s->window = window ? window : (size_t)LZFSE_MI_STREAM_WINDOW;
+    {
+        StreamSpare &sp = ctx_spare(ctx);
+        s->tmp_dst = sp.p[0]; s->tmp_dst_cap = sp.cap[0]; sp.p[0] = nullptr; sp.cap[0] = 0;
+        s->in.swap(sp.v[0]);
+        s->in.clear();
+    }
     *out = s;
     return LZFSE_MI_OK;
 }
@@ -285,7 +296,11 @@ struct lzfse_mi_estream {
     uint64_t total_in = 0, total_out = 0;
     int status = 0;               // sticky
     bool finished = false;
-    ~lzfse_mi_estream() { std::free(out); }
+    ~lzfse_mi_estream() {
+        StreamSpare &sp = ctx_spare(ctx);
+        if (out_cap > sp.cap[1]) { std::free(sp.p[1]); sp.p[1] = out; sp.cap[1] = out_cap; } else std::free(out);
+        if (buf.capacity() > sp.v[1].capacity()) { buf.clear(); sp.v[1].swap(buf); }
+    }
 };
 
 namespace {
@@ -370,6 +385,12 @@ int lzfse_mi_estream_create(lzfse_mi_ctx *ctx, size_t window, lzfse_mi_estream *
     if (s->window < E_MIN_WINDOW) s->window = E_MIN_WINDOW;
     if (s->window > ((size_t)1 << 30)) s->window = (size_t)1 << 30;
     s->next_at = s->window + ((size_t)1 << 19);   // (the last 256 KiB + 16 KiB of a window are never final: one ring on top)
+    {
+        StreamSpare &sp = ctx_spare(ctx);
+        s->out = sp.p[1]; s->out_cap = sp.cap[1]; sp.p[1] = nullptr; sp.cap[1] = 0;
+        s->buf.swap(sp.v[1]);
+        s->buf.clear();
+    }
     *out = s;
     return LZFSE_MI_OK;
 }
@@ -405,7 +426,7 @@ int lzfse_mi_estream_finish(lzfse_mi_estream *s, lzfse_mi_write_fn write, void *
     const int st = es_window(s, true, write, user);
     if (bytes_in) *bytes_in = s->total_in;
     if (bytes_out) *bytes_out = st ? 0 : s->total_out;
-    std::vector<uint8_t>().swap(s->buf);
+    s->buf.clear();   // (its room goes back to the context with the object)
     return s->status = st;
 }
 
