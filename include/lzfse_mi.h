@@ -90,6 +90,10 @@ enum {
     LZFSE_MI_OPT_DECODE_PIPE = 4,   /* several workgroups per stream in the LZ stage of decode: 0 by the batch's shape (default),
                                        1 never, else K | variant << 8: K workgroups (2..64) for every stream of the tile
                                        kernel, variant 0 = 256 threads / 8 KiB tiles, 1 = 1024 threads / 32 KiB tiles */
+    LZFSE_MI_OPT_STREAM_SPARE = 5,  /* 1 (default): the window buffers of a destroyed stream object (lzfse_mi_dstream / _estream)
+                                       stay with the context for the next one -- host memory, up to about window x (1 + 1.125)
+                                       for a decoder and window x (1 + 1.75) for an encoder, ~300 MiB at the default window,
+                                       until lzfse_mi_destroy; 0: free what is held now and keep nothing from now on */
     LZFSE_MI_OPT_DIAG_LZ_PATH = 100, /* -1: by cost, 0: tile kernel only, 1: pointer jumping for every stream */
     LZFSE_MI_OPT_DIAG_LZ_TILE = 101, /* -1: by stream count, 0: 256-thread / 8 KiB tile, 1: 1024-thread / 32 KiB tile */
     LZFSE_MI_OPT_DIAG_STATS = 102,   /* bit mask: per-stage statistics on stderr */
@@ -213,6 +217,8 @@ LZFSE_MI_API int lzfse_mi_dstream_feed(lzfse_mi_dstream *s, const uint8_t *src, 
                                        void *user);
 /* bytes of input consumed / of output written so far: the (u, v) LzfseRingDecoder::decode returns */
 LZFSE_MI_API int lzfse_mi_dstream_totals(const lzfse_mi_dstream *s, uint64_t *bytes_in, uint64_t *bytes_out);
+/* A stream object (decoder or encoder) and its context may be destroyed in either order: lzfse_mi_destroy(ctx) detaches the
+ * stream objects still alive, whose feed / finish then return LZFSE_MI_BAD_ARGUMENT and whose destroy frees only their own. */
 LZFSE_MI_API void lzfse_mi_dstream_destroy(lzfse_mi_dstream *s);
 
 /* ---- Ring / stream encode (encode half): LzfseRingEncoder::encode(reader, writer)

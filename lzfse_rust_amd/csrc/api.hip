@@ -145,9 +145,12 @@ struct lzfse_mi_ctx {
     uint32_t pipe_refusals = 0; // times the pipelined LZ kernel was given up (self-test failed / a launch refused): lzfse_mi_get_info
     int lane_share = 1;    // sub-batches running side by side with this one (split_batch)
     lzmi::StreamSpare spare;             // buffers a finished stream object leaves for the next one (stream.hip)
+    std::vector<lzfse_mi_ctx **> stream_refs;   // the `ctx` members of the stream objects alive on this context (ctx_attach)
+    std::mutex stream_refs_m;
     lzmi::EncWindow *window = nullptr;   // set for the duration of one window of a stream encode (stream.hip)
     bool parse_ring = false;   // set for the duration of a ring / stream encode call (lzfse_mi_encode_ring*, lzfse_mi_estream_*)
     int diag_lz_jump = -1, diag_lz_variant = -1, diag_stats = 0, diag_chain = 0, diag_walk = 0, diag_pipe_scatter = 0;  // diagnostic build only
+    uint64_t diag_last_lmds = 0;   // LMD records the entropy stage of the last decode pass on this context left in d_lmds (stage hook)
 
     hipEvent_t get_event() {
         if (ev_used == ev_pool.size()) {
@@ -180,6 +183,15 @@ int ctx_diag_stats(lzfse_mi_ctx *c) { return c->diag_stats; }
 bool ctx_parse_ring(lzfse_mi_ctx *c) { return c->parse_ring; }
 EncWindow *ctx_window(lzfse_mi_ctx *c) { return c->window; }
 StreamSpare &ctx_spare(lzfse_mi_ctx *c) { return c->spare; }
+void ctx_attach(lzfse_mi_ctx *c, lzfse_mi_ctx **ref) {
+    std::lock_guard<std::mutex> g(c->stream_refs_m);
+    c->stream_refs.push_back(ref);
+}
+void ctx_detach(lzfse_mi_ctx *c, lzfse_mi_ctx **ref) {
+    std::lock_guard<std::mutex> g(c->stream_refs_m);
+    for (size_t k = 0; k < c->stream_refs.size(); k++)
+        if (c->stream_refs[k] == ref) { c->stream_refs[k] = c->stream_refs.back(); c->stream_refs.pop_back(); break; }
+}
 void ctx_set_window(lzfse_mi_ctx *c, EncWindow *w) { c->window = w; }
 int ctx_diag_chain(lzfse_mi_ctx *c) { return c->diag_chain; }
 }  // namespace lzmi
@@ -288,6 +300,12 @@ int lzfse_mi_create(int device, lzfse_mi_ctx **out) {
 
 void lzfse_mi_destroy(lzfse_mi_ctx *c) {
     if (!c) return;
+    {
+        // stream objects that outlive the context: from now on they have none (their calls fail, their destructors free their own buffers)
+        std::lock_guard<std::mutex> g(c->stream_refs_m);
+        for (lzfse_mi_ctx **r : c->stream_refs) *r = nullptr;
+        c->stream_refs.clear();
+    }
     for (auto &w : c->worker) { delete w; w = nullptr; }
     for (auto &s : c->shadow) { if (s) lzfse_mi_destroy(s); s = nullptr; }
     (void)hipSetDevice(c->device);
@@ -508,6 +526,7 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
         }
     }
     if (nb > 0x7FFFFFFFull) return LZFSE_MI_UNSUPPORTED;
+    c->diag_last_lmds = nl;
     // Streams of the tile kernel that are large and few share several workgroups each (dec_lzp_kernel): with hundreds of
     // streams, or small ones, one workgroup per stream already fills the chip.
     std::vector<uint32_t> mlist;
@@ -683,6 +702,21 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
     timing_end(c);
     return LZFSE_MI_OK;
 }
+
+#ifdef LZFSE_MI_DIAG
+// Debug hook of the diagnostic build for stage-level parity tests (tests/test_gpu_decode.py): the LMD records dec_fse_kernel left
+// for the LZ stage in the last decode pass on this context -- pairs (l | m << 16, d with D = 0 substituted: lmd_type.rs:153-160),
+// streams in call order, blocks in stream order. Not part of the ABI; the product library does not export it.
+extern "C" LZFSE_MI_API int lzfse_mi_debug_last_lmds(lzfse_mi_ctx *c, uint32_t *h_pairs, size_t cap_lmds, size_t *n_lmds) {
+    if (!c || !n_lmds) return LZFSE_MI_BAD_ARGUMENT;
+    *n_lmds = (size_t)c->diag_last_lmds;
+    if (!h_pairs || cap_lmds < c->diag_last_lmds) return LZFSE_MI_BUFFER_OVERFLOW;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->diag_last_lmds) HIP_TRY(hipMemcpy(h_pairs, c->d_lmds.p, c->diag_last_lmds * sizeof(LmdRec), hipMemcpyDeviceToHost));
+    return LZFSE_MI_OK;
+}
+#endif
 
 static int encode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_src, const uint64_t *src_off,
                                    const uint64_t *src_len, void *d_dst, const uint64_t *dst_off,
@@ -903,6 +937,17 @@ int lzfse_mi_set_option(lzfse_mi_ctx *c, int option, int64_t value) {
         (option == LZFSE_MI_OPT_ENCODE_LANES ? c->opt_lanes_enc : c->opt_lanes_dec) = (int)value;
         return LZFSE_MI_OK;
     case LZFSE_MI_OPT_STAGGER: c->opt_stagger = value != 0; return LZFSE_MI_OK;
+    case LZFSE_MI_OPT_STREAM_SPARE:
+        // 0: free what finished stream objects left with the context and keep nothing from now on; 1 (default): keep
+        if (value != 0 && value != 1) return LZFSE_MI_BAD_ARGUMENT;
+        c->spare.keep = value != 0;
+        if (!c->spare.keep) {
+            for (int k = 0; k < 2; k++) {
+                std::free(c->spare.p[k]); c->spare.p[k] = nullptr; c->spare.cap[k] = 0;
+                std::vector<uint8_t>().swap(c->spare.v[k]);
+            }
+        }
+        return LZFSE_MI_OK;
     case LZFSE_MI_OPT_DECODE_PIPE:
         if (value < 0 || value > 0x1FF || (value > 1 && (value & 0xFF) > 64) || (value > 1 && (value & 0xFF) == 0)) return LZFSE_MI_BAD_ARGUMENT;
         c->opt_pipe = (int)value;

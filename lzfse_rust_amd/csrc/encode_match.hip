@@ -255,6 +255,39 @@ __device__ __forceinline__ uint32_t lcp_fwd(const uint8_t *s, uint32_t a, uint32
     return len;
 }
 
+__device__ __forceinline__ uint32_t ffbl_m1(uint32_t x) {   // v_ffbl_b32: index of the lowest set bit, 0xFFFFFFFF for 0
+    uint32_t r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ uint32_t add_sat(uint32_t a, uint32_t b) {   // unsigned add that stays at 0xFFFFFFFF
+    uint32_t r;
+    asm("v_add_u32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// index of the first non-zero byte of a 16-byte value (the difference of two: 0x1FFFFFFF if none). v_ffbl_b32 gives -1 for a zero dword, and
+// the saturating adds keep it there, so the minimum over the four dwords is the first set bit of the 128-bit difference.
+__device__ __forceinline__ uint32_t first_set_byte(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) {
+    const uint32_t b0 = ffbl_m1(x0), b1 = add_sat(ffbl_m1(x1), 32u), b2 = add_sat(ffbl_m1(x2), 64u), b3 = add_sat(ffbl_m1(x3), 96u);
+    const uint32_t bit = min(min(b0, b1), min(b2, b3));
+    return bit >> 3;
+}
+
+// minimum over the aligned group of 8 lanes a lane belongs to, in all of them (three DPP steps: the pairs of a quad, the
+// halves of a quad, the two quads of a half row)
+__device__ __forceinline__ uint32_t group8_min(uint32_t v) {
+    // (one v_min_u32_dpp per step; a DPP source written by the instruction before needs two wait states, which the compiler
+    // cannot see inside an asm: the s_nop)
+    asm("s_nop 1\n"
+        "v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf"
+        : "+v"(v));
+    return v;
+}
+
 // rec[i] = rec_make(dist, fwd_len, bwd) (enc_common.h); 0: no match at i
 //
 // One lane per position, hops in lock-step. A lane compares at most CAND_C1 bytes on its own. Lanes
@@ -264,6 +297,27 @@ __device__ __forceinline__ uint32_t lcp_fwd(const uint8_t *s, uint32_t a, uint32
 constexpr uint32_t CAND_C1 = 12;   // a lane compares 12 bytes on its own: what one dword-aligned 16-byte load holds of a candidate
 constexpr int CAND_GL = 8;  // lanes per group of the long-match work list
 constexpr uint32_t CAND_BPT = (TILE_POS + 255) / 256;  // workgroups per tile
+constexpr uint32_t CAND_WIN_DW = (32 + 256 + FCAP + 64 + 20 + 3) / 4 + 1;   // dwords of the workgroup's source window
+// (scripts/cand_phases.sh: instruction counts per phase -- the kernel is cut short after phase CAND_ABL with what it has computed kept
+// alive by an empty asm, and records "no match" everywhere: a valid all-literal parse; never defined in a library build)
+#ifdef CAND_STATS
+// (scripts/cand_phases.sh stats: what phase 3 meets -- printed per launch on stderr; never defined in a library build)
+__device__ unsigned long long g_cand_stats[32];
+#define CAND_STAT(k, v) do { if (lane == 0) atomicAdd(&g_cand_stats[k], (unsigned long long)(v)); } while (0)
+#else
+#define CAND_STAT(k, v)
+#endif
+#ifdef CAND_ABL
+#define CAND_ABL_EXIT(n, expr)                                                                      \
+    if (CAND_ABL == (n)) {                                                                          \
+        asm volatile("" ::"v"(expr));                                                               \
+        if (valid) rec[tl.pos_base + i] = 0;                                                        \
+        if (lane == 0 && i < tl.start + TILE_POS && i < n_pos) bitmap[(tl.pos_base + i) >> 6] = 0;  \
+        return;                                                                                     \
+    }
+#else
+#define CAND_ABL_EXIT(n, expr)
+#endif
 
 __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
                                                        const EncTile *__restrict__ tiles, uint32_t n_tiles, const uint32_t *__restrict__ prev,
@@ -274,7 +328,7 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
     // (LDS is kept small on purpose: this kernel runs next to another lane's chain kernel, whose tiles need 64 KiB each)
     __shared__ uint16_t q_id[4][256], q_res[4][256];   // per-wave work list of phase 3: slot * 64 + lane of a head; its length
     __shared__ uint32_t q_dist[4][256], q_tab[4][64];  // distance of a head (by slot * 64 + lane); first head per distance hash
-    __shared__ uint32_t s_win[4][52];                  // per wave: 192 source bytes around its 64 positions (+ read slack)
+    __shared__ uint32_t s_win[CAND_WIN_DW];            // source bytes [i_wg - 32, i_wg + 256 + FCAP + 64 + 16 ..) around the workgroup's 256 positions
     const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     // g: the g-th tile this XCD works on. An XCD takes 8 CONSECUTIVE tiles of every 64: a tile gathers from the up to
     // four tiles before it (the 262 139-byte window), and those are then the tiles the same L2 has just worked on.
@@ -293,24 +347,25 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
     const uint32_t max_total = valid ? n - i : 0;
     const uint32_t cap_total = max_total < FCAP ? max_total : FCAP;
     const uint32_t c1 = cap_total < CAND_C1 ? cap_total : CAND_C1;
-    // ---- source window of the wave: bytes [i0 - 32, i0 + 160) of the stream (i0 = position of lane 0) go to LDS
-    // with one coalesced load; every lane's own side of the byte compares (forward up to 64 + 16 bytes, backward
-    // up to 32) is read from there instead of 64 separate unaligned loads per step ----
+    // ---- source window of the workgroup: bytes [i_wg - 32, i_wg + 256 + FCAP + 64 + 20) of the stream (i_wg = position of
+    // thread 0; zeros before the stream's first and behind its last byte) go to LDS with coalesced loads. Every lane's OWN
+    // side of all byte compares is read from there -- forward up to FCAP + 64 (phase 3), backward up to 32 -- so that the
+    // texture addresser, which is what bounds this kernel (TA_BUSY 77 %, profiles/r04_cand_phases_tcp.txt), only sees the
+    // candidates' side ----
     {
-        const uint32_t i0 = i - (uint32_t)lane;
-        if (lane < 48) {
-            const int64_t pos = (int64_t)i0 - 32 + 4 * lane;
+        const int64_t w0 = (int64_t)(tl.start + bx * blockDim.x) - 32;
+        for (uint32_t k = threadIdx.x; k < CAND_WIN_DW; k += 256) {
+            const int64_t pos = w0 + 4 * (int64_t)k;
             uint32_t wv4 = 0;
             if (pos >= 0 && pos + 4 <= (int64_t)n) wv4 = ld_u32(s + pos);
             else
-                for (int k = 0; k < 4; k++)
-                    if (pos + k >= 0 && pos + k < (int64_t)n) wv4 |= (uint32_t)s[pos + k] << (8 * k);
-            s_win[threadIdx.x >> 6][lane] = wv4;
+                for (int t = 0; t < 4; t++)
+                    if (pos + t >= 0 && pos + t < (int64_t)n) wv4 |= (uint32_t)s[pos + t] << (8 * t);
+            s_win[k] = wv4;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
     }
-    const uint32_t *win = s_win[threadIdx.x >> 6];
+    const uint32_t *win = s_win + 16 * (threadIdx.x >> 6);   // the wave's view: byte 32 + lane is its lane's position
     // ---- phase 1: follow the chain (<= 3 dependent 4-byte gathers: a link record holds the distance to the next entry and
     // 14 check bits of THAT entry's 4 bytes). Equal check bits = candidate; the byte compare starts at byte 0, so the
     // rare entry whose check bits agree by chance (2^-14) is dropped there: history.rs Item.val == val, exactly. ----
@@ -334,6 +389,7 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
             }
         }
     }
+    CAND_ABL_EXIT(1, cc[0] ^ cc[1] ^ cc[2] ^ cc[3] ^ ln[0] ^ (ln[1] << 4) ^ (ln[2] << 8) ^ (ln[3] << 12))
     // ---- runs: consecutive positions inside one match see the same distance in the same chain slot, and
     // LCP(i + t, c + t) = LCP(i, c) - t. Only the first lane of such a run (its head) compares bytes; the
     // followers derive their length from the head's. The kernel is bound by the number of cache lines its
@@ -348,6 +404,7 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
         const uint32_t dlo = dpp_take<0x138, 0xF>(NONE, dk);   // wave_shr:1 -- one vector instruction; __shfl_up is a trip through the LDS crossbar
         fol[k] = ln[k] != 0 && lane > 0 && dlo == dk;
     }
+    CAND_ABL_EXIT(2, cc[0] ^ cc[1] ^ cc[2] ^ cc[3] ^ ln[0] ^ (ln[1] << 4) ^ (ln[2] << 8) ^ (ln[3] << 12) ^ ((uint32_t)fol[0] << 20) ^ ((uint32_t)fol[1] << 21) ^ ((uint32_t)fol[2] << 22) ^ ((uint32_t)fol[3] << 23))
     // ---- phase 2: the first CAND_C1 bytes of all heads together. A candidate's bytes come from ONE dword-aligned 16-byte
     // load (the 16 bytes from c & ~3 hold s[c .. c + 12] at any byte offset) shifted into place: a byte-misaligned vector
     // load costs the texture addresser about four times the cycles of an aligned one, and the addresser is what bounds
@@ -383,9 +440,12 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
         for (int k = 0; k < 4; k++)
             if (tail[k]) { const uint32_t m = lcp_fwd(s, i, cc[k], 0, c1); ln[k] = m >= 4 ? m : 0u; }  // within 16 bytes of the stream's end
     }
-    // ---- phase 3: heads still equal after CAND_C1 bytes go to a per-wave work list and are extended by groups
-    // of CAND_GL lanes, 16 bytes per lane and step, several heads at a time (up to FCAP + 64, so that 63
-    // followers stay exact up to FCAP); then the followers take head - t ----
+    CAND_ABL_EXIT(3, cc[0] ^ cc[1] ^ cc[2] ^ cc[3] ^ ln[0] ^ (ln[1] << 4) ^ (ln[2] << 8) ^ (ln[3] << 12) ^ ((uint32_t)fol[0] << 20) ^ ((uint32_t)fol[1] << 21) ^ ((uint32_t)fol[2] << 22) ^ ((uint32_t)fol[3] << 23))
+    // ---- phase 3: heads still equal after CAND_C1 bytes go to a per-wave work list and are extended by groups of
+    // CAND_GL lanes, 16 bytes per lane and step, 8 heads at a time (up to FCAP + 64, so that 63 followers stay exact up to
+    // FCAP); a group that has finished its head takes the next one from the list while the others go on with theirs (on the
+    // Snappy files a wave has 13 such heads on average, 15 % of them longer than the 128 bytes of a step, 9 % longer than the
+    // cap: profiles/r04_cand_stats.txt); then the followers take head - t ----
     {
         const int wv = threadIdx.x >> 6;
         bool more[4], dep[4];
@@ -398,7 +458,10 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
             any_more |= __ballot(more[k]);
         }
         uint32_t total = 0;
+        CAND_STAT(0, 1);
+        CAND_STAT(1, any_more != 0);
         if (any_more) {
+#ifndef CAND_NO_DEDUP
             // Heads of the wave with the same distance that are < CAND_C1 positions apart lie inside one match (each is
             // >= CAND_C1 long): LCP(i2, i2 - d) = LCP(i0, i0 - d) + i0 - i2. One of them is measured.
             q_tab[wv][lane] = 0xFFFFFFFFu;
@@ -423,6 +486,11 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
                     dep[k] = lead[k] != (uint32_t)(k * 64 + lane) && q_dist[wv][lead[k]] == dk &&
                              (uint32_t)(gap < 0 ? -gap : gap) < CAND_C1;
                 }
+#else
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (more[k]) q_dist[wv][k * 64 + lane] = i - cc[k];
+#endif
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const bool ind = more[k] && !dep[k];
@@ -431,62 +499,81 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
                 total += (uint32_t)__popcll(mk);
             }
         }
+#ifdef CAND_STATS
+        {
+            uint32_t nm = 0, nd = 0;
+            for (int k = 0; k < 4; k++) { nm += (uint32_t)__popcll(__ballot(more[k])); nd += (uint32_t)__popcll(__ballot(dep[k])); }
+            CAND_STAT(2, nm); CAND_STAT(3, nd); CAND_STAT(4, total);
+            CAND_STAT(8 + (total == 0 ? 0 : total == 1 ? 1 : total == 2 ? 2 : total <= 4 ? 3 : total <= 8 ? 4 : total <= 16 ? 5 : total <= 32 ? 6 : 7), 1);
+        }
+        uint32_t n_iter = 0;
+#endif
         if (total) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const int g = lane / CAND_GL, sub = lane % CAND_GL;
-            const uint64_t gmask = ((1ull << CAND_GL) - 1) << (g * CAND_GL);
-            const uint64_t before = (1ull << (g * CAND_GL)) - 1;
-            uint32_t next = 0, it_i = 0, it_c = 0, it_lim = 0, it_off = 0, it_id = 0;
+            // A step of a group: 128 bytes of its head. The CANDIDATE's bytes come as 16-byte ALIGNED chunks, one per lane
+            // (8 lanes on 128 contiguous bytes cost the texture addresser 0.58 clk per lane when they are aligned, 1.06 when
+            // they are not: profiles/r04_gather_bench.txt; round 3 loaded both sides byte-misaligned, 43 % of the kernel's L1
+            // accesses); the position's own bytes are read from the workgroup's window in LDS at whatever byte offset that
+            // makes. The first chunk may begin up to 3 bytes before the head's position (those bytes are masked) or inside
+            // the CAND_C1 bytes phase 2 has compared (equal again); behind the end of the stream the window holds zeros and
+            // whatever differs there lies beyond the limit.
+            const uint32_t i0 = i - (uint32_t)lane, sub = (uint32_t)lane % CAND_GL;
+            uint32_t next = 0, it_lim = 0, it_id = 0, it_w = 0;
+            int32_t it_t = 0;           // offset (from the head's position) of the byte the group's NEXT chunk 0 begins with
+            const uint4 *it_p = nullptr;   // that chunk
             bool busy = false;
             for (;;) {
-                const uint64_t idle = __ballot(!busy && sub == 0);
+                const uint64_t idle = __ballot(!busy);   // (a group is idle or busy as a whole)
                 if (next < total && idle) {
-                    const uint32_t q = next + (uint32_t)__popcll(idle & before);
+                    // the idle groups take the next heads of the list, in group order: a lane counts the idle LANES below it
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                    const uint32_t q = next + below / CAND_GL;
                     if (!busy && q < total) {
                         busy = true;
                         it_id = q_id[wv][q];
-                        it_i = i - (uint32_t)lane + (it_id & 63);
-                        it_c = it_i - q_dist[wv][it_id];
-                        it_off = CAND_C1;
-                        const uint32_t maxh = n - it_i;
-                        it_lim = maxh < FCAP + 64 ? maxh : FCAP + 64;
+                        const uint32_t hl = it_id & 63, hi = i0 + hl;
+                        const uint8_t *cp = s + (hi - q_dist[wv][it_id]);
+                        const uintptr_t pa = ((uintptr_t)cp + CAND_C1) & ~(uintptr_t)15;
+                        it_p = reinterpret_cast<const uint4 *>(pa);
+                        it_t = (int32_t)(uint32_t)(pa - (uintptr_t)cp);   // -3 .. CAND_C1
+                        it_w = 32u + 64u * (uint32_t)wv + hl;
+                        const uint32_t room = n - hi;
+                        it_lim = room < FCAP + 64 ? room : FCAP + 64;
                     }
-                    next += (uint32_t)__popcll(idle);
+                    next += (uint32_t)__popcll(idle) / CAND_GL;
                 }
                 if (!__any(busy)) break;
-                const uint32_t o = it_off + 16 * sub;
-                uint64_t xl = 0, xh = 0;
-                if (busy && o < it_lim) {
-                    if (it_i + o + 16 <= n) {
-                        const uint4 a = ld_u128(s + it_i + o), bq = ld_u128(s + it_c + o);
-                        xl = ((uint64_t)(a.y ^ bq.y) << 32) | (a.x ^ bq.x);
-                        xh = ((uint64_t)(a.w ^ bq.w) << 32) | (a.z ^ bq.z);
-                    } else {
-                        for (uint32_t t = 0; it_i + o + t < n; t++) {
-                            const uint64_t x = (uint64_t)(s[it_i + o + t] ^ s[it_c + o + t]);
-                            if (t < 8) xl |= x << (8 * t); else xh |= x << (8 * (t - 8));
-                        }
-                    }
+#ifdef CAND_STATS
+                n_iter++;
+#endif
+                const int32_t t = it_t + 16 * (int32_t)sub;
+                uint32_t r = 0xFFFFu;   // first byte found to differ (none: beyond every limit)
+                if (busy && t < (int32_t)it_lim) {
+                    const uint4 cb = it_p[sub];
+                    const uint32_t wo = it_w + (uint32_t)t, q = wo >> 2, sh = (wo & 3) * 8;
+                    const uint32_t d0 = s_win[q], d1 = s_win[q + 1], d2 = s_win[q + 2], d3 = s_win[q + 3], d4 = s_win[q + 4];
+                    uint32_t x0 = cb.x ^ __builtin_amdgcn_alignbit(d1, d0, sh);
+                    const uint32_t x1 = cb.y ^ __builtin_amdgcn_alignbit(d2, d1, sh);
+                    const uint32_t x2 = cb.z ^ __builtin_amdgcn_alignbit(d3, d2, sh);
+                    const uint32_t x3 = cb.w ^ __builtin_amdgcn_alignbit(d4, d3, sh);
+                    if (t < 0) x0 &= 0xFFFFFFFFu << (8 * (uint32_t)(-t));   // (bytes before the head's position)
+                    r = (uint32_t)t + first_set_byte(x0, x1, x2, x3);
                 }
-                const bool bad = (xl | xh) != 0;
-                const uint32_t r = o + (xl ? (uint32_t)(__builtin_ctzll(xl) >> 3) : 8 + (uint32_t)(__builtin_ctzll(xh | (1ull << 63)) >> 3));
-                const uint64_t badm = __ballot(bad) & gmask;
-                const uint32_t rr = __shfl(r, badm ? __builtin_ctzll(badm) : lane);
+                r = group8_min(r);
                 if (busy) {
-                    uint32_t res = 0;
-                    bool done = false;
-                    if (badm) { res = rr < it_lim ? rr : it_lim; done = true; }
-                    else {
-                        it_off += 16 * CAND_GL;
-                        if (it_off >= it_lim) { res = it_lim; done = true; }
-                    }
-                    if (done) {
-                        if (sub == 0) q_res[wv][it_id] = (uint16_t)res;
+                    it_t += 16 * CAND_GL;
+                    it_p += CAND_GL;
+                    if (r < 0xFFFFu || it_t >= (int32_t)it_lim) {   // (no difference found: 0xFFFF, or 0x1FFFFFFF and more)
+                        if (sub == 0) q_res[wv][it_id] = (uint16_t)(r < it_lim ? r : it_lim);
                         busy = false;
                     }
                 }
             }
+#ifdef CAND_STATS
+            CAND_STAT(5, n_iter);
+            CAND_STAT(16 + (n_iter <= 1 ? 1 : n_iter == 2 ? 2 : n_iter <= 4 ? 3 : n_iter <= 8 ? 4 : n_iter <= 16 ? 5 : 6), 1);
+#endif
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -494,6 +581,7 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
                 if (more[k]) ln[k] = dep[k] ? q_res[wv][lead[k]] + (lead[k] & 63) - (uint32_t)lane : q_res[wv][k * 64 + lane];
         }
     }
+    CAND_ABL_EXIT(4, cc[0] ^ cc[1] ^ cc[2] ^ cc[3] ^ ln[0] ^ (ln[1] << 4) ^ (ln[2] << 8) ^ (ln[3] << 12) ^ ((uint32_t)fol[0] << 20) ^ ((uint32_t)fol[1] << 21) ^ ((uint32_t)fol[2] << 22) ^ ((uint32_t)fol[3] << 23))
     uint32_t best_len = 0, best_idx = 0;
     bool capped = false;
 #pragma unroll
@@ -522,6 +610,7 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
             if (len > best_len) { best_len = len; best_idx = c; }  // ties keep the newest (:226)
         }
     }
+    CAND_ABL_EXIT(5, best_len ^ (best_idx << 10) ^ ((uint32_t)capped << 31))
     // backward extension: the same run structure, LCS(i + t, c + t) = LCS(i, c) + t (up to the cap)
     uint32_t r = 0;
     {
@@ -559,6 +648,18 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
             rec[tl.pos_base + i] = r;
         }
     }
+#ifdef CAND_PAD_VALU
+    // (sensitivity experiment, scripts/cand_pad.sh: CAND_PAD_VALU extra vector instructions per wave -- 1xx: full-rate v_add_u32, 2xx: half-rate v_alignbit_b32)
+    {
+        uint32_t pz = r;
+#pragma unroll
+        for (int u = 0; u < CAND_PAD_VALU % 1000; u++) {
+            if (CAND_PAD_VALU / 1000 == 1) asm volatile("v_add_u32 %0, %0, %1" : "+v"(pz) : "v"(best_len));
+            else asm volatile("v_alignbit_b32 %0, %0, %1, %1" : "+v"(pz) : "v"(best_len));
+        }
+        asm volatile("" ::"v"(pz));
+    }
+#endif
     // has-match bitmap: tile starts are multiples of 64, so a wave covers exactly one word
     const uint64_t bits = __ballot(valid && r != 0);
     // (words past the stream's last position belong to the next stream: never touch them)
@@ -586,6 +687,15 @@ void launch_enc_cand(const uint8_t *src, const EncStream *streams, const EncTile
                      uint64_t *bitmap, hipStream_t st) {
     if (!n_tiles) return;
     hipLaunchKernelGGL(enc_cand_kernel, dim3(((n_tiles + 63) / 64) * 64 * CAND_BPT), dim3(256), 0, st, src, streams, tiles, n_tiles, prev, rec, bitmap);
+#ifdef CAND_STATS
+    {
+        unsigned long long h[32], z[32] = {};
+        (void)hipStreamSynchronize(st);
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_cand_stats), sizeof h) == hipSuccess && hipMemcpyToSymbol(HIP_SYMBOL(g_cand_stats), z, sizeof z) == hipSuccess)
+            fprintf(stderr, "cand_stats tiles=%u waves=%llu with_more=%llu more=%llu dep=%llu heads=%llu iters=%llu busy_groups=%llu | heads/wave 0,1,2,3-4,5-8,9-16,17-32,33+: %llu %llu %llu %llu %llu %llu %llu %llu | iters/wave 1,2,3-4,5-8,9-16,17+: %llu %llu %llu %llu %llu %llu\n",
+                    n_tiles, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15], h[17], h[18], h[19], h[20], h[21], h[22]);
+    }
+#endif
 }
 
 }  // namespace lzmi

@@ -59,8 +59,14 @@ struct StreamSpare {
     uint8_t *p[2] = {nullptr, nullptr};
     size_t cap[2] = {0, 0};
     std::vector<uint8_t> v[2];
+    bool keep = true;   // LZFSE_MI_OPT_STREAM_SPARE
 };
 StreamSpare &ctx_spare(lzfse_mi_ctx *c);
+// A stream object names its context through ONE pointer, registered here: lzfse_mi_destroy of the context sets the pointers of
+// the stream objects still alive to null, so that a stream object destroyed (or fed) AFTER its context neither hands buffers
+// to freed memory nor runs a call on it (include/lzfse_mi.h: either order of destruction is allowed).
+void ctx_attach(lzfse_mi_ctx *c, lzfse_mi_ctx **ref);
+void ctx_detach(lzfse_mi_ctx *c, lzfse_mi_ctx **ref);
 void ctx_set_window(lzfse_mi_ctx *c, EncWindow *w);
 int ctx_diag_chain(lzfse_mi_ctx *c);  // LZFSE_MI_OPT_DIAG_CHAIN: 1 = every chain tile through the ballot kernel
 

@@ -33,10 +33,13 @@ struct lzfse_mi_dstream {
     uint8_t *tmp_dst = nullptr;    // malloc'd, never zero-filled: a damaged header may promise gigabytes that are never written
     size_t tmp_dst_cap = 0;
     ~lzfse_mi_dstream() {
-        // (what this object's windows grew stays with the context for the next stream object)
+        // (what this object's windows grew stays with the context for the next stream object -- if the context is still there
+        // and keeps such buffers: ctx is null once lzfse_mi_destroy has run, LZFSE_MI_OPT_STREAM_SPARE)
+        if (!ctx) { std::free(tmp_dst); return; }
+        ctx_detach(ctx, &ctx);
         StreamSpare &sp = ctx_spare(ctx);
-        if (tmp_dst_cap > sp.cap[0]) { std::free(sp.p[0]); sp.p[0] = tmp_dst; sp.cap[0] = tmp_dst_cap; } else std::free(tmp_dst);
-        if (in.capacity() > sp.v[0].capacity()) { in.clear(); sp.v[0].swap(in); }
+        if (sp.keep && tmp_dst_cap > sp.cap[0]) { std::free(sp.p[0]); sp.p[0] = tmp_dst; sp.cap[0] = tmp_dst_cap; } else std::free(tmp_dst);
+        if (sp.keep && in.capacity() > sp.v[0].capacity()) { in.clear(); sp.v[0].swap(in); }
     }
     uint64_t total_in = 0, total_out = 0;
     int status = 0;                // sticky
@@ -204,6 +207,7 @@ LZFSE_MI_API int lzfse_mi_dstream_create(lzfse_mi_ctx *ctx, size_t window, lzfse
     lzfse_mi_dstream *s = new (std::nothrow) lzfse_mi_dstream;
     if (!s) return LZFSE_MI_IO;
     s->ctx = ctx;
+    ctx_attach(ctx, &s->ctx);
     s->window = window ? window : (size_t)LZFSE_MI_STREAM_WINDOW;
     {
         StreamSpare &sp = ctx_spare(ctx);
@@ -227,6 +231,7 @@ LZFSE_MI_API int lzfse_mi_dstream_totals(const lzfse_mi_dstream *s, uint64_t *by
 LZFSE_MI_API int lzfse_mi_dstream_feed(lzfse_mi_dstream *s, const uint8_t *src, size_t n, int finish, lzfse_mi_write_fn write, void *user) {
     if (!s || (!src && n)) return LZFSE_MI_BAD_ARGUMENT;
     if (s->status) return s->status;
+    if (!s->ctx) return s->status = LZFSE_MI_BAD_ARGUMENT;   // its context has been destroyed
     if (n) {
         // (consumed input is dropped now and then; MAX_D_VALUE + 8 bytes of it stay in front of the rest: the next window's
         // history block is written there, decode_span)
@@ -297,9 +302,11 @@ struct lzfse_mi_estream {
     int status = 0;               // sticky
     bool finished = false;
     ~lzfse_mi_estream() {
+        if (!ctx) { std::free(out); return; }   // (the context went first)
+        ctx_detach(ctx, &ctx);
         StreamSpare &sp = ctx_spare(ctx);
-        if (out_cap > sp.cap[1]) { std::free(sp.p[1]); sp.p[1] = out; sp.cap[1] = out_cap; } else std::free(out);
-        if (buf.capacity() > sp.v[1].capacity()) { buf.clear(); sp.v[1].swap(buf); }
+        if (sp.keep && out_cap > sp.cap[1]) { std::free(sp.p[1]); sp.p[1] = out; sp.cap[1] = out_cap; } else std::free(out);
+        if (sp.keep && buf.capacity() > sp.v[1].capacity()) { buf.clear(); sp.v[1].swap(buf); }
     }
 };
 
@@ -381,6 +388,7 @@ int lzfse_mi_estream_create(lzfse_mi_ctx *ctx, size_t window, lzfse_mi_estream *
     lzfse_mi_estream *s = new (std::nothrow) lzfse_mi_estream();
     if (!s) return LZFSE_MI_IO;
     s->ctx = ctx;
+    ctx_attach(ctx, &s->ctx);
     s->window = window ? window : (size_t)LZFSE_MI_STREAM_WINDOW;
     if (s->window < E_MIN_WINDOW) s->window = E_MIN_WINDOW;
     if (s->window > ((size_t)1 << 30)) s->window = (size_t)1 << 30;
@@ -402,6 +410,7 @@ void lzfse_mi_estream_destroy(lzfse_mi_estream *s) { delete s; }
 int lzfse_mi_estream_feed(lzfse_mi_estream *s, const uint8_t *src, size_t n, lzfse_mi_write_fn write, void *user) {
     if (!s || (!src && n) || !write || s->finished) return LZFSE_MI_BAD_ARGUMENT;
     if (s->status) return s->status;
+    if (!s->ctx) return s->status = LZFSE_MI_BAD_ARGUMENT;   // its context has been destroyed
     while (n) {
         const size_t room = s->next_at > s->buf.size() ? s->next_at - s->buf.size() : 0;
         const size_t take = n < room ? n : room;
@@ -423,6 +432,7 @@ int lzfse_mi_estream_finish(lzfse_mi_estream *s, lzfse_mi_write_fn write, void *
     if (!s || !write || s->finished) return LZFSE_MI_BAD_ARGUMENT;
     s->finished = true;
     if (s->status) return s->status;
+    if (!s->ctx) return s->status = LZFSE_MI_BAD_ARGUMENT;   // its context has been destroyed
     const int st = es_window(s, true, write, user);
     if (bytes_in) *bytes_in = s->total_in;
     if (bytes_out) *bytes_out = st ? 0 : s->total_out;

@@ -56,6 +56,12 @@ int main(int argc, char **argv) {
     run<4, 0, 16>("4 B  runs of 16 lanes", buf, n16, out);
     run<16, 0, 4>("16 B runs of 4 lanes", buf, n16, out);
     run<16, 0, 16>("16 B runs of 16 lanes", buf, n16, out);
+    run<16, 0, 8>("16 B runs of 8 lanes, aligned", buf, n16, out);      // (round 4: what enc_cand's phase 3 issues -- 8-lane groups on 128 contiguous bytes)
+    run<16, 4, 8>("16 B runs of 8 lanes, dword-aligned", buf, n16, out);
+    run<16, 1, 8>("16 B runs of 8 lanes, byte-misaligned", buf, n16, out);
+    run<8, 0, 8>("8 B  runs of 8 lanes, aligned", buf, n16, out);
+    run<8, 1, 8>("8 B  runs of 8 lanes, byte-misaligned", buf, n16, out);
+    run<4, 0, 8>("4 B  runs of 8 lanes", buf, n16, out);
     run<4, 0, 64>("4 B  coalesced wave", buf, n16, out);
     run<16, 0, 64>("16 B coalesced wave", buf, n16, out);
     return 0;

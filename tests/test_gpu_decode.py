@@ -35,6 +35,61 @@ def test_decode_fixtures_batch(ctx, oracle, golden_dir):
         assert o.tobytes() == oracle.decode(s), f
 
 
+def gpu_last_lmds(dctx):
+    """LMD records dec_fse_kernel left for the LZ stage in the context's last decode pass (diagnostic build's stage hook)."""
+    import ctypes as C
+    from lzfse_rust_amd import _native
+    L = _native.lib(diag=True)
+    f = L.lzfse_mi_debug_last_lmds
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    n = C.c_size_t(0)
+    assert f(dctx._h, None, 0, C.byref(n)) in (0, 6)   # (6: BUFFER_OVERFLOW = "tell me the size")
+    rec = np.zeros((n.value, 2), dtype=np.uint32)
+    assert f(dctx._h, rec.ctypes.data, n.value, C.byref(n)) == 0
+    return rec
+
+
+def _parse_lmd_text(text):
+    """src/ring/ring_lz_writer.rs:88-155: one 'L:n' line per LMD, followed by 'M:n' and 'D:n' when M != 0."""
+    toks = text.split()
+    kinds = np.array([ord(t[0]) for t in toks], dtype=np.uint8)
+    vals = np.array([int(t[2:]) for t in toks], dtype=np.int64)
+    out, i = [], 0
+    while i < len(toks):
+        assert kinds[i] == ord("L")
+        if i + 2 < len(toks) and kinds[i + 1] == ord("M"):
+            assert kinds[i + 2] == ord("D")
+            out.append((vals[i], vals[i + 1], vals[i + 2]))
+            i += 3
+        else:
+            out.append((vals[i], 0, -1))
+            i += 1
+    return np.array(out, dtype=np.int64).reshape(-1, 3)
+
+
+def test_fse_stage_matches_reference_lmd_streams(diag_ctx, golden_dir):
+    """dec_fse_kernel's LMD array against the reference's own decoded-LMD streams
+    (data/snappy/lmdy_output/*.lmd, committed as tests/golden/lmd/*.lmd.gz): L always, M and D when M != 0, D = 0 already
+    replaced by the previous distance -- the same comparison tests/test_oracle.py makes for the oracle, at the stage."""
+    import gzip
+    fs = sorted(glob.glob(os.path.join(golden_dir, "lmd", "*.lmd.gz")))
+    assert len(fs) == 12
+    for f in fs:
+        name = os.path.basename(f)[:-7]
+        exp = _parse_lmd_text(gzip.open(f, "rt").read())
+        src = open(os.path.join(golden_dir, "snappy", name + ".lzfse"), "rb").read()
+        outs, st = diag_ctx.decode_batch([src])
+        assert st[0] == 0, name
+        rec = gpu_last_lmds(diag_ctx).astype(np.int64)
+        assert rec.shape[0] == exp.shape[0], (name, rec.shape, exp.shape)
+        l, m, d = rec[:, 0] & 0xFFFF, rec[:, 0] >> 16, rec[:, 1]
+        assert np.array_equal(l, exp[:, 0]), name
+        assert np.array_equal(m, exp[:, 1]), name
+        has_m = exp[:, 1] != 0
+        assert np.array_equal(d[has_m], exp[has_m, 2]), name
+
+
 def test_decode_single_api(ctx, golden_dir):
     import lzfse_rust_amd as m
     dec = m.LzfseDecoder(context=ctx)
