@@ -288,6 +288,15 @@ __device__ __forceinline__ uint32_t group8_min(uint32_t v) {
     return v;
 }
 
+__device__ __forceinline__ uint32_t group4_min(uint32_t v) {   // the same over the aligned group of 4 lanes
+    asm("s_nop 1\n"
+        "v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+        : "+v"(v));
+    return v;
+}
+
 // rec[i] = rec_make(dist, fwd_len, bwd) (enc_common.h); 0: no match at i
 //
 // One lane per position, hops in lock-step. A lane compares at most CAND_C1 bytes on its own. Lanes
@@ -295,9 +304,9 @@ __device__ __forceinline__ uint32_t group8_min(uint32_t v) {
 // (the inside of one long match): only the head of a run is extended, by the whole wave, and the
 // followers derive LCP(i + t, c + t) = LCP(i, c) - t. Repetitive data costs O(1) per position.
 constexpr uint32_t CAND_C1 = 12;   // a lane compares 12 bytes on its own: what one dword-aligned 16-byte load holds of a candidate
-constexpr int CAND_GL = 8;  // lanes per group of the long-match work list
+constexpr int CAND_GL = 4;  // lanes per group of the long-match work list (each takes 32 bytes of a step: 16 heads at a time, 128 bytes per head)
 constexpr uint32_t CAND_BPT = (TILE_POS + 255) / 256;  // workgroups per tile
-constexpr uint32_t CAND_WIN_DW = (32 + 256 + FCAP + 64 + 20 + 3) / 4 + 1;   // dwords of the workgroup's source window
+constexpr uint32_t CAND_WIN_DW = (32 + 256 + FCAP + 64 + 36 + 3) / 4 + 1;   // dwords of the workgroup's source window
 // (scripts/cand_phases.sh: instruction counts per phase -- the kernel is cut short after phase CAND_ABL with what it has computed kept
 // alive by an empty asm, and records "no match" everywhere: a valid all-literal parse; never defined in a library build)
 #ifdef CAND_STATS
@@ -328,7 +337,7 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
     // (LDS is kept small on purpose: this kernel runs next to another lane's chain kernel, whose tiles need 64 KiB each)
     __shared__ uint16_t q_id[4][256], q_res[4][256];   // per-wave work list of phase 3: slot * 64 + lane of a head; its length
     __shared__ uint32_t q_dist[4][256], q_tab[4][64];  // distance of a head (by slot * 64 + lane); first head per distance hash
-    __shared__ uint32_t s_win[CAND_WIN_DW];            // source bytes [i_wg - 32, i_wg + 256 + FCAP + 64 + 16 ..) around the workgroup's 256 positions
+    __shared__ uint32_t s_win[CAND_WIN_DW];            // source bytes [i_wg - 32, i_wg + 256 + FCAP + 64 + 36 ..) around the workgroup's 256 positions
     const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     // g: the g-th tile this XCD works on. An XCD takes 8 CONSECUTIVE tiles of every 64: a tile gathers from the up to
     // four tiles before it (the 262 139-byte window), and those are then the tiles the same L2 has just worked on.
@@ -347,7 +356,7 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
     const uint32_t max_total = valid ? n - i : 0;
     const uint32_t cap_total = max_total < FCAP ? max_total : FCAP;
     const uint32_t c1 = cap_total < CAND_C1 ? cap_total : CAND_C1;
-    // ---- source window of the workgroup: bytes [i_wg - 32, i_wg + 256 + FCAP + 64 + 20) of the stream (i_wg = position of
+    // ---- source window of the workgroup: bytes [i_wg - 32, i_wg + 256 + FCAP + 64 + 36) of the stream (i_wg = position of
     // thread 0; zeros before the stream's first and behind its last byte) go to LDS with coalesced loads. Every lane's OWN
     // side of all byte compares is read from there -- forward up to FCAP + 64 (phase 3), backward up to 32 -- so that the
     // texture addresser, which is what bounds this kernel (TA_BUSY 77 %, profiles/r04_cand_phases_tcp.txt), only sees the
@@ -442,7 +451,7 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
     }
     CAND_ABL_EXIT(3, cc[0] ^ cc[1] ^ cc[2] ^ cc[3] ^ ln[0] ^ (ln[1] << 4) ^ (ln[2] << 8) ^ (ln[3] << 12) ^ ((uint32_t)fol[0] << 20) ^ ((uint32_t)fol[1] << 21) ^ ((uint32_t)fol[2] << 22) ^ ((uint32_t)fol[3] << 23))
     // ---- phase 3: heads still equal after CAND_C1 bytes go to a per-wave work list and are extended by groups of
-    // CAND_GL lanes, 16 bytes per lane and step, 8 heads at a time (up to FCAP + 64, so that 63 followers stay exact up to
+    // CAND_GL lanes, 32 bytes per lane and step, 16 heads at a time (up to FCAP + 64, so that 63 followers stay exact up to
     // FCAP); a group that has finished its head takes the next one from the list while the others go on with theirs (on the
     // Snappy files a wave has 13 such heads on average, 15 % of them longer than the 128 bytes of a step, 9 % longer than the
     // cap: profiles/r04_cand_stats.txt); then the followers take head - t ----
@@ -511,10 +520,10 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
         if (total) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            // A step of a group: 128 bytes of its head. The CANDIDATE's bytes come as 16-byte ALIGNED chunks, one per lane
-            // (8 lanes on 128 contiguous bytes cost the texture addresser 0.58 clk per lane when they are aligned, 1.06 when
-            // they are not: profiles/r04_gather_bench.txt; round 3 loaded both sides byte-misaligned, 43 % of the kernel's L1
-            // accesses); the position's own bytes are read from the workgroup's window in LDS at whatever byte offset that
+            // A step of a group: 128 bytes of its head. The CANDIDATE's bytes come as 16-byte ALIGNED chunks, two per lane
+            // (lanes on 128 contiguous bytes cost the texture addresser 0.58 clk per lane and chunk when they are aligned, 1.06
+            // when they are not: profiles/r04_gather_bench.txt; round 3 loaded both sides byte-misaligned, 43 % of the kernel's
+            // L1 accesses); the position's own bytes are read from the workgroup's window in LDS at whatever byte offset that
             // makes. The first chunk may begin up to 3 bytes before the head's position (those bytes are masked) or inside
             // the CAND_C1 bytes phase 2 has compared (equal again); behind the end of the stream the window holds zeros and
             // whatever differs there lies beyond the limit.
@@ -547,23 +556,32 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
 #ifdef CAND_STATS
                 n_iter++;
 #endif
-                const int32_t t = it_t + 16 * (int32_t)sub;
+                const int32_t t = it_t + 32 * (int32_t)sub;
                 uint32_t r = 0xFFFFu;   // first byte found to differ (none: beyond every limit)
                 if (busy && t < (int32_t)it_lim) {
-                    const uint4 cb = it_p[sub];
+                    const uint4 *cp = it_p + 2 * sub;
+                    const bool two = t + 16 < (int32_t)it_lim;   // (a chunk that begins at or behind the limit may lie behind the buffer: not touched)
+                    const uint4 cb = cp[0];
+                    uint4 cb2 = make_uint4(0, 0, 0, 0);
+                    if (two) cb2 = cp[1];
                     const uint32_t wo = it_w + (uint32_t)t, q = wo >> 2, sh = (wo & 3) * 8;
                     const uint32_t d0 = s_win[q], d1 = s_win[q + 1], d2 = s_win[q + 2], d3 = s_win[q + 3], d4 = s_win[q + 4];
+                    const uint32_t d5 = s_win[q + 5], d6 = s_win[q + 6], d7 = s_win[q + 7], d8 = s_win[q + 8];
                     uint32_t x0 = cb.x ^ __builtin_amdgcn_alignbit(d1, d0, sh);
                     const uint32_t x1 = cb.y ^ __builtin_amdgcn_alignbit(d2, d1, sh);
                     const uint32_t x2 = cb.z ^ __builtin_amdgcn_alignbit(d3, d2, sh);
                     const uint32_t x3 = cb.w ^ __builtin_amdgcn_alignbit(d4, d3, sh);
                     if (t < 0) x0 &= 0xFFFFFFFFu << (8 * (uint32_t)(-t));   // (bytes before the head's position)
-                    r = (uint32_t)t + first_set_byte(x0, x1, x2, x3);
+                    const uint32_t m1 = first_set_byte(x0, x1, x2, x3);
+                    const uint32_t y0 = cb2.x ^ __builtin_amdgcn_alignbit(d5, d4, sh), y1 = cb2.y ^ __builtin_amdgcn_alignbit(d6, d5, sh);
+                    const uint32_t y2 = cb2.z ^ __builtin_amdgcn_alignbit(d7, d6, sh), y3 = cb2.w ^ __builtin_amdgcn_alignbit(d8, d7, sh);
+                    const uint32_t m2 = two ? 16u + first_set_byte(y0, y1, y2, y3) : 0x1FFFFFFFu;
+                    r = (uint32_t)t + (m1 < m2 ? m1 : m2);
                 }
-                r = group8_min(r);
+                r = group4_min(r);
                 if (busy) {
-                    it_t += 16 * CAND_GL;
-                    it_p += CAND_GL;
+                    it_t += 32 * CAND_GL;
+                    it_p += 2 * CAND_GL;
                     if (r < 0xFFFFu || it_t >= (int32_t)it_lim) {   // (no difference found: 0xFFFF, or 0x1FFFFFFF and more)
                         if (sub == 0) q_res[wv][it_id] = (uint16_t)(r < it_lim ? r : it_lim);
                         busy = false;
