@@ -59,12 +59,36 @@ def main(argv=None):
             self.f.write(b)
             self.n += len(b)
 
+    class _Chained:
+        """the bytes already taken from an input, then the input"""
+
+        def __init__(self, head, f):
+            self.head, self.f = head, f
+
+        def read(self, n=-1):
+            if not self.head:
+                return self.f.read(n)
+            if n is None or n < 0:
+                out, self.head = self.head + self.f.read(), b""
+                return out
+            out, self.head = self.head[:n], self.head[n:]
+            return out   # (a short read is allowed; the next call goes on)
+
     fin = open(a.input, "rb") if a.input else sys.stdin.buffer
     t0 = time.perf_counter()
     n_in = n_out = 0
     try:
         ctxs = [lz.Context(int(d)) for d in a.devices.split(",")]
-        head = fin.peek(4)[:4] if mode == "decode" and hasattr(fin, "peek") else b""
+        head = b""
+        if mode == "decode":
+            # container or plain stream? Exactly 4 bytes are taken (a pipe may hand over fewer per read, and not every input
+            # can peek) and put back in front of the rest
+            while len(head) < 4:
+                more = fin.read(4 - len(head))
+                if not more:
+                    break
+                head += more
+            fin = _Chained(head, fin)
         streamed = (mode == "encode" and a.plain) or (mode == "decode" and head != b"LZMC")
         if streamed:
             # one LZFSE stream, reader -> writer (lzfoo/main.rs:86-107)

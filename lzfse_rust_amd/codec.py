@@ -40,7 +40,7 @@ def _check(st):
 class Context:
     """One HIP device + stream + scratch (lzfse_mi_ctx)."""
 
-    OPTIONS = {"encode_lanes": 1, "decode_lanes": 2, "stagger": 3, "decode_pipe": 4, "diag_lz_path": 100, "diag_lz_tile": 101, "diag_stats": 102, "diag_chain": 103, "diag_walk": 104, "diag_pipe_scatter": 105}
+    OPTIONS = {"encode_lanes": 1, "decode_lanes": 2, "stagger": 3, "decode_pipe": 4, "stream_spare": 5, "diag_lz_path": 100, "diag_lz_tile": 101, "diag_stats": 102, "diag_chain": 103, "diag_walk": 104, "diag_pipe_scatter": 105}
 
     def __init__(self, device=0, diag=False):
         self._lib = _native.lib(diag=diag)
@@ -327,12 +327,15 @@ class LzfseWriterBytes(LzfseWriter):
 
 class LzfseRingDecoder:
     """src/decode/ring_decoder.rs:17-68: decode(reader, writer) -> (bytes read, bytes written). `reader.read(n)` returns
-    b"" at the end of the input, `writer.write(b)` takes the output in pieces; `window` = raw bytes per device call."""
+    b"" at the end of the input, `writer.write(b)` takes the output in pieces; `window` = raw bytes per device call.
+    `zero_copy=True` hands the writer a memoryview of the library's window buffer instead of bytes: one copy less, but the
+    piece is only valid DURING the write call (file objects and hashers are fine; a sink that keeps the object is not)."""
 
-    def __init__(self, device=0, context=None, window=0, read_size=1 << 20):
+    def __init__(self, device=0, context=None, window=0, read_size=1 << 20, zero_copy=False):
         self._ctx = context or Context(device)
         self._window = window
         self._read_size = read_size
+        self._zero_copy = zero_copy
 
     def decode(self, reader, writer):
         lib = self._ctx._lib
@@ -342,8 +345,10 @@ class LzfseRingDecoder:
 
         def _write(_user, p, n):
             try:
-                # (a view of the library's buffer, valid during the call: the writer takes its copy, no second one is made here)
-                writer.write(memoryview((C.c_uint8 * n).from_address(C.addressof(p.contents))) if n else b"")
+                # copy=False: a view of the library's buffer, valid during the call only (a writer that keeps the object it is
+                # handed -- list.append, a queue -- must not use it)
+                view = memoryview((C.c_uint8 * n).from_address(C.addressof(p.contents))) if n else b""
+                writer.write(view if self._zero_copy else bytes(view))
                 return 0
             except Exception as e:   # the sink's error travels back through the C layer as LZFSE_MI_IO
                 failure.append(e)

@@ -535,15 +535,16 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
     if (c->opt_pipe != 1 && !c->pipe_broken && !c->pipe_tested) {
         // before the pipelined LZ kernel is used for the first time on this context: its hand-over, on this device
         c->pipe_tested = true;
+        uint32_t res[2] = {1, 0};   // (a self-test that could not run -- no memory, a failed copy -- is a refusal like one that failed)
         if (c->d_lzp.ensure((1088 + 2) * 4)) {
-            uint32_t *tb = (uint32_t *)c->d_lzp.p, res[2] = {1, 0};
+            uint32_t *tb = (uint32_t *)c->d_lzp.p;
             if (hipMemsetAsync(tb, 0, (1088 + 2) * 4, c->stream) == hipSuccess) {
                 launch_dec_lzp_selftest(tb, tb + 1088, c->stream);
                 if (hipMemcpyAsync(res, tb + 1088, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) res[0] = 1;
             }
-            const bool same_xcd = (res[1] & 0xFF) == ((res[1] >> 8) & 0xFF);
-            if (res[0] != 0 || (res[1] & 0x10000u) || !same_xcd) { c->pipe_broken = true; c->pipe_refusals++; }
         }
+        const bool same_xcd = (res[1] & 0xFF) == ((res[1] >> 8) & 0xFF);
+        if (res[0] != 0 || (res[1] & 0x10000u) || !same_xcd) { c->pipe_broken = true; c->pipe_refusals++; }
     }
     if (c->opt_pipe != 1 && !c->pipe_broken) {
         const bool forced = c->opt_pipe > 1;

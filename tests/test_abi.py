@@ -122,7 +122,8 @@ def test_product_library_reads_no_environment_and_has_no_debug_hook():
     assert "getenv" not in und
     prod = subprocess.check_output([nm, "-D", "--defined-only", build.LIB_PATH], text=True)
     diag = subprocess.check_output([nm, "-D", "--defined-only", build.DIAG_LIB_PATH], text=True)
-    assert "lzfse_mi_debug_candidates" not in prod and "lzfse_mi_debug_candidates" in diag
+    for hook in ("lzfse_mi_debug_candidates", "lzfse_mi_debug_last_lmds"):
+        assert hook not in prod and hook in diag, hook
     for n in _declared_functions(os.path.join(ROOT, "include", "lzfse_mi.h")):
         assert n in prod and n in diag, n
 

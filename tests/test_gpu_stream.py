@@ -279,3 +279,63 @@ def test_fuzz_read(ctx, oracle):
                     break
             rdr.into_inner()
             assert bytes(got) == data, (mult, seed)
+
+
+def test_stream_objects_may_outlive_their_context(oracle, snappy_raw):
+    """include/lzfse_mi.h: a stream object and its context may be destroyed in either order. Destroying the context first
+    detaches the stream objects still alive: their calls fail with BAD_ARGUMENT, their destroy frees only their own buffers
+    (round 3 handed them to the freed context)."""
+    import lzfse_rust_amd as m
+    from lzfse_rust_amd import _native
+    raw = snappy_raw["alice29.txt"]
+    enc = oracle.encode(raw)
+    c = m.Context(0)
+    lib = c._lib
+    d, e = C.c_void_p(), C.c_void_p()
+    assert lib.lzfse_mi_dstream_create(c._h, 1 << 20, C.byref(d)) == 0
+    assert lib.lzfse_mi_estream_create(c._h, 1 << 20, C.byref(e)) == 0
+    got = []
+    cb = _native.WRITE_FN(lambda _u, p, n: got.append(bytes((C.c_uint8 * n).from_address(C.addressof(p.contents)))) and 0)
+    a = np.frombuffer(enc, dtype=np.uint8)
+    half = a.size // 2
+    assert lib.lzfse_mi_dstream_feed(d, a.ctypes.data, half, 0, cb, None) == 0     # (grows the decoder's window buffers)
+    r = np.frombuffer(raw, dtype=np.uint8)
+    assert lib.lzfse_mi_estream_feed(e, r.ctypes.data, r.size, cb, None) == 0
+    c.close()                                                                      # the context goes first
+    assert lib.lzfse_mi_dstream_feed(d, a[half:].ctypes.data, a.size - half, 1, cb, None) == 11   # LZFSE_MI_BAD_ARGUMENT
+    u, v = C.c_uint64(0), C.c_uint64(0)
+    assert lib.lzfse_mi_estream_finish(e, cb, None, C.byref(u), C.byref(v)) == 11
+    lib.lzfse_mi_dstream_destroy(d)
+    lib.lzfse_mi_estream_destroy(e)
+    # and the usual order still hands the buffers on: a second object on a live context works as the first did
+    c2 = m.Context(0)
+    for _ in range(2):
+        out = io.BytesIO()
+        m.LzfseRingDecoder(context=c2, window=1 << 20).decode(PieceReader(enc, [70000]), out)
+        assert out.getvalue() == raw
+    c2.set_option("stream_spare", 0)   # frees what the finished objects left, keeps nothing from now on
+    out = io.BytesIO()
+    m.LzfseRingDecoder(context=c2, window=1 << 20).decode(PieceReader(enc, [70000]), out)
+    assert out.getvalue() == raw
+    c2.close()
+
+
+def test_writer_pieces_are_copies_unless_asked(ctx, oracle, snappy_raw):
+    """LzfseRingDecoder hands the writer bytes it may keep; zero_copy=True hands views of the window buffer (valid during the call)."""
+    import lzfse_rust_amd as m
+    raw = snappy_raw["html"]
+    enc = oracle.encode(raw)
+
+    class Keep:
+        def __init__(self):
+            self.pieces = []
+
+        def write(self, b):
+            self.pieces.append(b)
+
+    k = Keep()
+    m.LzfseRingDecoder(context=ctx, window=1 << 16).decode(PieceReader(enc, [9000]), k)
+    assert all(isinstance(p, bytes) for p in k.pieces) and b"".join(k.pieces) == raw
+    out = io.BytesIO()
+    m.LzfseRingDecoder(context=ctx, window=1 << 16, zero_copy=True).decode(PieceReader(enc, [9000]), out)
+    assert out.getvalue() == raw
