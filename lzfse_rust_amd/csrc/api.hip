@@ -519,7 +519,9 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
         nb += h_walk[i].n_blocks; nl += h_walk[i].n_lmds; nu += h_walk[i].n_lits;
         // large streams: LZ stage by pointer jumping (origin indices are 31-bit over the whole batch, the top bit marks final bytes)
         const bool big = jump_mode < 0 ? h_walk[i].raw_total >= (2ull << 20) : jump_mode > 0;
-        if (big && h_walk[i].n_vxn == 0 && nj + h_walk[i].raw_total + 8 < 0x7FFFFFF0ull && h_walk[i].raw_total > 0 &&
+        // (an origin is 31 bits + the "final" bit, and all ones is the filler of undefined entries: positions up to 0x7FFFFFFE, so
+        // that a stream of 0x7FFF_FFFF bytes -- the largest the slice calls take -- still goes this way when it is alone)
+        if (big && h_walk[i].n_vxn == 0 && nj + h_walk[i].raw_total <= 0x7FFFFFFFull && h_walk[i].raw_total > 0 &&
             h_walk[i].raw_total <= dst_cap[i]) {
             p.jump = 1; p.jbase = nj;
             nj += (h_walk[i].raw_total + 3) & ~3ull;

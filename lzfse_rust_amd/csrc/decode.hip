@@ -2005,7 +2005,13 @@ __global__ __launch_bounds__(JUMP_THREADS) void dec_jump_init_kernel(
         const uint8_t *ls = blit + run_lit + ex_l;
         const bool l_long = l > 32, m_long = m > 32 && !bad_d;
         if (!l_long) for (uint32_t k = 0; k < l; k++) { dst[o + k] = ls[k]; org[o + k] = (jb + o + k) | JUMP_FINAL; }
-        if (!m_long && !bad_d) for (uint32_t k = 0; k < m; k++) org[p + k] = jb + p + k - dd;
+        // A match that overlaps itself (dd < m) repeats its first dd bytes: byte k is byte k mod dd of the dd bytes IN FRONT of the
+        // match (lz/object.rs:60-74), so every byte of it points there directly instead of dd bytes back -- a run of zeros is
+        // then one hop per match, not one per byte
+        if (!m_long && !bad_d) {
+            uint32_t rr = 0;
+            for (uint32_t k = 0; k < m; k++) { org[p + k] = jb + p - dd + rr; if (++rr == dd) rr = 0; }
+        }
         // long runs: the whole wave works on one lane's run at a time
         uint64_t ql = __ballot(l_long);
         while (ql) {
@@ -2019,7 +2025,12 @@ __global__ __launch_bounds__(JUMP_THREADS) void dec_jump_init_kernel(
         while (qm) {
             const int L = __builtin_ctzll(qm); qm &= qm - 1;
             const uint32_t qp = read_lane(p, L), qn = read_lane(m, L), qd = read_lane(dd, L);
-            for (uint32_t k = lane; k < qn; k += 64) org[qp + k] = jb + qp + k - qd;
+            if (qd >= qn) for (uint32_t k = lane; k < qn; k += 64) org[qp + k] = jb + qp + k - qd;
+            else {   // (overlaps itself: k mod qd, stepped by 64 mod qd per turn)
+                const uint32_t step = 64u % qd;
+                uint32_t rr = (uint32_t)lane % qd;
+                for (uint32_t k = lane; k < qn; k += 64) { org[qp + k] = jb + qp - qd + rr; rr += step; if (rr >= qd) rr -= qd; }
+            }
         }
         run_lit += tot_l; run_out += tot_s;
     }
