@@ -346,6 +346,7 @@ def main():
             if args.workload == "snappy":
                 ctx.enable_timing(False)
                 out["html"] = html_rows(ctx, torch, dev, lz, raws[names.index("html")])
+                out["per_file"] = per_file_compact(ctx, torch, dev, lz, names, raws)
         if not args.no_cpu_baseline:
             sample = batch_raw[:12] if args.workload == "snappy" else [batch_raw[0][:8 << 20]]
             out["cpu_baseline"] = cpu_baseline(sample)
@@ -588,11 +589,24 @@ def html_rows(ctx, torch, dev, lz, raw):
     itself: R = 256 and R = 16 copies per call, so that a driver record carries it."""
     rows = {}
     for R in (256, 16):
-        _, enc_len, te, td = file_rates(ctx, torch, dev, lz, raw, R)
+        _, enc_len, te, td = file_rates(ctx, torch, dev, lz, raw, R, samples=20 if R == 256 else 5)
         rows[f"x{R}"] = {"encode_GBps": round(len(raw) * R / te.mean() / 1e9, 2), "decode_GBps": round(len(raw) * R / td.mean() / 1e9, 2),
                          "encode_sd_pct": round(100 * te.std() / te.mean(), 1), "decode_sd_pct": round(100 * td.std() / td.mean(), 1)}
     rows["what"] = (f"data/snappy/html ({len(raw)} B) alone as a batch of R independent copies resident in HBM, wall time of the "
-                    "batch call, 2 warm-up + 5 samples")
+                    "batch call, 2 warm-up + 20 (x256) / 5 (x16) samples")
+    return rows
+
+
+def per_file_compact(ctx, torch, dev, lz, names, raws, R=256, samples=20):
+    """BASELINE config 4 inside the default line: every Snappy file by itself as a batch of R copies resident in HBM, Criterion's
+    sample count (bench/src/bench.rs:5-6,279-283: 20 samples), [encode GB/s, decode GB/s] from the MEAN wall time of the batch
+    calls. The full table (sd, CPU port column, bit-exact check per file) is --per-file R."""
+    rows = {}
+    for name, raw in zip(names, raws):
+        _, _, te, td = file_rates(ctx, torch, dev, lz, raw, R, samples=samples)
+        rows[name] = [round(len(raw) * R / te.mean() / 1e9, 2), round(len(raw) * R / td.mean() / 1e9, 2)]
+    rows["what"] = (f"each file alone as a batch of {R} independent copies resident in HBM, 2 warm-up + {samples} samples, "
+                    "[encode GB/s, decode GB/s] of the mean wall time of the batch call, round trip checked")
     return rows
 
 

@@ -630,7 +630,9 @@ __device__ int fse_build_tables(FseLds &lds, uint32_t kind, const FseHeader &h, 
 // LDS table entry formats
 //   U: (delta & 0xFFFF) | symbol << 16 | k << 24                      (decoder.rs:222-238; the symbol in byte 2 is what a
 //      d16_hi byte store takes without a shift, the delta in the low word what an SDWA add takes)
-//   V: .x = k | v_bits << 8 | (delta & 0xFFFF) << 16, .y = v_base     (decoder.rs:205-220)
+//   V: .x = k | v_bits << 8 | (delta & 0xFF) << 16 | (-(k + v_bits) & 0xFF) << 24, .y = v_base   (decoder.rs:205-220; delta is below
+//      the number of states, <= 256, by the choice of k; the signed byte is what the step's prefix sum over L, M, D runs on: it IS
+//      the window shift)
 __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
     const uint8_t *__restrict__ src, uint64_t src_total, const BlockDesc *__restrict__ blocks,
     uint32_t n_blocks, uint8_t *__restrict__ lit_out, LmdRec *__restrict__ lmd_out,
