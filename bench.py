@@ -214,6 +214,17 @@ def main():
             merged = sharding.merge_reports(reports, len(bounds))
             if world > 1:
                 sharding.check_against(merged, sharding.process_shard(data, sharding.CHUNK_BYTES, 0, 1, GpuCodec(ctx)))
+        # one PROCESS over every visible device (what a Rust caller of lzfse_mi_encode_chunked does; untimed, rank 0): the frame of
+        # the first 64 MiB over all devices equals the one a single context makes, and decodes back on all of them
+        chunked_devices = lz.device_count()
+        if rank == 0 and chunked_devices > 1:
+            cx = [ctx] + [lz.Context(k) for k in range(chunked_devices) if k != local_rank]
+            part = data[:64 << 20]
+            frame = lz.encode_chunked(cx, part, sharding.CHUNK_BYTES)
+            assert frame.tobytes() == lz.encode_chunked(cx[:1], part, sharding.CHUNK_BYTES).tobytes()
+            assert np.array_equal(np.asarray(lz.decode_chunked(cx, frame)), part)
+            for c in cx[1:]:
+                c.close()
         del data
     else:
         t = synth_text(256 << 20, seed=1 + rank)
@@ -334,6 +345,8 @@ def main():
             "kernel_ms_per_step": {k: round(v / args.steps, 4) for k, v in sorted(kern_ms.items())},
             "roofline": roof,
         }
+        if args.workload == "chunks1g":
+            out["chunked_over_devices"] = chunked_devices   # (> 1: lzfse_mi_encode_chunked ran over that many devices from rank 0, checked)
         if kx is not None:
             if dom in kx:   # (an unsplit call may take another LZ path than its sub-batches did)
                 ex_ms = kx[dom][0] / max(kx[dom][1], 1)

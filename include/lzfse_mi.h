@@ -70,6 +70,9 @@ enum {
  * not thread-safe; distinct contexts are independent. Results never depend on prior calls. */
 typedef struct lzfse_mi_ctx lzfse_mi_ctx;
 
+/* HIP devices visible to the process (0: none, and lzfse_mi_create fails with LZFSE_MI_NO_DEVICE): what a caller that wants one
+ * context per device (lzfse_mi_encode_chunked / _decode_chunked) iterates over. Initialises nothing on any device. */
+LZFSE_MI_API int lzfse_mi_device_count(void);
 LZFSE_MI_API int lzfse_mi_create(int device, lzfse_mi_ctx **out);
 LZFSE_MI_API void lzfse_mi_destroy(lzfse_mi_ctx *ctx);
 LZFSE_MI_API const char *lzfse_mi_status_string(int status);

@@ -18,7 +18,7 @@ _lib = None
 _diag_lib = None
 
 _SYMBOLS = [
-    "lzfse_mi_create", "lzfse_mi_destroy", "lzfse_mi_status_string", "lzfse_mi_version", "lzfse_mi_set_stream",
+    "lzfse_mi_device_count", "lzfse_mi_create", "lzfse_mi_destroy", "lzfse_mi_status_string", "lzfse_mi_version", "lzfse_mi_set_stream",
     "lzfse_mi_encode_bound", "lzfse_mi_encode", "lzfse_mi_decode", "lzfse_mi_decode_size",
     "lzfse_mi_encode_batch", "lzfse_mi_decode_batch", "lzfse_mi_decode_batch_device",
     "lzfse_mi_encode_batch_device", "lzfse_mi_enable_timing", "lzfse_mi_get_timings", "lzfse_mi_encode_small",
@@ -50,6 +50,8 @@ def _load(path):
     for s in _SYMBOLS:
         getattr(L, s)  # raises AttributeError if the ABI is incomplete
     vp, sz, u64p, ip = C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_int)
+    L.lzfse_mi_device_count.restype = C.c_int
+    L.lzfse_mi_device_count.argtypes = []
     L.lzfse_mi_create.restype = C.c_int
     L.lzfse_mi_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.lzfse_mi_destroy.restype = None

@@ -37,6 +37,11 @@ def _check(st):
         raise LzfseError(st)
 
 
+def device_count():
+    """lzfse_mi_device_count: HIP devices visible to the process (0 without one)."""
+    return int(_native.lib().lzfse_mi_device_count())
+
+
 class Context:
     """One HIP device + stream + scratch (lzfse_mi_ctx)."""
 

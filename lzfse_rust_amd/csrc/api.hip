@@ -279,6 +279,11 @@ const char *lzfse_mi_status_string(int s) {
     }
 }
 
+int lzfse_mi_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess && n > 0 ? n : 0;
+}
+
 int lzfse_mi_create(int device, lzfse_mi_ctx **out) {
     if (!out) return LZFSE_MI_BAD_ARGUMENT;
     *out = nullptr;

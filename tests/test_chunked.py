@@ -65,6 +65,29 @@ def test_chunked_round_trip_and_chunk_streams_are_plain_lzfse(oracle, snappy_raw
 
 
 @pytest.mark.gpu
+def test_chunked_over_every_visible_device(snappy_raw):
+    """lzfse_mi_encode_chunked / _decode_chunked over one context per VISIBLE device (chunk c on device c mod n): the frame is the
+    one a single context makes, whichever devices decode it. Skips on a one-GPU box; the first multi-GPU run exercises it."""
+    import lzfse_rust_amd as m
+    n = m.device_count()
+    if n < 2:
+        pytest.skip(f"{n} HIP device(s) visible: needs at least two")
+    ctxs = [m.Context(k) for k in range(n)]
+    data = (snappy_raw["lcet10.txt"] + snappy_raw["kppkn.gtb"]) * (2 * n) + b"end"
+    chunk = 1 << 19
+    frame = m.encode_chunked(ctxs, data, chunk).tobytes()
+    assert frame == m.encode_chunked(ctxs[:1], data, chunk).tobytes()
+    assert m.decode_chunked(ctxs, frame).tobytes() == data
+    assert m.decode_chunked(ctxs[::-1], frame).tobytes() == data
+    assert m.decode_chunked(ctxs[-1:], frame).tobytes() == data
+
+
+def test_device_count_needs_no_device():
+    import lzfse_rust_amd as m
+    assert m.device_count() >= 0
+
+
+@pytest.mark.gpu
 def test_cli_like_lzfoo(tmp_path, snappy_raw, oracle):
     raw = snappy_raw["alice29.txt"] * 40
     src, enc, dec, plain = (tmp_path / n for n in ("in", "enc", "dec", "plain"))
