@@ -719,8 +719,12 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
                 const uint32_t x = (uint32_t)(win >> ((0u - pre) & 63));   // pre == 0 only with k == 0
                 const uint32_t bits = __builtin_amdgcn_ubfe(x, 0u, k);
                 state = bits + (ent & 0xFFFFu);   // (0 <= delta, and delta + the k bits read < 1024 by the construction of the table: no mask)
-                stg_lit[sidx + slot_off] = (uint8_t)(ent >> 16);
+                const uint32_t sym = ent;
                 ent = u_tab[state];
+#ifndef FSE_NO_ORDER
+                __builtin_amdgcn_sched_barrier(0);   // (see the LMD loop: the look-up first)
+#endif
+                stg_lit[sidx + slot_off] = (uint8_t)(sym >> 16);
                 r2 = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)(r2 - (int32_t)read_lane(pre, 3)));   // (scalar: the address arithmetic below stays off the vector pipe)
                 const int32_t di = r2 >> 5;
                 const uint32_t d0 = ringw[di], d1 = ringw[di + 1], d2 = ringw[di + 2];
@@ -782,7 +786,6 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
             acc_m += vm;
             if (nz) carry_d = read_lane(vd, 63 - __builtin_clzll(nz));
         };
-        uint64_t win = n ? bw_window(w) : 0;
         uint2 ent = v_tab[tbase + state];   // (looked up one step ahead of its window, see the literal loop)
         constexpr uint32_t SUB = 16;   // (see the literal loop)
         const uint32_t *const ringw = w.buf;
@@ -793,6 +796,13 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
             const int32_t r2_bias = 64 + 32 * w.cb;
             int32_t r2 = w.rem - r2_bias;
             const int32_t low57 = w.base_bit + 57 - r2_bias;
+            // The window of a step is put together at the step's beginning from three dwords that the step BEFORE has asked
+            // for (d0 .. d2 at cursor r2): a lone wave issues one instruction every ~5 cycles and an LDS read takes ~50, so a
+            // step is as long as its instructions plus whatever no other instruction covers. In program order: the prefix of
+            // the bit counts, the window, the state -> the NEXT entry's look-up (the chain every step hangs on) -> the cursor
+            // and the next window's reads -> the value and its staging store, which nothing waits for.
+            uint32_t d0, d1, d2;
+            { const int32_t di = r2 >> 5; d0 = ringw[di]; d1 = ringw[di + 1]; d2 = ringw[di + 2]; }
             auto lmd_step = [&](auto safe_tag, uint32_t slot_off) {
                 constexpr bool SAFE = decltype(safe_tag)::value;
                 // (v_bfe_u32 takes its width from bits 4:0 of the operand: the entry itself serves as k <= 10)
@@ -800,21 +810,24 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
                 const uint32_t ntot = (uint32_t)((int32_t)ent.x >> 24);   // -(k + vb)
                 uint32_t npre = ntot + dpp_shr<1>(ntot);
                 npre += dpp_shr<2>(ntot);   // (both moves read `ntot`: no wait between them) minus the bits of lanes 0 .. this one
+                const uint32_t x0 = __builtin_amdgcn_alignbit(d1, d0, (uint32_t)r2), x1 = __builtin_amdgcn_alignbit(d2, d1, (uint32_t)r2);
+                uint64_t win = (uint64_t)x0 | ((uint64_t)x1 << 32);
+                if (SAFE && r2 < low57) win = 0;
                 // a lane's field (state bits above value bits) is at most 10 + 15 bits: one 64-bit shift, two bit-field extracts
                 const uint32_t x = (uint32_t)(win >> (npre & 63));  // npre == 0 only when k = vb = 0 below
-                const uint32_t extra = __builtin_amdgcn_ubfe(x, 0u, vb);
                 const uint32_t sb = __builtin_amdgcn_ubfe(x, vb, k);
                 // (no mask: delta + the k bits read stay below the number of states by the construction of the table, decoder.rs:244-335)
                 state = sb + ((ent.x >> 16) & 0xFFu);
                 asm volatile("" : "+v"(state));   // (one SDWA add; left alone the compiler scales both terms by 8 first: one instruction more)
-                stg_lmd[sidx + slot_off] = ent.y + extra;
+                const uint32_t base = ent.y;
                 ent = vt[state];
+                __builtin_amdgcn_sched_barrier(0);
                 r2 = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)(r2 + (int32_t)read_lane(npre, 2)));
                 const int32_t di = r2 >> 5;
-                const uint32_t d0 = ringw[di], d1 = ringw[di + 1], d2 = ringw[di + 2];
-                const uint32_t x0 = __builtin_amdgcn_alignbit(d1, d0, (uint32_t)r2), x1 = __builtin_amdgcn_alignbit(d2, d1, (uint32_t)r2);
-                win = (uint64_t)x0 | ((uint64_t)x1 << 32);
-                if (SAFE && r2 < low57) win = 0;
+                d0 = ringw[di]; d1 = ringw[di + 1]; d2 = ringw[di + 2];
+                __builtin_amdgcn_sched_barrier(0);
+                stg_lmd[sidx + slot_off] = base + __builtin_amdgcn_ubfe(x, 0u, vb);
+                __builtin_amdgcn_sched_barrier(0);
             };
             if (lane < 3) {
                 if (i1 - i0 == SUB && r2 - 64 * (int32_t)SUB >= low57) {
