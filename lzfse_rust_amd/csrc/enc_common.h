@@ -5,7 +5,10 @@
 namespace lzmi {
 
 constexpr uint32_t TILE_POS = 65472;        // positions per chain tile: multiple of 64 and of CAND_P, offset + 1 fits u16
-constexpr uint32_t SEG = 2048;              // positions per speculative-parse segment of a large batch (small ones: 1024 or 512, seg_for)
+#ifndef LZMI_SEG
+#define LZMI_SEG 2048
+#endif
+constexpr uint32_t SEG = LZMI_SEG;          // positions per speculative-parse segment of a large batch (small ones: 512, seg_for)
 constexpr uint32_t OVER = 512;              // overrun of a segment walker into the next segment
 constexpr uint32_t SEG_EV_CAP = (SEG + OVER) / 4 + 4;  // every emit advances literal_index by >= 4
 __host__ __device__ __forceinline__ uint32_t seg_ev_cap(uint32_t seg) { return (seg + OVER) / 4 + 4; }   // events a walker of `seg` positions can log

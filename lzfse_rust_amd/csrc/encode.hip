@@ -226,7 +226,10 @@ __device__ __forceinline__ uint32_t bo_finalize(BitOut &o) {
     return nbytes * 8 - o.fill;
 }
 
-__global__ __launch_bounds__(BLK_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void enc_block_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
+#ifndef BLK_WAVES_PER_EU
+#define BLK_WAVES_PER_EU 4
+#endif
+__global__ __launch_bounds__(BLK_THREADS) __attribute__((amdgpu_waves_per_eu(BLK_WAVES_PER_EU, BLK_WAVES_PER_EU))) void enc_block_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
                                                                 uint32_t n_streams, const EncStreamOut *__restrict__ outs,
                                                                 const uint2 *__restrict__ lmds, EncBlock *__restrict__ blocks,
                                                                 const uint32_t *__restrict__ slot_stream, uint8_t *__restrict__ stage,
