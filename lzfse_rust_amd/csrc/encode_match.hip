@@ -297,6 +297,20 @@ __device__ __forceinline__ uint32_t group4_min(uint32_t v) {   // the same over 
     return v;
 }
 
+// (after group4_min: the quads of a half row, then the half rows of a row, exchange their minima)
+__device__ __forceinline__ uint32_t half_row_min(uint32_t v) {
+    asm("s_nop 1\n"
+        "v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf"
+        : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ uint32_t row_min(uint32_t v) {
+    asm("s_nop 1\n"
+        "v_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
+        : "+v"(v));
+    return v;
+}
+
 // rec[i] = rec_make(dist, fwd_len, bwd) (enc_common.h); 0: no match at i
 //
 // One lane per position, hops in lock-step. A lane compares at most CAND_C1 bytes on its own. Lanes
@@ -527,7 +541,11 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
             // makes. The first chunk may begin up to 3 bytes before the head's position (those bytes are masked) or inside
             // the CAND_C1 bytes phase 2 has compared (equal again); behind the end of the stream the window holds zeros and
             // whatever differs there lies beyond the limit.
-            const uint32_t i0 = i - (uint32_t)lane, sub = (uint32_t)lane % CAND_GL;
+            // A wave with few heads gives each of them more lanes (4 lanes = 128 bytes a step, up to 16 lanes = 512): inside a long run
+            // every wave has just its lane 0 as a head, in up to four slots, each of them 1 087 bytes long -- 9 steps with 4 lanes,
+            // 3 with 16 (zeros, long periods: profiles/r04_repetitive.txt)
+            const uint32_t gl = total <= 4 ? 16u : total <= 8 ? 8u : (uint32_t)CAND_GL, gl_sh = total <= 4 ? 4u : total <= 8 ? 3u : 2u;
+            const uint32_t i0 = i - (uint32_t)lane, sub = (uint32_t)lane & (gl - 1);
             uint32_t next = 0, it_lim = 0, it_id = 0, it_w = 0;
             int32_t it_t = 0;           // offset (from the head's position) of the byte the group's NEXT chunk 0 begins with
             const uint4 *it_p = nullptr;   // that chunk
@@ -537,7 +555,7 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
                 if (next < total && idle) {
                     // the idle groups take the next heads of the list, in group order: a lane counts the idle LANES below it
                     const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-                    const uint32_t q = next + below / CAND_GL;
+                    const uint32_t q = next + (below >> gl_sh);
                     if (!busy && q < total) {
                         busy = true;
                         it_id = q_id[wv][q];
@@ -550,7 +568,7 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
                         const uint32_t room = n - hi;
                         it_lim = room < FCAP + 64 ? room : FCAP + 64;
                     }
-                    next += (uint32_t)__popcll(idle) / CAND_GL;
+                    next += (uint32_t)__popcll(idle) >> gl_sh;
                 }
                 if (!__any(busy)) break;
 #ifdef CAND_STATS
@@ -579,9 +597,11 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
                     r = (uint32_t)t + (m1 < m2 ? m1 : m2);
                 }
                 r = group4_min(r);
+                if (gl >= 8) r = half_row_min(r);
+                if (gl >= 16) r = row_min(r);
                 if (busy) {
-                    it_t += 32 * CAND_GL;
-                    it_p += 2 * CAND_GL;
+                    it_t += (int32_t)(32u << gl_sh);
+                    it_p += 2u << gl_sh;
                     if (r < 0xFFFFu || it_t >= (int32_t)it_lim) {   // (no difference found: 0xFFFF, or 0x1FFFFFFF and more)
                         if (sub == 0) q_res[wv][it_id] = (uint16_t)(r < it_lim ? r : it_lim);
                         busy = false;

@@ -24,7 +24,10 @@ cases = [("period 300", lambda: periodic(300, 1 << 20, 0)), ("period 1100", lamb
          ("runs of 3 .. 400 equal bytes", lambda: np.repeat(rng.integers(0, 256, size=12000, dtype=np.uint8), rng.integers(3, 400, size=12000))[:1 << 20].copy()),
          ("runs of 2 400 .. 7 000 equal bytes", lambda: np.repeat(rng.integers(0, 256, size=900, dtype=np.uint8), rng.integers(2400, 7000, size=900))[:1 << 20].copy()),
          ("zeros", lambda: np.zeros(1 << 20, dtype=np.uint8))]
+only = [a[5:] for a in sys.argv[1:] if a.startswith('only=')]   # only=zeros only='period 1100' ...
 for name, gen in cases:
+    if only and name not in only:
+        continue
     parts = [gen() for _ in range(4)] * 64          # 256 streams of 1 MiB
     n = parts[0].size
     src = torch.from_numpy(np.concatenate(parts)).to(dev)
@@ -40,6 +43,11 @@ for name, gen in cases:
     ol, st = ctx.encode_batch_device(src.data_ptr(), so, sl, dst.data_ptr(), do, dc)
     t1 = time.perf_counter()
     assert all(int(e) == 0 for e in st)
+    if len(sys.argv) > 1 and sys.argv[1] == "stages":   # where the encoder's time goes (one more pass, one lane, stage timers on)
+        ctx.set_option("encode_lanes", 1); ctx.enable_timing(True)
+        ctx.encode_batch_device(src.data_ptr(), so, sl, dst.data_ptr(), do, dc)
+        print("      ", {k: round(v[0], 2) for k, v in sorted(ctx.timings().items()) if v[0] > 0.15})
+        ctx.enable_timing(False); ctx.set_option("encode_lanes", 0)
     back = torch.empty(n * len(parts), dtype=torch.uint8, device=dev)
     el = np.asarray([int(x) for x in ol], dtype=np.uint64)
     ctx.decode_batch_device(dst.data_ptr(), do, el, back.data_ptr(), so, sl)
