@@ -26,7 +26,7 @@ constexpr uint32_t NONE_TILE = 0xFFFFFFFEu; // no previous position inside the t
 constexpr uint32_t FCAP = 1023;             // cap of the forward length computed per position (>= GOOD_MATCH_LEN); 10 bits of a record
 constexpr uint32_t XCAP = 16384;            // cap of the exact per-lane extension in the segment walkers (runs of 2 400 .. 7 000 equal bytes, 64 x 4 MiB:
                                             // with 4 096 every segment gave up and the stitcher walked alone, enc_stitch 8.1 ms; now 0.2; 65 536 costs zeros and the Snappy mix)
-constexpr uint32_t BCAP = 15;               // cap of the backward length kept per position; 4 bits of a record
+constexpr uint32_t BCAP = 13;               // cap of the backward length kept per position (4 bits of a record): what ONE dword-aligned 16-byte load in front of a candidate always holds
 
 // Candidate record of a position (4 bytes): the best match as if the position were visited. distance (18 bits) |
 // forward length << 18 (10 bits; FCAP = "at least FCAP": the walkers ask for the exact length) | backward length << 28

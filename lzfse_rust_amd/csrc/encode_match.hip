@@ -260,6 +260,11 @@ __device__ __forceinline__ uint32_t ffbl_m1(uint32_t x) {   // v_ffbl_b32: index
     asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
     return r;
 }
+__device__ __forceinline__ uint32_t ffbh_m1(uint32_t x) {   // v_ffbh_u32: number of leading zero bits, 0xFFFFFFFF for 0
+    uint32_t r;
+    asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
 __device__ __forceinline__ uint32_t add_sat(uint32_t a, uint32_t b) {   // unsigned add that stays at 0xFFFFFFFF
     uint32_t r;
     asm("v_add_u32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
@@ -652,26 +657,33 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
     // backward extension: the same run structure, LCS(i + t, c + t) = LCS(i, c) + t (up to the cap)
     uint32_t r = 0;
     {
-        constexpr uint32_t BW_CALC = 16;   // two 8-byte steps; stored as min(.., BCAP)
         const uint32_t bd = best_len ? i - best_idx : NONE;
         const uint32_t bd_lo = dpp_take<0x138, 0xF>(NONE, bd);
         const bool bfol = best_len != 0 && lane > 0 && bd_lo == bd;
-        const uint32_t bmax = best_idx < BW_CALC ? best_idx : BW_CALC;
+        const uint32_t bmax = best_idx < BCAP ? best_idx : BCAP;   // (BCAP = "at least BCAP": the walkers ask for more)
         uint32_t bw = 0;
         if (best_len && !bfol) {
-            // lcs_bwd with this position's side read from the window (8 bytes per step, at most 16 back)
-            uint32_t len = 0;
-            bool open = true;
-            while (open && len + 8 <= bmax) {
-                const uint32_t wo = 32u + (uint32_t)lane - len - 8, q = wo >> 2, sh = (wo & 3) * 8;
-                const uint32_t d0 = win[q], d1 = win[q + 1], d2 = win[q + 2];
-                const uint64_t av = (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
-                const uint64_t x = av ^ ld_u64(s + best_idx - len - 8);
-                if (x) { len += (uint32_t)(__builtin_clzll(x) >> 3); open = false; }
-                else len += 8;
+            if (best_idx >= 16) {
+                // The BCAP = 13 bytes in front of the candidate come with ONE dword-aligned 16-byte load that ends at or behind it
+                // (round 3: up to two dependent byte-misaligned 8-byte loads in a loop); the position's own 16 bytes, shifted to
+                // lie the same way, come from the window in LDS. Byte j of the chunk is byte e - 1 - j back from the candidate
+                // (e = 13 .. 16 bytes of the chunk lie in front of it, the rest is masked), so the backward length is the number
+                // of equal bytes counted from the chunk's top: v_ffbh_u32 gives -1 for a zero dword and the saturating adds keep it.
+                const uintptr_t cpa = ((uintptr_t)(s + best_idx) - BCAP) & ~(uintptr_t)3;
+                const uint32_t e = (uint32_t)((uintptr_t)(s + best_idx) - cpa);
+                const uint4 cb = *reinterpret_cast<const uint4 *>(cpa);
+                const uint32_t wo = 32u + (uint32_t)lane - e, q = wo >> 2, sh = (wo & 3) * 8;
+                const uint32_t d0 = win[q], d1 = win[q + 1], d2 = win[q + 2], d3 = win[q + 3], d4 = win[q + 4];
+                const uint32_t x0 = cb.x ^ __builtin_amdgcn_alignbit(d1, d0, sh), x1 = cb.y ^ __builtin_amdgcn_alignbit(d2, d1, sh);
+                const uint32_t x2 = cb.z ^ __builtin_amdgcn_alignbit(d3, d2, sh);
+                uint32_t x3 = cb.w ^ __builtin_amdgcn_alignbit(d4, d3, sh);
+                x3 &= 0xFFFFFFFFu >> (8 * (16 - e));   // (e >= 13: at most three bytes of the last dword lie behind the candidate's position)
+                const uint32_t lead = min(min(ffbh_m1(x3), add_sat(ffbh_m1(x2), 32u)), min(add_sat(ffbh_m1(x1), 64u), add_sat(ffbh_m1(x0), 96u)));
+                bw = (lead >> 3) - (16 - e);         // equal bytes from the chunk's top, less the masked ones (all equal: huge)
+            } else {
+                while (bw < bmax && s[i - bw - 1] == s[best_idx - bw - 1]) bw++;   // (a candidate in the stream's first 16 bytes)
             }
-            while (open && len < bmax && s[i - len - 1] == s[best_idx - len - 1]) len++;
-            bw = len;
+            bw = bw < bmax ? bw : bmax;
         }
         const uint64_t hm = __ballot(best_len != 0 && !bfol);
         if (__any(bfol)) {
