@@ -414,12 +414,14 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+def pmc_files():
+    """profiles/rNN_pmc_traffic.json, newest round first (the one stamped with this build's kernel sources is the one used)"""
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")), reverse=True)
 
 
 def pmc_traffic(dom, args, b_enc=None):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE runs of this same default command, profiles/r03_pmc_traffic.json), CORRECTED as MI355X_MICROARCH.md's HBM
+    WRITE_SIZE runs of this same default command, profiles/rNN_pmc_traffic.json), CORRECTED as MI355X_MICROARCH.md's HBM
     section prescribes for gfx950: 2 x FETCH_SIZE + WRITE_SIZE (the read counter tallies 128-byte requests at 64 bytes;
     checked on this build's own mandatory coalesced reads). Only reported when that file was taken
     on exactly the kernel sources of this build (source_sha) and for the default workload; otherwise null. Returns
@@ -427,8 +429,9 @@ def pmc_traffic(dom, args, b_enc=None):
     try:
         if args.workload != "snappy" or args.replicas != 256 or args.lanes:
             return None, None
-        pm = json.load(open(PMC_FILE))
-        if pm.get("source_sha") != kernel_source_sha():
+        sha = kernel_source_sha()
+        pm = next((m for m in (json.load(open(f)) for f in pmc_files()) if m.get("source_sha") == sha), None)
+        if pm is None:
             return None, None
         ks = pm["kernels"]
 
