@@ -130,12 +130,10 @@ def test_pattern_6_random_short_repeats(ctx, oracle):
 # ---------------------------------------------------------------------------------------------- patchwork_*.rs
 
 def test_patchwork_0_long_files(ctx, oracle):
-    """patchwork_0.rs:13-87: (rounds, shift) = (0x10000, 28), (0x10000, 26), (0x1000, 22), (0x100, 18); every 8th of the 256 seeds
-    (the generator is a scalar loop)."""
-    inputs = []
+    """patchwork_0.rs:13-87: (rounds, shift) = (0x10000, 28), (0x10000, 26), (0x1000, 22), (0x100, 18); all 0x100 seeds (round 4:
+    every 8th until then), one batch per (rounds, shift)."""
     for rounds, shift in ((0x10000, 28), (0x10000, 26), (0x1000, 22), (0x100, 18)):
-        inputs += [tk.patchwork(seed, rounds, shift) for seed in range(0, 0x100, 8)]
-    encode_decode(ctx, oracle, inputs, "patchwork_0")
+        encode_decode(ctx, oracle, [tk.patchwork(seed, rounds, shift) for seed in range(0x100)], f"patchwork_0/{rounds:x}/{shift}")
 
 
 def test_patchwork_1_short_files(ctx, oracle):
@@ -204,17 +202,17 @@ def test_mutate_0_every_bit(ctx, oracle, golden_dir, name):
 
 @pytest.mark.parametrize("name", FIXTURES)
 def test_mutate_1_every_byte_value(ctx, oracle, golden_dir, name):
-    """mutate_1.rs:24-36: data[index] ^= byte for every byte value; all positions of the header region (first 96 bytes),
-    every 16th position after it."""
+    """mutate_1.rs:24-36: data[index] ^= byte for every byte value at EVERY position (round 4: every 16th behind the header until
+    then), in batches of 64 positions."""
     data, digest = _fixture(golden_dir, name)
-    pos = list(range(min(96, len(data)))) + list(range(96, len(data), 16))
-    cases = []
-    for i in pos:
-        for b in range(1, 256):
-            m = bytearray(data)
-            m[i] ^= b
-            cases.append(bytes(m))
-    blind_decode(ctx, oracle, cases, 1 << 20, f"mutate_1/{name}")
+    for p0 in range(0, len(data), 64):
+        cases = []
+        for i in range(p0, min(p0 + 64, len(data))):
+            for b in range(1, 256):
+                m = bytearray(data)
+                m[i] ^= b
+                cases.append(bytes(m))
+        blind_decode(ctx, oracle, cases, 1 << 20, f"mutate_1/{name}/{p0}")
     _intact(ctx, data, digest)
 
 
@@ -236,10 +234,10 @@ def test_mutate_2_3_min_max_words(ctx, oracle, golden_dir, name):
 @pytest.mark.parametrize("name", FIXTURES)
 def test_mutate_4_5_compound_random_damage(ctx, oracle, golden_dir, name):
     """mutate_4.rs:25-41 (bits), mutate_5.rs:25-41 (bytes; the reference's own index = n / 8 is kept): damage accumulates
-    over 0x100 steps per seed; 24 of the 0x100 seeds."""
+    over 0x100 steps per seed; all 0x100 seeds (round 4: 24 of them until then)."""
     data, digest = _fixture(golden_dir, name)
     cases = []
-    for seed in range(0, 0x100, 11):
+    for seed in range(0x100):
         rng = tk.Rng(seed)
         m = bytearray(data)
         for _ in range(0x100):
