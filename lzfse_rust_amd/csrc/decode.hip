@@ -689,7 +689,6 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
         // exec masking), and every 64 groups the wave stores 64 dwords coalesced: two instructions per step.
         const uint32_t s_home = lane < 4 ? (uint32_t)lane : 256u, s_inc = lane < 4 ? 4u : 0u;
         uint32_t sidx = s_home;
-        uint64_t win = n_groups ? bw_window(w) : 0;
         // the lookup of step g + 1 needs only the state, so it is issued before the window of step g + 1 is fetched: the
         // two LDS round trips of a step overlap instead of following each other
         uint32_t ent = u_tab[state];
@@ -711,26 +710,30 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
             const int32_t r2_bias = 64 + 32 * w.cb;
             int32_t r2 = w.rem - r2_bias;   // uniform: bits below the window's lowest bit, counted from the ring's first dword
             const int32_t low57 = w.base_bit + 57 - r2_bias;   // bw_step_window's rule (rem - base_bit < 57: the window reads as zero) is r2 < low57
+            // (software-pipelined like the LMD loop below: the window's three dwords are asked for by the step before, the next
+            // entry's look-up goes first)
+            uint32_t d0, d1, d2;
+            { const int32_t di = r2 >> 5; d0 = ringw[di]; d1 = ringw[di + 1]; d2 = ringw[di + 2]; }
             auto lit_step = [&](auto safe_tag, uint32_t slot_off) {
                 constexpr bool SAFE = decltype(safe_tag)::value;
                 const uint32_t k = ent >> 24;
                 uint32_t pre = k + dpp_shr<1>(k);
                 pre += dpp_shr<2>(pre);  // inclusive prefix over lanes 0..3
+                const uint32_t x0 = __builtin_amdgcn_alignbit(d1, d0, (uint32_t)r2), x1 = __builtin_amdgcn_alignbit(d2, d1, (uint32_t)r2);
+                uint64_t win = (uint64_t)x0 | ((uint64_t)x1 << 32);
+                if (SAFE && r2 < low57) win = 0;
                 const uint32_t x = (uint32_t)(win >> ((0u - pre) & 63));   // pre == 0 only with k == 0
                 const uint32_t bits = __builtin_amdgcn_ubfe(x, 0u, k);
                 state = bits + (ent & 0xFFFFu);   // (0 <= delta, and delta + the k bits read < 1024 by the construction of the table: no mask)
                 const uint32_t sym = ent;
                 ent = u_tab[state];
-#ifndef FSE_NO_ORDER
-                __builtin_amdgcn_sched_barrier(0);   // (see the LMD loop: the look-up first)
-#endif
-                stg_lit[sidx + slot_off] = (uint8_t)(sym >> 16);
+                __builtin_amdgcn_sched_barrier(0);
                 r2 = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)(r2 - (int32_t)read_lane(pre, 3)));   // (scalar: the address arithmetic below stays off the vector pipe)
                 const int32_t di = r2 >> 5;
-                const uint32_t d0 = ringw[di], d1 = ringw[di + 1], d2 = ringw[di + 2];
-                const uint32_t x0 = __builtin_amdgcn_alignbit(d1, d0, (uint32_t)r2), x1 = __builtin_amdgcn_alignbit(d2, d1, (uint32_t)r2);
-                win = (uint64_t)x0 | ((uint64_t)x1 << 32);
-                if (SAFE && r2 < low57) win = 0;
+                d0 = ringw[di]; d1 = ringw[di + 1]; d2 = ringw[di + 2];
+                __builtin_amdgcn_sched_barrier(0);
+                stg_lit[sidx + slot_off] = (uint8_t)(sym >> 16);
+                __builtin_amdgcn_sched_barrier(0);
             };
             if (lane < 4) {
                 if (g1 - g0 == SUB && r2 - 64 * (int32_t)SUB >= low57) {
