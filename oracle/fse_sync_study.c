@@ -4,7 +4,7 @@
  * literals.rs:49-91) somewhere inside a block with something WRONG -- the states, or the cursor by a few bits -- and count the
  * steps until (cursor, states) fall onto the true decoder's sequence. A decoder that never does within 4 096 steps counts as "never".
  *
- *   gcc -O2 -o oracle/_ref/fse_sync_study oracle/fse_sync_study.c && oracle/_ref/fse_sync_study tests/golden/snappy/ *.lzfse
+ *   make -C oracle fse_sync_study.bin && oracle/fse_sync_study.bin tests/golden/snappy/ *.lzfse
  */
 #include "lzfse_oracle.c"
 
