@@ -481,7 +481,13 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
         uint64_t any_more = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
+#ifdef CAND_LOWCAP
+            // (experiment, experiments/README.md: no phase 3 at all -- a candidate that is still equal after CAND_C1 bytes, and every
+            // follower of one, is recorded as "at least": the segment walkers measure it exactly if and when they stand there)
+            more[k] = false;
+#else
             more[k] = ln[k] == CAND_C1 && !fol[k] && CAND_C1 < cap_total;
+#endif
             dep[k] = false; lead[k] = 0;
             any_more |= __ballot(more[k]);
         }
@@ -641,6 +647,10 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
             // equal check bits; should the head's turn out a chance hit (< 4 + t bytes), this lane measures for itself.
             if (fol[k]) {
                 const uint32_t tt = (uint32_t)(lane - h);
+#ifdef CAND_LOWCAP
+                if (hl >= CAND_C1) { len = CAND_C1; capped = true; }
+                else
+#endif
                 if (hl >= tt + 4) len = hl - tt;
                 else { const uint32_t m = lcp_fwd(s, i, c, 0, cap_total); len = m >= 4 ? m : 0u; }
             }
@@ -650,6 +660,9 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
             // (ring parse: a candidate that runs to the end of the input is compared past it by the reference's coarse compare,
             // ring/object.rs:39-84, and which candidate wins depends on that: the walkers evaluate such a position exactly)
             if (len == cap_total && (cap_total < max_total || tl.ring)) capped = true;
+#ifdef CAND_LOWCAP
+            if (len >= CAND_C1 && CAND_C1 < cap_total) capped = true;
+#endif
             if (len > best_len) { best_len = len; best_idx = c; }  // ties keep the newest (:226)
         }
     }
