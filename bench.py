@@ -471,12 +471,12 @@ def copy_peak(torch, dev):
     return {"GBps": round(2 * n / (ms * 1e-3) / 1e9, 1), "what": "torch uint8 device-to-device copy of 1 GiB, read + write bytes"}
 
 
-def pcie_inclusive(ctx, lz, batch_raw):
+def pcie_inclusive(ctx, lz, batch_raw, n_streams=384):
     """The host-pointer entry points (what the Rust shim binds): pageable host buffers in, pinned staging, one H2D and one
     D2H per batch, results back in host memory. Never `value`."""
     import ctypes as C
     ctx.enable_timing(False)   # (stage timings are per context: a large host call is not cut in two while they are collected)
-    sample = batch_raw[:384]
+    sample = batch_raw[:n_streams]
     n = len(sample)
     raw = sum(len(r) for r in sample)
     arrs = [np.frombuffer(r, dtype=np.uint8) for r in sample]

@@ -1176,8 +1176,13 @@ static int host_batch(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, size_
     uint64_t bytes = 0;
     for (size_t i = 0; i < count; i++) bytes += (uint64_t)lens[i] + caps[i];
     size_t nA = 0;
-    // (measured: 1 GiB of 4 MiB streams +18 % encode, +10 % decode; 94 MB in 384 streams -10 % / -25 %: the halves must be large)
-    if (count >= 2 && bytes >= ((uint64_t)512 << 20) && !c->timing && !c->is_peer) {
+    // (measured: 1 GiB of 4 MiB streams +18 % encode, +10 % decode. Round 3 found 94 MB in 384 streams 10 - 25 % SLOWER cut in two,
+    // with each half cut once more into its two encode lanes: four sub-batches of 24 MB. Round 4: below 512 MiB the halves ARE the
+    // two lanes, each half one pass: 94 MB +8 % encode, +4 % decode (A/B on one box, scripts/pcie_sample.py); 29 MB: no difference)
+#ifndef HOST_SPLIT_MIN
+#define HOST_SPLIT_MIN ((uint64_t)64 << 20)
+#endif
+    if (count >= 2 && bytes >= HOST_SPLIT_MIN && !c->timing && !c->is_peer) {
         uint64_t acc = 0;
         while (nA + 1 < count && acc + lens[nA] + caps[nA] <= bytes / 2) { acc += (uint64_t)lens[nA] + caps[nA]; nA++; }
         if (nA == 0) nA = 1;
@@ -1196,6 +1201,9 @@ static int host_batch(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, size_
     }
     lzfse_mi_ctx *p = c->host_peer;
     p->opt_lanes_enc = c->opt_lanes_enc; p->opt_lanes_dec = c->opt_lanes_dec; p->opt_stagger = c->opt_stagger; p->opt_pipe = c->opt_pipe;
+    // (a call below 512 MiB that is cut in two: the halves ARE the two sub-batches, each runs as one pass)
+    const int keep_lanes = c->opt_lanes_enc;
+    if (bytes < ((uint64_t)512 << 20) && !c->opt_lanes_enc) { c->opt_lanes_enc = 1; p->opt_lanes_enc = 1; }
     p->diag_lz_jump = c->diag_lz_jump; p->diag_lz_variant = c->diag_lz_variant; p->diag_stats = c->diag_stats; p->diag_chain = c->diag_chain;
     p->diag_walk = c->diag_walk; p->diag_pipe_scatter = c->diag_pipe_scatter;
     p->parse_ring = c->parse_ring;
@@ -1209,6 +1217,7 @@ static int host_batch(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, size_
     const int rA = host_batch_one(c, fn, pack_outputs, nA, srcs, lens, dsts, caps, out_lens, statuses, &kick);
     if (!started) kick();   // (the first half failed before its inputs were staged: the second still has to give its answers)
     c->host_worker->wait();
+    c->opt_lanes_enc = keep_lanes;
     // the detail words of both halves, in the caller's order
     std::vector<uint32_t> det(count, 0u);
     for (size_t i = 0; i < nA && i < c->detail_out.size(); i++) det[i] = c->detail_out[i];
