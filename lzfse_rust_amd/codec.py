@@ -333,10 +333,11 @@ class LzfseWriterBytes(LzfseWriter):
 class LzfseRingDecoder:
     """src/decode/ring_decoder.rs:17-68: decode(reader, writer) -> (bytes read, bytes written). `reader.read(n)` returns
     b"" at the end of the input, `writer.write(b)` takes the output in pieces; `window` = raw bytes per device call.
-    `zero_copy=True` hands the writer a memoryview of the library's window buffer instead of bytes: one copy less, but the
-    piece is only valid DURING the write call (file objects and hashers are fine; a sink that keeps the object is not)."""
+    The writer is handed a memoryview of the library's window buffer that is valid DURING the write call only and released
+    after it (file objects, hashers, `bytearray +=` are fine; a sink that keeps the object gets a ValueError when it uses it
+    later, one that keeps an export of it makes the call fail); `zero_copy=False` hands out bytes it may keep instead."""
 
-    def __init__(self, device=0, context=None, window=0, read_size=1 << 20, zero_copy=False):
+    def __init__(self, device=0, context=None, window=0, read_size=1 << 20, zero_copy=True):
         self._ctx = context or Context(device)
         self._window = window
         self._read_size = read_size
@@ -350,10 +351,20 @@ class LzfseRingDecoder:
 
         def _write(_user, p, n):
             try:
-                # copy=False: a view of the library's buffer, valid during the call only (a writer that keeps the object it is
-                # handed -- list.append, a queue -- must not use it)
-                view = memoryview((C.c_uint8 * n).from_address(C.addressof(p.contents))) if n else b""
-                writer.write(view if self._zero_copy else bytes(view))
+                # A view of the library's window buffer, valid during the call only -- and RELEASED after it, so that a writer
+                # that keeps the object it was handed (list.append, a queue) gets a ValueError when it touches it later instead
+                # of reading memory that has been overwritten or freed. zero_copy=False hands out bytes instead (one copy and a
+                # fresh allocation per piece: 64 MiB windows then decode at 3.2 instead of 10.3 GB/s, profiles/r04_stream_bench.txt)
+                if not n:
+                    writer.write(b"")
+                elif not self._zero_copy:
+                    writer.write(bytes((C.c_uint8 * n).from_address(C.addressof(p.contents))))
+                else:
+                    view = memoryview((C.c_uint8 * n).from_address(C.addressof(p.contents)))
+                    try:
+                        writer.write(view)
+                    finally:
+                        view.release()   # (BufferError if the writer still holds an export of it, e.g. np.frombuffer: reported below)
                 return 0
             except Exception as e:   # the sink's error travels back through the C layer as LZFSE_MI_IO
                 failure.append(e)

@@ -51,6 +51,12 @@ def main():
             dt = time.perf_counter() - t
         assert (u, v, s.n) == (len(enc), len(raw), len(raw))
         print(f"stream decode, window {window >> 20:3d} MiB: {len(raw) / dt / 1e6:9.1f} MB/s")
+    for _ in range(2):
+        s = Sink()
+        t = time.perf_counter()
+        u, v = m.LzfseRingDecoder(context=ctx, window=64 << 20, read_size=1 << 20, zero_copy=False).decode(io.BytesIO(enc), s)
+        dt = time.perf_counter() - t
+    print(f"stream decode, window  64 MiB: {len(raw) / dt / 1e6:9.1f} MB/s   (zero_copy=False: the writer is handed bytes it may keep -- one more copy into a fresh allocation per window)")
     # ---- encode: the ring / stream encoder's bytes, whole input in one call against windows ----
     for _ in range(2):
         t = time.perf_counter()

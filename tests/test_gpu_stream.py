@@ -320,8 +320,9 @@ def test_stream_objects_may_outlive_their_context(oracle, snappy_raw):
     c2.close()
 
 
-def test_writer_pieces_are_copies_unless_asked(ctx, oracle, snappy_raw):
-    """LzfseRingDecoder hands the writer bytes it may keep; zero_copy=True hands views of the window buffer (valid during the call)."""
+def test_writer_pieces_are_views_released_after_the_call(ctx, oracle, snappy_raw):
+    """LzfseRingDecoder hands the writer views of the window buffer that die with the call: a sink that keeps one fails LOUDLY
+    later (ValueError) instead of reading overwritten memory; zero_copy=False hands out bytes it may keep."""
     import lzfse_rust_amd as m
     raw = snappy_raw["html"]
     enc = oracle.encode(raw)
@@ -335,7 +336,12 @@ def test_writer_pieces_are_copies_unless_asked(ctx, oracle, snappy_raw):
 
     k = Keep()
     m.LzfseRingDecoder(context=ctx, window=1 << 16).decode(PieceReader(enc, [9000]), k)
+    assert k.pieces and all(isinstance(p, memoryview) for p in k.pieces)
+    with pytest.raises(ValueError):
+        bytes(k.pieces[0])                      # released: no silent read of a reused buffer
+    k = Keep()
+    m.LzfseRingDecoder(context=ctx, window=1 << 16, zero_copy=False).decode(PieceReader(enc, [9000]), k)
     assert all(isinstance(p, bytes) for p in k.pieces) and b"".join(k.pieces) == raw
     out = io.BytesIO()
-    m.LzfseRingDecoder(context=ctx, window=1 << 16, zero_copy=True).decode(PieceReader(enc, [9000]), out)
+    m.LzfseRingDecoder(context=ctx, window=1 << 16).decode(PieceReader(enc, [9000]), out)
     assert out.getvalue() == raw
