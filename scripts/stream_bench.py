@@ -2,6 +2,7 @@
 stream: host-pointer rates, PCIe included.
     python scripts/stream_bench.py [MB]"""
 import hashlib
+import numpy as np
 import io
 import os
 import sys
@@ -75,6 +76,29 @@ def main():
             dt = time.perf_counter() - t
         assert (u, v, s.n) == (len(raw), len(want), len(want))
         print(f"stream encode, window {window >> 20:3d} MiB: {len(raw) / dt / 1e6:9.1f} MB/s")
+
+    # ---- the C entry points by themselves: no Python reader (pieces are views of one array), a sink that only counts ----
+    import ctypes as C
+    from lzfse_rust_amd import _native
+    lib = ctx._lib
+    a = np.frombuffer(raw, dtype=np.uint8)
+    for window in (16 << 20, 64 << 20):
+        for _ in range(2):
+            h = C.c_void_p()
+            assert lib.lzfse_mi_estream_create(ctx._h, window, C.byref(h)) == 0
+            got = [0]
+            cb = _native.WRITE_FN(lambda u, p, n: (got.__setitem__(0, got[0] + n), 0)[1])
+            t = time.perf_counter()
+            for o in range(0, a.size, 1 << 20):
+                piece = a[o:o + (1 << 20)]
+                assert lib.lzfse_mi_estream_feed(h, piece.ctypes.data, piece.size, cb, None) == 0
+            u, v = C.c_uint64(0), C.c_uint64(0)
+            assert lib.lzfse_mi_estream_finish(h, cb, None, C.byref(u), C.byref(v)) == 0
+            dt = time.perf_counter() - t
+            lib.lzfse_mi_estream_destroy(h)
+        assert got[0] == len(want)
+        print(f"stream encode, window {window >> 20:3d} MiB, lzfse_mi_estream_* called directly (1 MiB pieces, counting sink): {len(raw) / dt / 1e6:9.1f} MB/s")
+
 
 if __name__ == "__main__":
     main()
