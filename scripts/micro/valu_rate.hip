@@ -1,12 +1,13 @@
 // What does a wave64 vector instruction cost a gfx950 SIMD? (the question under "what bounds enc_cand": DESIGN.md section 3)
 //
 // Every wave runs a long stream of INDEPENDENT instructions of one kind (8 rotating destination registers, so no instruction
-// waits for the one before it), W waves per SIMD on every CU of the chip. Reported: cycles per wave-instruction per SIMD =
-// elapsed shader cycles / (W x instructions per wave). The elapsed cycles are the slowest wave's own s_memtime span (a tick is
-// one shader cycle on gfx950: memtime_rate.hip) -- waves of one SIMD start together and share it for the whole run -- and the
-// wave placement is checked through HW_REG_HW_ID (every SIMD must hold exactly W waves).
+// waits for the one before it; one row runs a dependent chain on purpose), W waves per SIMD on every CU of the chip: one
+// workgroup of 256 threads is one wave per SIMD of a CU, W workgroups per CU. Reported: s_memtime ticks per wave-instruction per
+// SIMD = the slowest wave's own span / (W x instructions per wave); a tick is one shader cycle at 2.39 GHz (memtime_rate.hip), the
+// last column is that span against the host's wall time of the W = 8 launch. (s_memtime counts per XCD: spans of single waves
+// are compared, never stamps of different waves.)
 //
-//   hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_rate scripts/micro/valu_rate.hip && /tmp/valu_rate
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_rate scripts/micro/valu_rate.hip && /tmp/valu_rate     (profiles/r04_valu_rate.txt)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
