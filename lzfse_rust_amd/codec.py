@@ -272,7 +272,16 @@ class LzfseWriter:
 
         def _write(_user, p, n):
             try:
-                self._sink(C.string_at(p, n))
+                # (as in LzfseRingDecoder: a view of the library's buffer, released after the call, so that a sink that keeps it
+                # fails loudly later instead of reading a reused buffer; file objects, hashers, `bytearray +=` copy what they need)
+                if not n:
+                    self._sink(b"")
+                else:
+                    view = memoryview((C.c_uint8 * n).from_address(C.addressof(p.contents)))
+                    try:
+                        self._sink(view)
+                    finally:
+                        view.release()
                 return 0
             except Exception as e:   # the sink's error travels back through the C layer as LZFSE_MI_IO
                 self._failure.append(e)
