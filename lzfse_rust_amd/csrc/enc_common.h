@@ -124,10 +124,36 @@ struct EncStream {       // one input stream (n > VN_CUTOFF) of the batch
     uint32_t st_skip;   // bytes of the window's first event (its literals, then its match) that the window before has emitted already
 };
 
-struct SpecEvent {   // one emitted match of a segment walker + the walker state after it
-    uint32_t e_idx, e_len, e_dist, e_lit;          // match and literal_index before it
-    uint32_t index_after, p_idx, p_midx, p_len;    // state after (pending zeroed when empty)
-};
+// One emitted match of a segment walker + the walker state after it, in 16 bytes (round 4; eight plain words before: the
+// events were 2.4 of the 43 bytes of HBM traffic per input byte written by the walkers and read again by the sync search and the
+// compaction). A walker starts at its segment's first position S with literal_index = S and visits positions below
+// S + seg + OVER < S + 4096, so everything it logs lies within 12 bits of something else in the event:
+//   x  e_idx
+//   y  e_dist (18) | e_idx - literal_index before (12) | p_len bits 1:0
+//   z  pending: p_idx - p_midx (18) | index_after - p_idx (12) | p_len bits 3:2      (0 when nothing is pending)
+//   w  e_len (15: <= XCAP + a backward extension inside the walk) | index_after - (e_idx + e_len) (12) | p_len bits 5:4
+// (a pending match is shorter than GOOD_MATCH_LEN = 40, match_object.rs:12-33, and after an emit one is pending only when the
+// pending one before it was emitted and the incoming match took its place: index_after = p + 1, p_idx = p - backward length)
+typedef uint4 SpecEvent;
+static_assert(SEG + OVER < 4096 && XCAP + SEG + OVER < 32768, "SpecEvent's fields");
+__device__ __forceinline__ SpecEvent ev_pack(uint32_t e_idx, uint32_t e_len, uint32_t e_dist, uint32_t e_lit, uint32_t index_after,
+                                             uint32_t p_idx, uint32_t p_midx, uint32_t p_len) {
+    SpecEvent e;
+    e.x = e_idx;
+    e.y = e_dist | ((e_idx - e_lit) << 18) | (p_len << 30);
+    e.z = p_len ? ((p_idx - p_midx) | ((index_after - p_idx) << 18) | ((p_len >> 2) << 30)) : 0u;
+    e.w = e_len | ((index_after - (e_idx + e_len)) << 15) | ((p_len >> 4) << 27);
+    return e;
+}
+__device__ __forceinline__ uint32_t ev_idx(const SpecEvent &e) { return e.x; }
+__device__ __forceinline__ uint32_t ev_len(const SpecEvent &e) { return e.w & 0x7FFFu; }
+__device__ __forceinline__ uint32_t ev_dist(const SpecEvent &e) { return e.y & 0x3FFFFu; }
+__device__ __forceinline__ uint32_t ev_lit(const SpecEvent &e) { return e.x - ((e.y >> 18) & 0xFFFu); }        // literal_index before the match
+__device__ __forceinline__ uint32_t ev_lit_after(const SpecEvent &e) { return e.x + (e.w & 0x7FFFu); }
+__device__ __forceinline__ uint32_t ev_index_after(const SpecEvent &e) { return e.x + (e.w & 0x7FFFu) + ((e.w >> 15) & 0xFFFu); }
+__device__ __forceinline__ uint32_t ev_plen(const SpecEvent &e) { return (e.y >> 30) | ((e.z >> 30) << 2) | (((e.w >> 27) & 3u) << 4); }
+__device__ __forceinline__ uint32_t ev_pidx(const SpecEvent &e) { return ev_index_after(e) - ((e.z >> 18) & 0xFFFu); }
+__device__ __forceinline__ uint32_t ev_pmidx(const SpecEvent &e) { return ev_pidx(e) - (e.z & 0x3FFFFu); }
 struct SpecHeader {
     uint32_t n_events, status;                     // status 1: aborted on a record needing an exact length
     uint32_t f_index, f_lit, f_pidx, f_pmidx, f_plen, pad;  // final state

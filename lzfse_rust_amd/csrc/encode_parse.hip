@@ -209,24 +209,27 @@ __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict_
     WState st;
     st.index = exists ? S : 0; st.lit = S; st.p_idx = 0; st.p_midx = 0; st.p_len = 0;
     uint32_t nev = 0, status = 0;
-    // Event log through LDS: a lane's events are 32 bytes each at its own place in memory, so storing them one by one
-    // costs two 16-byte write requests per event and lane, and the store rate is what this kernel pays for most after the
+    // Event log through LDS: a lane's events are 16 bytes each at its own place in memory, so storing them one by one
+    // costs a write request per event and lane, and the store rate is what this kernel pays for most after the
     // record gathers. A lane collects SPEC_STAGE events in LDS (slot-major: the lanes' events of one slot are adjacent,
-    // no bank conflicts); when its stage is full the wave writes those bytes as whole lines, one lane per 16 bytes.
+    // no bank conflicts); when its stage is full the wave writes those bytes as whole lines, one lane per event.
     // (STAGED = false, small batches: every event is stored at once; such a launch is one round of resident waves whose
     // time is the longest walk, and the flush loops would only lengthen its steps)
-    constexpr uint32_t SPEC_STAGE = 8;
-    __shared__ uint4 s_stage[STAGED ? SPEC_STAGE : 1][STAGED ? 64 : 1][2];
+#ifndef LZMI_SPEC_STAGE
+#define LZMI_SPEC_STAGE 8
+#endif
+    constexpr uint32_t SPEC_STAGE = LZMI_SPEC_STAGE;
+    __shared__ SpecEvent s_stage[STAGED ? SPEC_STAGE : 1][STAGED ? 64 : 1];
     uint32_t n_staged = 0;      // events of this lane in LDS (they follow the nev - n_staged events already in memory)
     auto flush_full = [&](uint64_t who) {
-        // every lane in `who` has its stage written out: lanes 0 .. 2 * count - 1 move 16 bytes each
+        // every lane in `who` has its stage written out: lanes 0 .. count - 1 move one event each
         while (who) {
             const int L = __builtin_ctzll(who);
             who &= who - 1;
             const uint32_t cnt = e_readlane(n_staged, L), done = e_readlane(nev, L) - cnt;
             const uint64_t eb = ((uint64_t)e_readlane((uint32_t)((uintptr_t)ev >> 32), L) << 32) | e_readlane((uint32_t)(uintptr_t)ev, L);
-            uint4 *dst = reinterpret_cast<uint4 *>((SpecEvent *)(uintptr_t)eb + done);
-            if ((uint32_t)lane < 2 * cnt) dst[lane] = s_stage[lane >> 1][L][lane & 1];
+            SpecEvent *dst = (SpecEvent *)(uintptr_t)eb + done;
+            if ((uint32_t)lane < cnt) dst[lane] = s_stage[lane][L];
         }
     };
     uint32_t cw = NONE - 1;  // word index of w0 (w1 is the following word); nothing cached yet
@@ -315,10 +318,9 @@ __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict_
                     st.lit = e_idx + e_len;
                     st.index = (p + 1 > st.lit) ? p + 1 : st.lit;
                     if (nev < ev_cap) {
-                        const uint4 h0 = make_uint4(e_idx, e_len, e_idx - e_midx, lit_before);   // SpecEvent, first half
-                        const uint4 h1 = make_uint4(st.index, st.p_len ? st.p_idx : 0, st.p_len ? st.p_midx : 0, st.p_len);
-                        if (STAGED) { s_stage[n_staged][lane][0] = h0; s_stage[n_staged][lane][1] = h1; n_staged++; }
-                        else { uint4 *de = reinterpret_cast<uint4 *>(ev + nev); de[0] = h0; de[1] = h1; }
+                        const SpecEvent h = ev_pack(e_idx, e_len, e_idx - e_midx, lit_before, st.index, st.p_idx, st.p_midx, st.p_len);
+                        if (STAGED) s_stage[n_staged++][lane] = h;
+                        else ev[nev] = h;
                         nev++;
                     } else nev = ev_cap + 1;   // (log overflow: cannot happen, reported below)
                 } else {
@@ -357,9 +359,16 @@ __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict_
 
 // ------------------------------------------------------------------------------------ stitch
 
+// the walker state after two events is the same (index, literal_index, pending match; with equal indices the pending
+// matches are equal when their packed fields are)
 __device__ __forceinline__ bool ev_state_eq(const SpecEvent &a, const SpecEvent &b) {
-    return a.index_after == b.index_after && a.e_idx + a.e_len == b.e_idx + b.e_len && a.p_len == b.p_len &&
-           (a.p_len == 0 || (a.p_idx == b.p_idx && a.p_midx == b.p_midx));
+    return ev_index_after(a) == ev_index_after(b) && ev_lit_after(a) == ev_lit_after(b) && a.z == b.z &&
+           ((a.y ^ b.y) >> 30) == 0 && ((a.w ^ b.w) >> 27) == 0;
+}
+// ... and the state after an event is this one
+__device__ __forceinline__ bool ev_state_is(const SpecEvent &e, const WState &T) {
+    return ev_index_after(e) == T.index && ev_lit_after(e) == T.lit && ev_plen(e) == T.p_len &&
+           (T.p_len == 0 || (ev_pidx(e) == T.p_idx && ev_pmidx(e) == T.p_midx));
 }
 
 // first event of a log with index_after >= key
@@ -367,7 +376,7 @@ __device__ __forceinline__ uint32_t ev_lower_bound(const SpecEvent *ev, uint32_t
     uint32_t lo = 0, hi = n;
     while (lo < hi) {
         uint32_t mid = (lo + hi) >> 1;
-        if (ev[mid].index_after < key) lo = mid + 1; else hi = mid;
+        if (ev_index_after(ev[mid]) < key) lo = mid + 1; else hi = mid;
     }
     return lo;
 }
@@ -386,10 +395,11 @@ __global__ __launch_bounds__(64) void enc_sync_kernel(const EncStream *__restric
         const SpecEvent *Lk = logs + (uint64_t)g * seg_ev_cap(seg), *Lk1 = Lk + seg_ev_cap(seg);
         uint32_t i = ev_lower_bound(Lk, nk, (sg.y + 1) * seg), j = 0;
         while (i < nk && j < nk1) {
-            const uint32_t ia = Lk[i].index_after, ja = Lk1[j].index_after;
+            const SpecEvent ei = Lk[i], ej = Lk1[j];
+            const uint32_t ia = ev_index_after(ei), ja = ev_index_after(ej);
             if (ia < ja) i++;
             else if (ia > ja) j++;
-            else if (ev_state_eq(Lk[i], Lk1[j])) { out = make_uint4(1, i, j, 0); break; }
+            else if (ev_state_eq(ei, ej)) { out = make_uint4(1, i, j, 0); break; }
             else { i++; j++; }
         }
     }
@@ -640,10 +650,7 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
                 const SpecEvent *Lkk = L0 + (uint64_t)kk * ev_cap;
                 uint32_t j = ev_lower_bound(Lkk, hh.n_events, T.index);
                 if (j < hh.n_events) {
-                    SpecEvent t;
-                    t.index_after = T.index; t.e_idx = T.lit; t.e_len = 0;
-                    t.p_idx = T.p_idx; t.p_midx = T.p_midx; t.p_len = T.p_len;
-                    if (ev_state_eq(t, Lkk[j])) {
+                    if (ev_state_is(Lkk[j], T)) {
                         sx_close_gap(x);
                         k = kk; a = j + 1;
                         walking = false;
@@ -716,7 +723,7 @@ __global__ __launch_bounds__(64) void enc_compact_kernel(const EncStream *__rest
         if (q < rg.count) {
             if (rg.kind == 0) {
                 const SpecEvent e = ev[q];
-                m.lit_pos = e.e_lit; m.l = e.e_idx - e.e_lit; m.m = e.e_len; m.d = e.e_dist;
+                m.lit_pos = ev_lit(e); m.l = ev_idx(e) - m.lit_pos; m.m = ev_len(e); m.d = ev_dist(e);
             } else {
                 m = g[q];
             }
@@ -1246,8 +1253,9 @@ __global__ __launch_bounds__(64) void enc_cut_kernel(const EncStream *__restrict
             const uint64_t at = r.begin + (ord - r.out_off);
             if (r.kind == 0) {
                 const SpecEvent ev = logs[at];
-                lit = ev.e_idx + ev.e_len;
-                return make_uint4(ev.index_after, ev.p_idx, ev.p_midx, ev.p_len);
+                const uint32_t pl = ev_plen(ev);
+                lit = ev_lit_after(ev);
+                return make_uint4(ev_index_after(ev), pl ? ev_pidx(ev) : 0u, pl ? ev_pmidx(ev) : 0u, pl);
             }
             const MatchRec m = (gaps + es.match_base)[at];
             lit = m.lit_pos + m.l + m.m;
