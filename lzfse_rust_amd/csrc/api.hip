@@ -14,6 +14,7 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <sys/mman.h>
 #include <thread>
 
 #include "common.h"
@@ -148,6 +149,7 @@ struct lzfse_mi_ctx {
     std::vector<lzfse_mi_ctx **> stream_refs;   // the `ctx` members of the stream objects alive on this context (ctx_attach)
     std::mutex stream_refs_m;
     lzmi::EncWindow *window = nullptr;   // set for the duration of one window of a stream encode (stream.hip)
+    bool pinned_out = false;             // ... of one window of either stream object: the destination is pinned memory
     bool parse_ring = false;   // set for the duration of a ring / stream encode call (lzfse_mi_encode_ring*, lzfse_mi_estream_*)
     int diag_lz_jump = -1, diag_lz_variant = -1, diag_stats = 0, diag_chain = 0, diag_walk = 0, diag_pipe_scatter = 0;  // diagnostic build only
     uint64_t diag_last_lmds = 0;   // LMD records the entropy stage of the last decode pass on this context left in d_lmds (stage hook)
@@ -193,6 +195,7 @@ void ctx_detach(lzfse_mi_ctx *c, lzfse_mi_ctx **ref) {
         if (c->stream_refs[k] == ref) { c->stream_refs[k] = c->stream_refs.back(); c->stream_refs.pop_back(); break; }
 }
 void ctx_set_window(lzfse_mi_ctx *c, EncWindow *w) { c->window = w; }
+void ctx_set_pinned_out(lzfse_mi_ctx *c, bool on) { c->pinned_out = on; }
 int ctx_diag_chain(lzfse_mi_ctx *c) { return c->diag_chain; }
 }  // namespace lzmi
 
@@ -332,7 +335,7 @@ void lzfse_mi_destroy(lzfse_mi_ctx *c) {
     c->h_in.release();
     c->h_out.release();
     c->h_small.release();
-    std::free(c->spare.p[0]); std::free(c->spare.p[1]);
+    for (auto &b : c->spare.b) b.release();
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -950,10 +953,7 @@ int lzfse_mi_set_option(lzfse_mi_ctx *c, int option, int64_t value) {
         if (value != 0 && value != 1) return LZFSE_MI_BAD_ARGUMENT;
         c->spare.keep = value != 0;
         if (!c->spare.keep) {
-            for (int k = 0; k < 2; k++) {
-                std::free(c->spare.p[k]); c->spare.p[k] = nullptr; c->spare.cap[k] = 0;
-                std::vector<uint8_t>().swap(c->spare.v[k]);
-            }
+            for (auto &b : c->spare.b) b.release();
         }
         return LZFSE_MI_OK;
     case LZFSE_MI_OPT_DECODE_PIPE:
@@ -991,6 +991,68 @@ struct CopyJob {
     size_t len;
 };
 
+// helper threads that live as long as the context (a thread per granule and call costs as much as the copy it does);
+// returns how many of the `want` there are
+static unsigned copy_helpers(lzfse_mi_ctx *c, unsigned want) {
+    while (c->copy_workers.size() < want) {
+        LaneWorker *w = nullptr;
+        try { w = new (std::nothrow) LaneWorker(); } catch (...) { w = nullptr; }   // (no thread to be had: fewer helpers)
+        if (!w) break;
+        c->copy_workers.push_back(w);
+    }
+    return (unsigned)std::min<size_t>(want, c->copy_workers.size());
+}
+
+// A destination that has never been touched -- the Vec<u8> a binding has just made: a large malloc is an mmap -- is faulted in
+// page by page by whoever writes it first. The helper threads do that while the kernels run: MADV_POPULATE_WRITE maps the
+// pages writable without changing what they hold (Linux 5.14; anything it refuses is simply left to the copy). 256 MiB
+// decoded into fresh memory: 25.8 -> 17.3 ms, the time of a buffer used before (scripts/fresh_dst.py, profiles/r04_fresh_dst.txt).
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
+struct Populate {
+    lzfse_mi_ctx *c = nullptr;
+    unsigned busy = 0;
+    std::vector<std::pair<uintptr_t, uintptr_t>> spans;   // page-aligned [lo, hi)
+    void add(const void *p, uint64_t len) {
+        if (len < ((uint64_t)1 << 20)) return;
+        const uintptr_t lo = (uintptr_t)p & ~(uintptr_t)4095, hi = ((uintptr_t)p + len + 4095) & ~(uintptr_t)4095;
+        spans.push_back({lo, hi});
+    }
+    void start(lzfse_mi_ctx *ctx) {
+        uint64_t total = 0;
+        for (auto &s : spans) total += s.second - s.first;
+        if (total < ((uint64_t)4 << 20)) return;
+        c = ctx;
+        const unsigned hc = std::thread::hardware_concurrency();
+        unsigned T = std::min<unsigned>(8u, std::max<unsigned>(1u, hc / 2));
+        T = (unsigned)std::min<uint64_t>(T, total >> 21);
+        busy = copy_helpers(c, T);
+        for (unsigned t = 0; t < busy; t++) {
+            const uint64_t a = total * t / busy, b = total * (t + 1) / busy;
+            c->copy_workers[t]->submit([this, a, b] {
+                uint64_t at = 0;
+                for (auto &s : spans) {
+                    const uint64_t len = s.second - s.first;
+                    const uint64_t x = std::max(a, at), y = std::min(b, at + len);
+                    if (x < y) {
+                        // (whole pages: a page that two threads share is asked for twice, which is harmless)
+                        const uintptr_t lo = (s.first + (x - at)) & ~(uintptr_t)4095, hi = (s.first + (y - at) + 4095) & ~(uintptr_t)4095;
+                        for (uintptr_t q = lo; q < hi; q += (uintptr_t)8 << 20)
+                            if (madvise((void *)q, std::min<uintptr_t>(hi - q, (uintptr_t)8 << 20), MADV_POPULATE_WRITE)) break;
+                    }
+                    at += len;
+                }
+            });
+        }
+    }
+    void finish() {
+        for (unsigned t = 0; t < busy; t++) c->copy_workers[t]->wait();
+        busy = 0;
+    }
+    ~Populate() { finish(); }
+};
+
 // bytes [lo, hi) of the concatenation of the jobs, shared by a few threads
 static void par_copy(lzfse_mi_ctx *c, const std::vector<CopyJob> &jobs, const std::vector<uint64_t> &pre, uint64_t lo, uint64_t hi) {
     if (hi <= lo) return;
@@ -1010,13 +1072,7 @@ static void par_copy(lzfse_mi_ctx *c, const std::vector<CopyJob> &jobs, const st
             if (x < y) memcpy(j.dst + (x - pre[k]), j.src + (x - pre[k]), (size_t)(y - x));
         }
     };
-    // helper threads that live as long as the context (a thread per granule and call costs as much as the copy it does)
-    while (T > 1 && c->copy_workers.size() + 1 < T) {
-        LaneWorker *w = nullptr;
-        try { w = new (std::nothrow) LaneWorker(); } catch (...) { w = nullptr; }   // (no thread to be had: fewer helpers)
-        if (!w) { T = (unsigned)c->copy_workers.size() + 1; break; }
-        c->copy_workers.push_back(w);
-    }
+    T = copy_helpers(c, T - 1) + 1;
     if (T <= 1) { T = 1; work(0); return; }
     for (unsigned t = 1; t < T; t++) c->copy_workers[t - 1]->submit([&work, t] { work(t); });
     work(0);
@@ -1040,8 +1096,12 @@ static uint64_t staged_at(const std::vector<CopyJob> &jobs, const std::vector<ui
 #ifndef HOST_DIRECT_IN
 #define HOST_DIRECT_IN ((uint64_t)1 << 20)
 #endif
+// Outputs below 512 MiB do NOT travel that way (round 4): a transfer straight into pageable memory pins what it lands in, and for a
+// destination that is the untouched tail of a large allocation -- Vec::with_capacity(encode_bound) + 31 MB of stream -- that
+// took 27 - 38 ms where the staged form takes 10.8 (128 MiB of text encoded; scripts/fresh_dst.py); on a buffer used before the
+// two forms are within 7 % of each other either way.
 #ifndef HOST_DIRECT_OUT
-#define HOST_DIRECT_OUT ((uint64_t)1 << 20)
+#define HOST_DIRECT_OUT ((uint64_t)512 << 20)   // (beyond that a second copy of the output in pinned memory is the larger evil)
 #endif
 
 static int host_batch_one(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, size_t count, const uint8_t *const *srcs,
@@ -1051,6 +1111,7 @@ static int host_batch_one(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, s
     if (count == 0) { if (on_staged) (*on_staged)(); return LZFSE_MI_OK; }
     HIP_TRY(hipSetDevice(c->device));
     std::vector<uint64_t> so(count), sl(count), dof(count), dc(count), ol(count);
+    const uint64_t direct_out = c->pinned_out ? (uint64_t)1 << 20 : HOST_DIRECT_OUT;   // (a stream object's window: plain DMA into its pinned buffer)
     // device layout: the staged (small) streams first, in the caller's order, then the direct (large) ones
     uint64_t in_total = 0, out_total = 0, in_staged = 0, out_staged = 0;
     for (int big = 0; big < 2; big++) {
@@ -1060,7 +1121,7 @@ static int host_batch_one(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, s
     }
     for (int big = 0; big < 2; big++) {
         for (size_t i = 0; i < count; i++)
-            if ((caps[i] >= HOST_DIRECT_OUT) == (big != 0)) { dof[i] = out_total; dc[i] = caps[i]; out_total += (caps[i] + 255) & ~(uint64_t)255; }
+            if ((caps[i] >= direct_out) == (big != 0)) { dof[i] = out_total; dc[i] = caps[i]; out_total += (caps[i] + 255) & ~(uint64_t)255; }
         if (!big) out_staged = out_total;
     }
     if (!c->d_in.ensure(in_total + 256) || !c->d_out.ensure(out_total + 256) || !c->h_in.ensure(in_staged + 256))
@@ -1081,7 +1142,23 @@ static int host_batch_one(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, s
     for (size_t i = 0; i < count; i++)
         if (lens[i] >= HOST_DIRECT_IN) HIP_TRY(hipMemcpyAsync((uint8_t *)c->d_in.p + so[i], srcs[i], lens[i], hipMemcpyHostToDevice, c->stream));
     if (on_staged) (*on_staged)();   // (the inputs are on their way: the other half of a split call may start staging)
+    // while the kernels run, the helper threads fault in the large destinations: all of a decoded stream's (its capacity is
+    // its size unless the caller was generous: then what the headers say), 3/8 of the input for an encoded one
+    Populate pop;
+    for (size_t i = 0; i < count; i++) {
+        if (caps[i] < ((uint64_t)1 << 20) || c->pinned_out) continue;
+        uint64_t want = caps[i];
+        if (pack_outputs) want = std::min<uint64_t>(want, (uint64_t)lens[i] / 8 * 3);
+        else {
+            uint64_t promised = 0;
+            (void)lzfse_mi_decode_size(srcs[i], lens[i], &promised);
+            want = std::min<uint64_t>(want, promised);
+        }
+        pop.add(dsts[i], want);
+    }
+    pop.start(c);
     int r = fn(c, count, c->d_in.p, so.data(), sl.data(), c->d_out.p, dof.data(), dc.data(), ol.data(), statuses);
+    pop.finish();
     if (r) return r;
     // ---- out: where each stream's bytes are on the device (packed first when they fill little of their capacity) ----
     std::vector<uint64_t> at(count);        // offset of stream i's output in the buffer that travels
@@ -1097,7 +1174,7 @@ static int host_batch_one(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, s
     const uint8_t *d_from = (const uint8_t *)c->d_out.p;
     uint64_t staged_span = out_staged;      // the staged outputs lie in [0, staged_span) of the buffer that travels
     std::vector<uint8_t> big_out(count);    // which outputs travel by a transfer of their own: by capacity (the layout) ...
-    for (size_t i = 0; i < count; i++) big_out[i] = caps[i] >= HOST_DIRECT_OUT;
+    for (size_t i = 0; i < count; i++) big_out[i] = caps[i] >= direct_out;
     if (pack_outputs && fits32 && produced + (produced >> 2) < hi_off) {
         uint64_t pk = 0;
         std::vector<SmallDesc> desc;
@@ -1105,7 +1182,7 @@ static int host_batch_one(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, s
         desc.reserve(count);
         uint64_t pk_staged = 0;
         // ... or, when the outputs are packed anyway (encoded streams: a third of their capacity), by what they really hold
-        for (size_t i = 0; i < count; i++) big_out[i] = out_lens[i] >= HOST_DIRECT_OUT;
+        for (size_t i = 0; i < count; i++) big_out[i] = out_lens[i] >= direct_out;
         for (int big = 0; big < 2; big++) {   // (staged streams first)
             for (size_t i = 0; i < count; i++) {
                 if ((big_out[i] != 0) != (big != 0)) continue;
@@ -1128,7 +1205,7 @@ static int host_batch_one(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, s
             at = packed;
             staged_span = pk_staged;
         } else {
-            for (size_t i = 0; i < count; i++) big_out[i] = caps[i] >= HOST_DIRECT_OUT;
+            for (size_t i = 0; i < count; i++) big_out[i] = caps[i] >= direct_out;
         }
     }
     if (!c->h_out.ensure(staged_span + 256)) return LZFSE_MI_IO;

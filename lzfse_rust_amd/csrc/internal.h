@@ -2,7 +2,9 @@
 #pragma once
 #include "common.h"
 
+#include <algorithm>
 #include <chrono>
+#include <cstring>
 #include <condition_variable>
 #include <mutex>
 #include <vector>
@@ -52,13 +54,43 @@ struct EncWindow {
     uint32_t found = 0, index = 0, lit = 0, p_idx = 0, p_midx = 0, p_len = 0, skip_out = 0;
 };
 EncWindow *ctx_window(lzfse_mi_ctx *c);
-// Host buffers of the stream objects (stream.hip) that outlive them: a stream object's window buffers are tens of MiB, and
-// pages touched for the first time cost more than the window's decode -- the next stream object of the context takes over
-// what the last one left (slot 0: decode output, 1: encode output; malloc'd) and the vectors (0: decoder input, 1: encoder input).
+// A growable byte buffer in PINNED host memory (hipHostMalloc): what the stream objects (stream.hip) keep their windows in, so
+// that a window travels by plain DMA in both directions -- a transfer from or to pageable memory is pinned page by page by the
+// runtime first, every time (64 MiB windows: stream decode 10.0 -> see profiles/r04_stream_bench.txt).
+struct PinBuf {
+    uint8_t *p = nullptr;
+    size_t size = 0, cap = 0;
+    PinBuf() = default;
+    PinBuf(const PinBuf &) = delete;
+    PinBuf &operator=(const PinBuf &) = delete;
+    ~PinBuf() { release(); }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; size = cap = 0; }
+    void swap(PinBuf &o) { std::swap(p, o.p); std::swap(size, o.size); std::swap(cap, o.cap); }
+    // room for n bytes; keep: the bytes held stay (false: they may be dropped -- no copy into the new room)
+    bool reserve(size_t n, bool keep = true) {
+        if (n <= cap) return true;
+        void *q = nullptr;
+        if (hipHostMalloc(&q, n, hipHostMallocDefault) != hipSuccess) return false;
+        if (keep && size) std::memcpy(q, p, size);
+        if (!keep) size = 0;
+        if (p) (void)hipHostFree(p);
+        p = (uint8_t *)q; cap = n;
+        return true;
+    }
+    bool append(const uint8_t *src, size_t n) {
+        if (!n) return true;
+        if (size + n > cap && !reserve(std::max<size_t>(std::max(size + n, 2 * cap), (size_t)256 << 10))) return false;
+        std::memcpy(p + size, src, n);
+        size += n;
+        return true;
+    }
+    void erase_front(size_t k) { std::memmove(p, p + k, size - k); size -= k; }
+};
+// Host buffers of the stream objects that outlive them: a stream object's window buffers are tens of MiB, and pinned pages
+// cost more to get than the window's decode -- the next stream object of the context takes over what the last one left
+// (0: decoder input, 1: decoder output, 2: encoder input, 3: encoder output).
 struct StreamSpare {
-    uint8_t *p[2] = {nullptr, nullptr};
-    size_t cap[2] = {0, 0};
-    std::vector<uint8_t> v[2];
+    PinBuf b[4];
     bool keep = true;   // LZFSE_MI_OPT_STREAM_SPARE
 };
 StreamSpare &ctx_spare(lzfse_mi_ctx *c);
@@ -68,6 +100,8 @@ StreamSpare &ctx_spare(lzfse_mi_ctx *c);
 void ctx_attach(lzfse_mi_ctx *c, lzfse_mi_ctx **ref);
 void ctx_detach(lzfse_mi_ctx *c, lzfse_mi_ctx **ref);
 void ctx_set_window(lzfse_mi_ctx *c, EncWindow *w);
+// the destination of the host-pointer call that follows is pinned memory: its output travels straight there (stream.hip)
+void ctx_set_pinned_out(lzfse_mi_ctx *c, bool on);
 int ctx_diag_chain(lzfse_mi_ctx *c);  // LZFSE_MI_OPT_DIAG_CHAIN: 1 = every chain tile through the ballot kernel
 
 // ---- decode.hip ----

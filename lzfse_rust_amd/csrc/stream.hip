@@ -24,22 +24,25 @@ using namespace lzmi;
 struct lzfse_mi_dstream {
     lzfse_mi_ctx *ctx = nullptr;
     size_t window = 0;
-    std::vector<uint8_t> in;       // bytes fed; in[in_pos..] are not yet decoded
+    PinBuf in;                     // bytes fed; in[in_pos..] are not yet decoded (pinned memory, like `dst`: a window is two plain DMAs)
     size_t in_pos = 0;
     size_t scan_span = 0;          // the blocks in[in_pos .. in_pos + scan_span) are known to be complete (the scan goes on from there) ...
     uint64_t scan_raw = 0;         // ... and hold this many raw bytes
     std::vector<uint8_t> hist;     // the last <= MAX_D_VALUE bytes of output
     std::vector<uint8_t> tmp_src;
-    uint8_t *tmp_dst = nullptr;    // malloc'd, never zero-filled: a damaged header may promise gigabytes that are never written
-    size_t tmp_dst_cap = 0;
+    PinBuf dst;                    // one window's output ...
+    uint8_t *far_dst = nullptr;    // ... unless a (damaged) header promises more than a GiB: malloc'd, never touched beyond what is written
+    size_t far_cap = 0;
+    uint8_t *out_p() const { return far_dst ? far_dst : dst.p; }
     ~lzfse_mi_dstream() {
         // (what this object's windows grew stays with the context for the next stream object -- if the context is still there
         // and keeps such buffers: ctx is null once lzfse_mi_destroy has run, LZFSE_MI_OPT_STREAM_SPARE)
-        if (!ctx) { std::free(tmp_dst); return; }
+        std::free(far_dst);
+        if (!ctx) return;
         ctx_detach(ctx, &ctx);
         StreamSpare &sp = ctx_spare(ctx);
-        if (sp.keep && tmp_dst_cap > sp.cap[0]) { std::free(sp.p[0]); sp.p[0] = tmp_dst; sp.cap[0] = tmp_dst_cap; } else std::free(tmp_dst);
-        if (sp.keep && in.capacity() > sp.v[0].capacity()) { in.clear(); sp.v[0].swap(in); }
+        if (sp.keep && in.cap > sp.b[0].cap) { in.size = 0; sp.b[0].swap(in); }
+        if (sp.keep && dst.cap > sp.b[1].cap) { dst.size = 0; sp.b[1].swap(dst); }
     }
     uint64_t total_in = 0, total_out = 0;
     int status = 0;                // sticky
@@ -86,21 +89,17 @@ int block_extent(const uint8_t *p, size_t avail, uint64_t &len, uint64_t &n_raw,
 }
 
 bool grow_dst(lzfse_mi_dstream *s, uint64_t cap) {
-    if (s->tmp_dst_cap >= cap + 64) return true;
-    std::free(s->tmp_dst);
-    s->tmp_dst_cap = 0;
-    // (with room to spare: windows end at block boundaries, so their sizes differ by a block or two, and a buffer that fits
-    // the largest one so far exactly is thrown away by every window that is a little larger -- fresh pages cost more than the decode)
-    const uint64_t want = cap + cap / 8 + ((uint64_t)1 << 20);
-    s->tmp_dst = (uint8_t *)std::malloc((size_t)want + 64);
-    if (!s->tmp_dst) {
-        s->tmp_dst = (uint8_t *)std::malloc((size_t)cap + 64);
-        if (!s->tmp_dst) return false;
-        s->tmp_dst_cap = (size_t)cap + 64;
-        return true;
+    std::free(s->far_dst); s->far_dst = nullptr; s->far_cap = 0;
+    if (cap > ((uint64_t)1 << 30)) {
+        s->far_dst = (uint8_t *)std::malloc((size_t)cap + 64);
+        s->far_cap = s->far_dst ? (size_t)cap + 64 : 0;
+        return s->far_dst != nullptr;
     }
-    s->tmp_dst_cap = (size_t)want + 64;
-    return true;
+    if (s->dst.cap >= cap + 64) return true;
+    // (with room to spare: windows end at block boundaries, so their sizes differ by a block or two, and a buffer that fits
+    // the largest one so far exactly is thrown away by every window that is a little larger -- fresh pinned pages cost more than the decode)
+    const uint64_t want = cap + cap / 8 + ((uint64_t)1 << 20);
+    return s->dst.reserve((size_t)want + 64, false) || s->dst.reserve((size_t)cap + 64, false);
 }
 
 // decode in[0 .. span) as one stream behind the history block; with_eos: the span's blocks are complete and bvx$ is added
@@ -117,20 +116,21 @@ int decode_span(lzfse_mi_dstream *s, size_t span, uint64_t raw, bool with_eos, l
     uint8_t saved[4] = {0, 0, 0, 0};
     size_t old_size = 0, eos_at = 0;
     if (in_place) {
-        old_size = s->in.size();
+        old_size = s->in.size;
         eos_at = s->in_pos + span;
         if (old_size < eos_at + 4) {
-            try { s->in.resize(eos_at + 4); } catch (...) { return LZFSE_MI_IO; }
+            if (!s->in.reserve(eos_at + 4)) return LZFSE_MI_IO;
+            s->in.size = eos_at + 4;
         }
-        uint8_t *p0 = s->in.data() + s->in_pos - head;
+        uint8_t *p0 = s->in.p + s->in_pos - head;
         if (nh) {
             const uint32_t m = MAGIC_RAW, n32 = (uint32_t)nh;
             std::memcpy(p0, &m, 4); std::memcpy(p0 + 4, &n32, 4);
             std::memcpy(p0 + 8, s->hist.data(), nh);
         }
-        std::memcpy(saved, s->in.data() + eos_at, 4);
+        std::memcpy(saved, s->in.p + eos_at, 4);
         const uint32_t m = MAGIC_EOS;
-        std::memcpy(s->in.data() + eos_at, &m, 4);
+        std::memcpy(s->in.p + eos_at, &m, 4);
         src = p0; src_len = head + span + 4;
     } else {
         s->tmp_src.clear();
@@ -141,14 +141,14 @@ int decode_span(lzfse_mi_dstream *s, size_t span, uint64_t raw, bool with_eos, l
             s->tmp_src.insert(s->tmp_src.end(), hd, hd + 8);
             s->tmp_src.insert(s->tmp_src.end(), s->hist.begin(), s->hist.end());
         }
-        s->tmp_src.insert(s->tmp_src.end(), s->in.begin() + s->in_pos, s->in.begin() + s->in_pos + span);
+        s->tmp_src.insert(s->tmp_src.end(), s->in.p + s->in_pos, s->in.p + s->in_pos + span);
         if (with_eos) { const uint32_t m = MAGIC_EOS; const uint8_t *q = (const uint8_t *)&m; s->tmp_src.insert(s->tmp_src.end(), q, q + 4); }
         src = s->tmp_src.data(); src_len = s->tmp_src.size();
     }
     auto put_back = [&] {
         if (!in_place) return;
-        std::memcpy(s->in.data() + eos_at, saved, 4);
-        if (s->in.size() != old_size) s->in.resize(old_size);
+        std::memcpy(s->in.p + eos_at, saved, 4);
+        s->in.size = old_size;
     };
     uint64_t cap64 = nh + raw;
     if (!with_eos) {   // a tail the parser could not delimit: what its headers promise, as the slice path's caller would size it
@@ -158,20 +158,23 @@ int decode_span(lzfse_mi_dstream *s, size_t span, uint64_t raw, bool with_eos, l
     }
     if (!grow_dst(s, cap64)) { put_back(); return LZFSE_MI_IO; }
     size_t got = 0;
-    int st = lzfse_mi_decode(s->ctx, src, src_len, s->tmp_dst, (size_t)cap64, &got);
+    ctx_set_pinned_out(s->ctx, s->far_dst == nullptr);
+    int st = lzfse_mi_decode(s->ctx, src, src_len, s->out_p(), (size_t)cap64, &got);
     if (st == LZFSE_MI_BUFFER_OVERFLOW) {   // the sink is unbounded: find the error the reference's Vec would have met
         cap64 += lzfse_mi_decode_headroom(src, src_len);
-        if (!grow_dst(s, cap64)) { put_back(); return LZFSE_MI_IO; }
-        st = lzfse_mi_decode(s->ctx, src, src_len, s->tmp_dst, (size_t)cap64, &got);
+        if (!grow_dst(s, cap64)) { ctx_set_pinned_out(s->ctx, false); put_back(); return LZFSE_MI_IO; }
+        ctx_set_pinned_out(s->ctx, s->far_dst == nullptr);
+        st = lzfse_mi_decode(s->ctx, src, src_len, s->out_p(), (size_t)cap64, &got);
     }
+    ctx_set_pinned_out(s->ctx, false);
     put_back();
     if (st) return st;
     if (got < nh) return LZFSE_MI_IO;
     const size_t fresh = got - nh;
-    if (fresh && write && write(user, s->tmp_dst + nh, fresh)) return LZFSE_MI_IO;
+    if (fresh && write && write(user, s->out_p() + nh, fresh)) return LZFSE_MI_IO;
     s->total_out += fresh;
     // history for the next window
-    s->hist.assign(s->tmp_dst + (got >= MAX_D_VALUE ? got - MAX_D_VALUE : 0), s->tmp_dst + got);
+    s->hist.assign(s->out_p() + (got >= MAX_D_VALUE ? got - MAX_D_VALUE : 0), s->out_p() + got);
     s->in_pos += span;
     s->total_in += span;
     return 0;
@@ -211,9 +214,9 @@ LZFSE_MI_API int lzfse_mi_dstream_create(lzfse_mi_ctx *ctx, size_t window, lzfse
     s->window = window ? window : (size_t)LZFSE_MI_STREAM_WINDOW;
     {
         StreamSpare &sp = ctx_spare(ctx);
-        s->tmp_dst = sp.p[0]; s->tmp_dst_cap = sp.cap[0]; sp.p[0] = nullptr; sp.cap[0] = 0;
-        s->in.swap(sp.v[0]);
-        s->in.clear();
+        s->in.swap(sp.b[0]);
+        s->dst.swap(sp.b[1]);
+        s->in.size = 0; s->dst.size = 0;
     }
     *out = s;
     return LZFSE_MI_OK;
@@ -236,12 +239,12 @@ LZFSE_MI_API int lzfse_mi_dstream_feed(lzfse_mi_dstream *s, const uint8_t *src, 
         // (consumed input is dropped now and then; MAX_D_VALUE + 8 bytes of it stay in front of the rest: the next window's
         // history block is written there, decode_span)
         constexpr size_t KEEP = (size_t)MAX_D_VALUE + 8;
-        if (s->in_pos > KEEP && s->in_pos - KEEP >= s->in.size() / 2) { s->in.erase(s->in.begin(), s->in.begin() + (s->in_pos - KEEP)); s->in_pos = KEEP; }
-        s->in.insert(s->in.end(), src, src + n);
+        if (s->in_pos > KEEP && s->in_pos - KEEP >= s->in.size / 2) { s->in.erase_front(s->in_pos - KEEP); s->in_pos = KEEP; }
+        if (!s->in.append(src, n)) return s->status = LZFSE_MI_IO;
     }
     for (;;) {
         if (s->eos_seen) {
-            if (s->in.size() > s->in_pos) return s->status = LZFSE_MI_PAYLOAD_OVERFLOW;   // bytes behind bvx$ (decoder.rs:93-95)
+            if (s->in.size > s->in_pos) return s->status = LZFSE_MI_PAYLOAD_OVERFLOW;   // bytes behind bvx$ (decoder.rs:93-95)
             return LZFSE_MI_OK;
         }
         // the longest run of complete blocks at the front of the input, up to a window of raw bytes
@@ -250,7 +253,7 @@ LZFSE_MI_API int lzfse_mi_dstream_feed(lzfse_mi_dstream *s, const uint8_t *src, 
         int why = 1;   // why the run ended: 0 bvx$, 1 input exhausted, 2 undecidable block, 3 window full
         while (true) {
             uint64_t len, nr; bool eos;
-            why = block_extent(s->in.data() + s->in_pos + span, s->in.size() - s->in_pos - span, len, nr, eos);
+            why = block_extent(s->in.p + s->in_pos + span, s->in.size - s->in_pos - span, len, nr, eos);
             if (why) break;
             if (eos) break;
             span += (size_t)len; raw += nr;
@@ -277,7 +280,7 @@ LZFSE_MI_API int lzfse_mi_dstream_feed(lzfse_mi_dstream *s, const uint8_t *src, 
         // blocks by then: decoder.rs:76-99 decodes block by block).
         if (span) { const int st = decode_span(s, span, raw, true, write, user); if (st) return s->status = st; }
         {
-            const int st = decode_span(s, s->in.size() - s->in_pos, 0, false, write, user);
+            const int st = decode_span(s, s->in.size - s->in_pos, 0, false, write, user);
             return s->status = st ? st : LZFSE_MI_PAYLOAD_UNDERFLOW;   // (no bvx$: cannot have decoded cleanly)
         }
     }
@@ -290,23 +293,22 @@ LZFSE_MI_API int lzfse_mi_dstream_feed(lzfse_mi_dstream *s, const uint8_t *src, 
 struct lzfse_mi_estream {
     lzfse_mi_ctx *ctx = nullptr;
     size_t window = 0;            // new input bytes per device call
-    std::vector<uint8_t> buf;     // the input from position `base` on: what the parse may still look at, and what it has not seen yet
+    PinBuf buf;                   // the input from position `base` on: what the parse may still look at, and what it has not seen yet (pinned, like `out`)
     uint64_t base = 0;            // position of buf[0] in the stream, a multiple of 16 KiB
     bool have_state = false;      // a window has been cut: the parse goes on from `st` (positions relative to base)
     uint32_t st[5] = {};          // index, literal_index, pending (idx, match idx, len): encode/frontend_ring.rs' idx, literal_idx, pending
     uint32_t skip = 0;            // bytes of the first event the parse makes from there that have left already (a block ended inside it)
     size_t next_at = 0;           // buf.size() at which the next window is tried
-    uint8_t *out = nullptr;       // one window's bytes (malloc'd)
-    size_t out_cap = 0;
+    PinBuf out;                   // one window's bytes
     uint64_t total_in = 0, total_out = 0;
     int status = 0;               // sticky
     bool finished = false;
     ~lzfse_mi_estream() {
-        if (!ctx) { std::free(out); return; }   // (the context went first)
+        if (!ctx) return;   // (the context went first)
         ctx_detach(ctx, &ctx);
         StreamSpare &sp = ctx_spare(ctx);
-        if (sp.keep && out_cap > sp.cap[1]) { std::free(sp.p[1]); sp.p[1] = out; sp.cap[1] = out_cap; } else std::free(out);
-        if (sp.keep && buf.capacity() > sp.v[1].capacity()) { buf.clear(); sp.v[1].swap(buf); }
+        if (sp.keep && buf.cap > sp.b[2].cap) { buf.size = 0; sp.b[2].swap(buf); }
+        if (sp.keep && out.cap > sp.b[3].cap) { out.size = 0; sp.b[3].swap(out); }
     }
 };
 
@@ -318,18 +320,12 @@ namespace {
 constexpr size_t E_KEEP = 262139 + 65536;
 constexpr size_t E_MIN_WINDOW = (size_t)1 << 20;
 
-int es_out_room(lzfse_mi_estream *s, size_t cap) {
-    if (cap <= s->out_cap) return 0;
-    std::free(s->out);
-    s->out = (uint8_t *)std::malloc(cap);
-    s->out_cap = s->out ? cap : 0;
-    return s->out ? 0 : LZFSE_MI_IO;
-}
+int es_out_room(lzfse_mi_estream *s, size_t cap) { return s->out.reserve(cap, false) ? 0 : LZFSE_MI_IO; }
 
 int es_write(lzfse_mi_estream *s, lzfse_mi_write_fn write, void *user, size_t len) {
     // the sink takes the stream in pieces, as the reference's 8 KiB output ring does (encode/constants.rs:36-48); larger here
     for (size_t o = 0; o < len; o += (size_t)1 << 20)
-        if (write(user, s->out + o, len - o < ((size_t)1 << 20) ? len - o : (size_t)1 << 20)) return LZFSE_MI_IO;
+        if (write(user, s->out.p + o, len - o < ((size_t)1 << 20) ? len - o : (size_t)1 << 20)) return LZFSE_MI_IO;
     s->total_out += len;
     return 0;
 }
@@ -338,13 +334,18 @@ int es_write(lzfse_mi_estream *s, lzfse_mi_write_fn write, void *user, size_t le
 // that no later byte can change (enc_cut_kernel, encode_parse.hip), those blocks leave through `write`, and the buffer
 // keeps what the parse still needs: E_KEEP bytes below the literal index of the cut, and everything from there on.
 int es_window(lzfse_mi_estream *s, bool final, lzfse_mi_write_fn write, void *user) {
-    const size_t n = s->buf.size();
+    const size_t n = s->buf.size;
+    struct PinnedOut {   // (the window's bytes land in `out`: pinned memory)
+        lzfse_mi_ctx *c;
+        explicit PinnedOut(lzfse_mi_ctx *ctx) : c(ctx) { ctx_set_pinned_out(c, true); }
+        ~PinnedOut() { ctx_set_pinned_out(c, false); }
+    } pinned(s->ctx);
     if (final && !s->have_state) {
         // the whole input in one call (all size classes)
         const size_t cap = lzfse_mi_encode_bound(n);
         if (es_out_room(s, cap ? cap : 1)) return LZFSE_MI_IO;
         size_t len = 0;
-        const int st = lzfse_mi_encode_ring(s->ctx, s->buf.data(), n, s->out, cap, &len);
+        const int st = lzfse_mi_encode_ring(s->ctx, s->buf.p, n, s->out.p, cap, &len);
         return st ? st : es_write(s, write, user, len);
     }
     if (n > (size_t)0x7FFFFFFFu) return LZFSE_MI_UNSUPPORTED;   // positions are 31 bits on the device
@@ -356,7 +357,7 @@ int es_window(lzfse_mi_estream *s, bool final, lzfse_mi_write_fn write, void *us
     w.skip = s->skip;
     size_t len = 0;
     ctx_set_window(s->ctx, &w);
-    const int st = lzfse_mi_encode_ring(s->ctx, s->buf.data(), n, s->out, cap, &len);
+    const int st = lzfse_mi_encode_ring(s->ctx, s->buf.p, n, s->out.p, cap, &len);
     ctx_set_window(s->ctx, nullptr);
     if (st) return st;
     if (final) return es_write(s, write, user, len);
@@ -368,14 +369,14 @@ int es_window(lzfse_mi_estream *s, bool final, lzfse_mi_write_fn write, void *us
     if (const int e = es_write(s, write, user, len)) return e;
     size_t keep = w.lit > E_KEEP ? (size_t)w.lit - E_KEEP : 0;
     keep &= ~(size_t)(0x4000 - 1);
-    s->buf.erase(s->buf.begin(), s->buf.begin() + (ptrdiff_t)keep);
+    s->buf.erase_front(keep);
     s->base += keep;
     const uint32_t k32 = (uint32_t)keep;
     s->st[0] = w.index - k32; s->st[1] = w.lit - k32;
     s->st[2] = w.p_len ? w.p_idx - k32 : 0; s->st[3] = w.p_len ? w.p_midx - k32 : 0; s->st[4] = w.p_len;
     s->skip = w.skip_out;
     s->have_state = true;
-    s->next_at = s->buf.size() + s->window;
+    s->next_at = s->buf.size + s->window;
     return 0;
 }
 
@@ -395,9 +396,9 @@ int lzfse_mi_estream_create(lzfse_mi_ctx *ctx, size_t window, lzfse_mi_estream *
     s->next_at = s->window + ((size_t)1 << 19);   // (the last 256 KiB + 16 KiB of a window are never final: one ring on top)
     {
         StreamSpare &sp = ctx_spare(ctx);
-        s->out = sp.p[1]; s->out_cap = sp.cap[1]; sp.p[1] = nullptr; sp.cap[1] = 0;
-        s->buf.swap(sp.v[1]);
-        s->buf.clear();
+        s->buf.swap(sp.b[2]);
+        s->out.swap(sp.b[3]);
+        s->buf.size = 0; s->out.size = 0;
     }
     *out = s;
     return LZFSE_MI_OK;
@@ -412,16 +413,14 @@ int lzfse_mi_estream_feed(lzfse_mi_estream *s, const uint8_t *src, size_t n, lzf
     if (s->status) return s->status;
     if (!s->ctx) return s->status = LZFSE_MI_BAD_ARGUMENT;   // its context has been destroyed
     while (n) {
-        const size_t room = s->next_at > s->buf.size() ? s->next_at - s->buf.size() : 0;
+        const size_t room = s->next_at > s->buf.size ? s->next_at - s->buf.size : 0;
         const size_t take = n < room ? n : room;
-        try {
-            // (room for the whole window at once, as soon as the input shows that it will be needed: growing by doubling copies
-            // the window's bytes once more and touches twice the pages)
-            if (s->buf.capacity() < s->next_at && s->buf.size() + take > ((size_t)4 << 20)) s->buf.reserve(s->next_at + ((size_t)1 << 16));
-            s->buf.insert(s->buf.end(), src, src + take);
-        } catch (...) { return s->status = LZFSE_MI_IO; }
+        // (room for the whole window at once, as soon as the input shows that it will be needed: growing step by step copies
+        // the window's bytes again and again and pins twice the pages)
+        if (s->buf.cap < s->next_at && s->buf.size + take > ((size_t)4 << 20) && !s->buf.reserve(s->next_at + ((size_t)1 << 16))) return s->status = LZFSE_MI_IO;
+        if (!s->buf.append(src, take)) return s->status = LZFSE_MI_IO;
         src += take; n -= take; s->total_in += take;
-        if (s->buf.size() >= s->next_at)
+        if (s->buf.size >= s->next_at)
             if (const int st = es_window(s, false, write, user)) return s->status = st;
     }
     return LZFSE_MI_OK;
@@ -436,7 +435,7 @@ int lzfse_mi_estream_finish(lzfse_mi_estream *s, lzfse_mi_write_fn write, void *
     const int st = es_window(s, true, write, user);
     if (bytes_in) *bytes_in = s->total_in;
     if (bytes_out) *bytes_out = st ? 0 : s->total_out;
-    s->buf.clear();   // (its room goes back to the context with the object)
+    s->buf.size = 0;   // (its room goes back to the context with the object)
     return s->status = st;
 }
 
