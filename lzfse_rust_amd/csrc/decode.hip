@@ -2061,7 +2061,10 @@ __global__ __launch_bounds__(JUMP_THREADS) void dec_jump_init_kernel(
 // origin mostly points a match distance back, so most hops of most chains stay inside a chunk, where a hop is an LDS read
 // instead of a gather from a 4-byte-per-output-byte array far larger than any L2. Any intermediate state is valid
 // (an origin always names a byte with the same final value), so no ordering between threads is needed.
-constexpr uint32_t JC_N = 16384;
+#ifndef LZMI_JC_N
+#define LZMI_JC_N 16384
+#endif
+constexpr uint32_t JC_N = LZMI_JC_N;
 __global__ __launch_bounds__(1024) void dec_jump_collapse_kernel(uint32_t *__restrict__ origin, uint64_t total) {
     __shared__ uint32_t o[JC_N];
     const uint64_t c0 = (uint64_t)blockIdx.x * JC_N;

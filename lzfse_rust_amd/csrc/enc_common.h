@@ -9,17 +9,25 @@ constexpr uint32_t TILE_POS = 65472;        // positions per chain tile: multipl
 #define LZMI_SEG 2048
 #endif
 constexpr uint32_t SEG = LZMI_SEG;          // positions per speculative-parse segment of a large batch (small ones: 512, seg_for)
-constexpr uint32_t OVER = 512;              // overrun of a segment walker into the next segment
+#ifndef LZMI_OVER
+#define LZMI_OVER 512
+#endif
+constexpr uint32_t OVER = LZMI_OVER;              // overrun of a segment walker into the next segment
 constexpr uint32_t SEG_EV_CAP = (SEG + OVER) / 4 + 4;  // every emit advances literal_index by >= 4
 __host__ __device__ __forceinline__ uint32_t seg_ev_cap(uint32_t seg) { return (seg + OVER) / 4 + 4; }   // events a walker of `seg` positions can log
 // Segment length of a batch (one value for all its streams). A walker's time goes with its segment, and a small batch is one
 // round of resident walkers whose longest walk sets enc_spec's time: quarter segments, four times the walkers (html x 16:
 // enc_spec 0.30 -> 0.13 ms, encode 2.55 -> 3.2 GB/s). Not for large streams: the stitcher is one wave per stream and pays per
-// boundary (one 64 MiB stream with 1 024-position segments: enc_spec 0.64 -> 0.49 ms but enc_stitch 0.33 -> 0.73); not for
-// large batches: they are bound by the traffic of their records and events, to which more walkers (each overrunning by OVER)
-// only add (188 MB in 768 streams: no difference).
+// boundary (one 64 MiB stream with 1 024-position segments: enc_spec 0.64 -> 0.49 ms but enc_stitch 0.33 -> 0.73; round 4: a lone
+// 4 MiB stream -- a small window of the stream encoder -- enc_spec 0.48 -> 0.20, enc_stitch 0.03 -> 0.10 ms, the call 1.18 -> 0.98 ms,
+// hence 8 MiB and not 2); not for large batches: they are bound by the traffic of their records and events, to which more
+// walkers (each overrunning by OVER) only add (188 MB in 768 streams: no difference; 32 x 4 MiB: encode 27.2 -> 25.6 GB/s).
 __host__ __forceinline__ uint32_t seg_for(uint64_t positions, uint64_t longest) {
-    return (positions <= ((uint64_t)24 << 20) && longest <= ((uint64_t)2 << 20)) ? 512u : SEG;
+#ifndef LZMI_SEG_SMALL_BATCH
+#define LZMI_SEG_SMALL_BATCH 24
+#define LZMI_SEG_SMALL_STREAM 8
+#endif
+    return (positions <= ((uint64_t)LZMI_SEG_SMALL_BATCH << 20) && longest <= ((uint64_t)LZMI_SEG_SMALL_STREAM << 20)) ? 512u : SEG;
 }
 constexpr uint32_t NONE = 0xFFFFFFFFu;      // no previous position
 constexpr uint32_t NONE_TILE = 0xFFFFFFFEu; // no previous position inside the tile (link pending)

@@ -1,5 +1,5 @@
 """Reads a rocprofv3 --kernel-trace csv and prints, for the last encode and decode bursts, wall span vs summed kernel time and the gaps."""
-import csv, sys, glob
+import csv, sys, glob, os
 f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0].replace('void ', '').replace('lzmi::', '')) for r in csv.DictReader(open(f))]
 rows.sort()
@@ -11,7 +11,7 @@ for r in rows[1:]:
         bursts.append(cur); cur = []
     cur.append(r); end = max(end, r[1])
 bursts.append(cur)
-for b in bursts[-4:]:
+for b in bursts[-int(os.environ.get('BURSTS', '4')):]:   # BURSTS=n: the last n bursts
     t0 = b[0][0]; t1 = max(r[1] for r in b)
     busy = 0; e = t0
     for s_, e_, _ in b:

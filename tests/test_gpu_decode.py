@@ -98,6 +98,34 @@ def test_decode_single_api(ctx, golden_dir):
     assert n == 152089 and dst[:4] == b"keep" and len(dst) == 4 + n
 
 
+def test_decode_bytes_writes_the_vec_where_it_lies(ctx, oracle, snappy_raw):
+    """The mirror decodes into the bytearray's own tail (codec._into_tail): what was there stays, what is appended is the
+    stream's bytes, an error leaves the Vec as it was, and a Vec with a live view cannot grow (as for `+=`)."""
+    import lzfse_rust_amd as m
+    dec = m.LzfseDecoder(context=ctx)
+    raw = snappy_raw["alice29.txt"] * 9      # (1.3 MB: a destination the library faults in while its kernels run)
+    enc = oracle.encode(raw)
+    dst = bytearray(b"head")
+    for k in (1, 2):
+        assert dec.decode_bytes(enc, dst) == len(raw)
+        assert len(dst) == 4 + k * len(raw) and dst[:4] == b"head" and bytes(dst[4 + (k - 1) * len(raw):]) == raw
+    bad = bytearray(enc)
+    bad[0:4] = b"bvx9"
+    before = bytes(dst)
+    with pytest.raises(m.LzfseError):
+        dec.decode_bytes(bytes(bad), dst)
+    assert bytes(dst) == before
+    view = memoryview(dst)
+    with pytest.raises(BufferError):
+        dec.decode_bytes(enc, dst)
+    view.release()
+    assert bytes(dst) == before
+    out = bytearray()
+    assert dec.decode_bytes(oracle.encode(b""), out) == 0 and out == bytearray()
+    big = bytearray(b"x")
+    assert m.LzfseEncoder(context=ctx).encode_bytes(raw, big) == len(enc) and bytes(big[1:]) == enc
+
+
 def test_decode_oracle_streams(ctx, oracle, snappy_raw):
     """Streams produced by the oracle encoder (10 000-LMD blocks, unlike Apple's 9 992)."""
     raws = list(snappy_raw.values())
