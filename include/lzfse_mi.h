@@ -94,7 +94,7 @@ enum {
                                        1 never, else K | variant << 8: K workgroups (2..64) for every stream of the tile
                                        kernel, variant 0 = 256 threads / 8 KiB tiles, 1 = 1024 threads / 32 KiB tiles */
     LZFSE_MI_OPT_STREAM_SPARE = 5,  /* 1 (default): the window buffers of a destroyed stream object (lzfse_mi_dstream / _estream)
-                                       stay with the context for the next one -- host memory, up to about window x (1 + 1.125)
+                                       stay with the context for the next one -- pinned host memory, up to about window x (1 + 1.125)
                                        for a decoder and window x (1 + 1.75) for an encoder, ~300 MiB at the default window,
                                        until lzfse_mi_destroy; 0: free what is held now and keep nothing from now on */
     LZFSE_MI_OPT_DIAG_LZ_PATH = 100, /* -1: by cost, 0: tile kernel only, 1: pointer jumping for every stream */
@@ -141,7 +141,9 @@ LZFSE_MI_API int lzfse_mi_encode_small(const uint8_t *src, size_t n, uint8_t *ds
 LZFSE_MI_API int lzfse_mi_decode_size(const uint8_t *src, size_t n, uint64_t *raw_len);
 
 /* Many independent streams per call (the unit of GPU parallelism). The
- * return value reports call-level failures only; statuses[i] is per stream. */
+ * return value reports call-level failures only; statuses[i] is per stream.
+ * dsts[i] may be memory that has never been touched (a Vec<u8> just made): only dsts[i][0 .. out_lens[i]) is written, but
+ * pages of dsts[i][0 .. caps[i]) may be mapped by the call (madvise MADV_POPULATE_WRITE while the kernels run). */
 LZFSE_MI_API int lzfse_mi_encode_batch(lzfse_mi_ctx *ctx, size_t count, const uint8_t *const *srcs,
                           const size_t *lens, uint8_t *const *dsts, const size_t *caps,
                           size_t *out_lens, int *statuses);
