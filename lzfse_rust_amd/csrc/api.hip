@@ -614,10 +614,15 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
             launch_dec_walk(true, (const uint8_t *)d_src, (const StreamIn *)c->d_streams.p, ns, nullptr,
                             (const StreamPlan *)c->d_plan.p, (BlockDesc *)c->d_blocks.p, nullptr, st);
     }
+    // all streams on the pointer-jumping path (a lone large stream, a window of a stream): its first step rides on the entropy kernel
+    bool jump_fused = nj != 0;
+    for (uint32_t i = 0; i < ns; i++) jump_fused &= h_plan[i].skip || h_plan[i].jump;
+    const JumpFuse jf = {(const StreamIn *)c->d_streams.p, (const StreamPlan *)c->d_plan.p, (uint8_t *)d_dst, (uint32_t *)c->d_origin.p, d_jerr, nj};
     {
         StageTimer t(c, "dec_fse");
         launch_dec_fse((const uint8_t *)d_src, src_total, (const BlockDesc *)c->d_blocks.p, (uint32_t)nb,
-                       (uint8_t *)c->d_lits.p, (LmdRec *)c->d_lmds.p, (BlockResult *)c->d_bres.p, d_ohist, d_order, st);
+                       (uint8_t *)c->d_lits.p, (LmdRec *)c->d_lmds.p, (BlockResult *)c->d_bres.p, d_ohist, d_order,
+                       jump_fused ? &jf : nullptr, st);
     }
     {
         StageTimer t(c, "dec_lz");
@@ -645,7 +650,7 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
         launch_dec_jump((const uint8_t *)d_src, (const StreamIn *)c->d_streams.p, (const StreamPlan *)c->d_plan.p,
                         (const StreamWalk *)c->d_walk.p, ns, (const BlockDesc *)c->d_blocks.p, (uint32_t)nb,
                         (const BlockResult *)c->d_bres.p, (const LmdRec *)c->d_lmds.p, (const uint8_t *)c->d_lits.p, (uint8_t *)d_dst,
-                        (uint32_t *)c->d_origin.p, nj, d_jerr, d_jflags, (StreamResult *)c->d_sres.p, c, st);
+                        (uint32_t *)c->d_origin.p, nj, d_jerr, d_jflags, (StreamResult *)c->d_sres.p, c, jump_fused, st);
     }
     std::vector<StreamResult> h_sres(ns);
     std::vector<uint32_t> h_state(mlist.empty() ? 0 : (size_t)LZP_STATE_WORDS * ns);

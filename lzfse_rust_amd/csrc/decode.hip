@@ -633,10 +633,20 @@ __device__ int fse_build_tables(FseLds &lds, uint32_t kind, const FseHeader &h, 
 //   V: .x = k | v_bits << 8 | (delta & 0xFF) << 16 | (-(k + v_bits) & 0xFF) << 24, .y = v_base   (decoder.rs:205-220; delta is below
 //      the number of states, <= 256, by the choice of k; the signed byte is what the step's prefix sum over L, M, D runs on: it IS
 //      the window shift)
+template <int NT>
+__device__ __forceinline__ void jump_init_block(const uint32_t b, const BlockDesc &d, const StreamPlan &pl, const BlockResult &br,
+                                                const uint8_t *__restrict__ src, const StreamIn *__restrict__ streams,
+                                                const LmdRec *__restrict__ lmds, const uint8_t *__restrict__ lits, uint8_t *dst_all,
+                                                uint32_t *__restrict__ origin, uint32_t *__restrict__ jerr, uint32_t *sh);
+
+// JUMP: every stream of the call takes the pointer-jumping LZ path, and a block's workgroup goes on with that path's first step
+// for its block (jump_init_block below) as soon as its entropy stage is done -- blocks of other kinds (raw) included
+template <bool JUMP>
 __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
     const uint8_t *__restrict__ src, uint64_t src_total, const BlockDesc *__restrict__ blocks,
     uint32_t n_blocks, uint8_t *__restrict__ lit_out, LmdRec *__restrict__ lmd_out,
-    BlockResult *__restrict__ results, const uint32_t *__restrict__ order) {
+    BlockResult *__restrict__ results, const uint32_t *__restrict__ order, const StreamIn *__restrict__ streams,
+    const StreamPlan *__restrict__ plan, uint8_t *dst_all, uint32_t *__restrict__ origin, uint32_t *__restrict__ jerr) {
     __shared__ __attribute__((aligned(16))) FseLds lds;
     uint32_t *const pool = lds.pool;
     uint32_t *const u_tab = lds.u_tab;
@@ -651,8 +661,12 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
     if (blockIdx.x >= n_blocks) return;
     const uint32_t b = order[blockIdx.x];   // longest blocks first (dec_order_*)
     const BlockDesc d = blocks[b];
-    if (d.kind != KIND_VX2 && d.kind != KIND_VX1) return;
+    const bool is_fse = d.kind == KIND_VX2 || d.kind == KIND_VX1;
+    if (!is_fse && !JUMP) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    BlockResult br;
+    br.status = 0; br.sum_l = 0; br.sum_m = 0; br.ok_until = 0;
+    if (is_fse) br = [&]() -> BlockResult {
     const uint8_t *p = src + d.src_pos;
     const uint8_t *glo = src, *ghi = src + ((src_total + 3) & ~3ull);
 
@@ -662,7 +676,7 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
     // literal payload and LMD payload one after the other, each with its own PayloadUnderflow (decoder.rs:102-141)
     const uint64_t avail = d.src_end - d.src_pos;
     if (!st && avail < h.hdr_size) st = LZFSE_MI_PAYLOAD_UNDERFLOW;
-    if (st) { if (tid == 0) { BlockResult r; r.status = st; r.sum_l = 0; r.sum_m = 0; r.ok_until = 0; results[b] = r; } return; }
+    if (st) { BlockResult r; r.status = st; r.sum_l = 0; r.sum_m = 0; r.ok_until = 0; return r; }
     const bool lit_short = avail < (uint64_t)h.hdr_size + h.lit_payload;
     const bool lmd_short = avail < (uint64_t)h.hdr_size + h.lit_payload + h.lmd_payload;
     if (tid < 2) sh_status[tid] = 0;
@@ -670,7 +684,7 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
     // ---- weights and decode tables ----
     {
         const int ts = fse_build_tables(lds, d.kind, h, p);
-        if (ts) { if (tid == 0) { BlockResult r; r.status = ts; r.sum_l = 0; r.sum_m = 0; r.ok_until = 0; results[b] = r; } return; }
+        if (ts) { BlockResult r; r.status = ts; r.sum_l = 0; r.sum_m = 0; r.ok_until = 0; return r; }
     }
 
     // ---- the two bit streams ----
@@ -864,13 +878,18 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
         if (lane == 0) { sh_status[0] = e; sh_sums[0] = sum_l; sh_sums[1] = sum_m; sh_sums[2] = ok_until; }
     }
     __syncthreads();
-    if (tid == 0) {
-        BlockResult r;
-        // literals are loaded before the LMD stream is touched (decoder.rs:127-141)
-        r.status = sh_status[1] ? sh_status[1] : sh_status[0];
-        r.sum_l = sh_sums[0]; r.sum_m = sh_sums[1];
-        r.ok_until = sh_status[1] ? 0u : sh_sums[2];
-        results[b] = r;
+    BlockResult r;
+    // literals are loaded before the LMD stream is touched (decoder.rs:127-141)
+    r.status = sh_status[1] ? sh_status[1] : sh_status[0];
+    r.sum_l = sh_sums[0]; r.sum_m = sh_sums[1];
+    r.ok_until = sh_status[1] ? 0u : sh_sums[2];
+    return r;
+    }();
+    if (is_fse && tid == 0) results[b] = br;
+    if (JUMP) {
+        // (the block's literal and LMD arrays were stored by this workgroup's two waves: drained and visible to both)
+        __syncthreads();
+        jump_init_block<FSE_THREADS>(b, d, plan[d.stream], br, src, streams, lmd_out, lit_out, dst_all, origin, jerr, pool);
     }
 }
 
@@ -1974,17 +1993,16 @@ constexpr int JUMP_THREADS = 256;
 // never visited again, so a round costs gathers only for the bytes that are still on a chain
 constexpr uint32_t JUMP_FINAL = 0x80000000u;
 
-// one workgroup per block: literals (and raw blocks) are written, origins initialised
-__global__ __launch_bounds__(JUMP_THREADS) void dec_jump_init_kernel(
-    const uint8_t *__restrict__ src, const StreamIn *__restrict__ streams, const StreamPlan *__restrict__ plan,
-    const BlockDesc *__restrict__ blocks, uint32_t n_blocks, const BlockResult *__restrict__ bres,
-    const LmdRec *__restrict__ lmds, const uint8_t *__restrict__ lits, uint8_t *dst_all, uint32_t *__restrict__ origin,
-    uint32_t *__restrict__ jerr) {
-    __shared__ uint32_t sh[2 * (JUMP_THREADS / 64) + 4];
-    const uint32_t b = blockIdx.x;
-    if (b >= n_blocks) return;
-    const BlockDesc d = blocks[b];
-    const StreamPlan pl = plan[d.stream];
+// One block's part of the pointer-jumping path's first step: literals (and raw blocks) are written, origins initialised.
+// By a whole workgroup of NT threads (uniform arguments): dec_jump_init_kernel's, or -- when every stream of the call takes
+// this path -- the block's own dec_fse workgroup right after its entropy stage (dec_fse_kernel<true>: the FSE stage of a lone
+// stream is one block's chain long whatever else runs beside it, so this work costs nothing there; text64m decode 22.4 -> see DESIGN.md).
+// br: the block's entropy result (not read for raw blocks); sh: 2 * NT / 64 + 4 words of LDS.
+template <int NT>
+__device__ __forceinline__ void jump_init_block(const uint32_t b, const BlockDesc &d, const StreamPlan &pl, const BlockResult &br,
+                                                const uint8_t *__restrict__ src, const StreamIn *__restrict__ streams,
+                                                const LmdRec *__restrict__ lmds, const uint8_t *__restrict__ lits, uint8_t *dst_all,
+                                                uint32_t *__restrict__ origin, uint32_t *__restrict__ jerr, uint32_t *sh) {
     if (pl.skip || !pl.jump) return;
     const StreamIn in = streams[d.stream];
     uint8_t *dst = dst_all + in.dst_off;
@@ -1993,15 +2011,22 @@ __global__ __launch_bounds__(JUMP_THREADS) void dec_jump_init_kernel(
     const uint32_t bi = b - (uint32_t)pl.blk_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t o0 = (uint32_t)d.dst_rel;
+    // Every origin entry is defined before the rounds read it (all bits set = final, names nothing), and by the workgroup of the
+    // block it lies in -- round 4; a fill of the whole array before: 0.09 ms for a 64 MiB stream: the up to three padding entries
+    // behind a stream, the bytes of a block that failed, the bytes of a match with a bad D.
+    if (bi + 1 == pl.n_blocks && tid < 3) {
+        const uint32_t e0 = o0 + d.n_raw + (uint32_t)tid;
+        if (e0 < ((o0 + d.n_raw + 3u) & ~3u)) org[e0] = 0xFFFFFFFFu;
+    }
     if (d.kind == KIND_RAW) {
         const uint8_t *p = src + d.src_pos + 8;
-        for (uint32_t i = tid; i < d.n_raw; i += JUMP_THREADS) { dst[o0 + i] = p[i]; org[o0 + i] = (jb + o0 + i) | JUMP_FINAL; }
+        for (uint32_t i = tid; i < d.n_raw; i += NT) { dst[o0 + i] = p[i]; org[o0 + i] = (jb + o0 + i) | JUMP_FINAL; }
         return;
     }
-    const BlockResult br = bres[b];
     const LmdRec *bl = lmds + d.lmd_base;
     if (br.status) {
-        int e = lmds_first_fault<JUMP_THREADS>(bl, br.ok_until, o0, in.dst_cap, sh);  // (a damaged block may overrun it)
+        for (uint32_t i = tid; i < d.n_raw; i += NT) org[o0 + i] = 0xFFFFFFFFu;
+        int e = lmds_first_fault<NT>(bl, br.ok_until, o0, in.dst_cap, sh);  // (a damaged block may overrun it)
         if (!e) e = br.status;
         if (tid == 0) atomicMin(&jerr[d.stream], (bi << 8) | (uint32_t)e);
         return;
@@ -2009,13 +2034,13 @@ __global__ __launch_bounds__(JUMP_THREADS) void dec_jump_init_kernel(
     const uint8_t *blit = lits + d.lit_base;
     uint32_t run_lit = 0, run_out = 0;
     bool bad = false;
-    for (uint32_t g0 = 0; g0 < d.n_lmd; g0 += JUMP_THREADS) {
+    for (uint32_t g0 = 0; g0 < d.n_lmd; g0 += NT) {
         const uint32_t idx = g0 + tid;
         const bool valid = idx < d.n_lmd;
         const LmdRec r = valid ? bl[idx] : make_uint2(0, 0);
         const uint32_t l = r.x & 0xFFFF, m = r.x >> 16, dd = r.y;
         uint32_t ex_l, ex_s, tot_l, tot_s;
-        block_excl_scan2<JUMP_THREADS>(l, l + m, ex_l, ex_s, tot_l, tot_s, sh);
+        block_excl_scan2<NT>(l, l + m, ex_l, ex_s, tot_l, tot_s, sh);
         const uint32_t o = o0 + run_out + ex_s;       // stream-relative position of the LMD's first byte
         const uint32_t p = o + l;                     // ... of its match
         const bool bad_d = valid && m != 0 && (dd == 0 || dd > p);  // lz/writer.rs:156-178
@@ -2030,6 +2055,7 @@ __global__ __launch_bounds__(JUMP_THREADS) void dec_jump_init_kernel(
             uint32_t rr = 0;
             for (uint32_t k = 0; k < m; k++) { org[p + k] = jb + p - dd + rr; if (++rr == dd) rr = 0; }
         }
+        if (bad_d) for (uint32_t k = 0; k < m; k++) org[p + k] = 0xFFFFFFFFu;
         // long runs: the whole wave works on one lane's run at a time
         uint64_t ql = __ballot(l_long);
         while (ql) {
@@ -2054,6 +2080,19 @@ __global__ __launch_bounds__(JUMP_THREADS) void dec_jump_init_kernel(
     }
     if (__any(bad) && lane == 0) atomicMin(&jerr[d.stream], (bi << 8) | (uint32_t)LZFSE_MI_BAD_D_VALUE);
     (void)wave;
+}
+
+// one workgroup per block
+__global__ __launch_bounds__(JUMP_THREADS) void dec_jump_init_kernel(
+    const uint8_t *__restrict__ src, const StreamIn *__restrict__ streams, const StreamPlan *__restrict__ plan,
+    const BlockDesc *__restrict__ blocks, uint32_t n_blocks, const BlockResult *__restrict__ bres,
+    const LmdRec *__restrict__ lmds, const uint8_t *__restrict__ lits, uint8_t *dst_all, uint32_t *__restrict__ origin,
+    uint32_t *__restrict__ jerr) {
+    __shared__ uint32_t sh[2 * (JUMP_THREADS / 64) + 4];
+    const uint32_t b = blockIdx.x;
+    if (b >= n_blocks) return;
+    const BlockDesc d = blocks[b];
+    jump_init_block<JUMP_THREADS>(b, d, plan[d.stream], bres[b], src, streams, lmds, lits, dst_all, origin, jerr, sh);
 }
 
 // Chains collapsed chunk by chunk in LDS before the global rounds: a workgroup takes 16 Ki consecutive origins (64 KB of
@@ -2197,14 +2236,20 @@ void launch_dec_emit(const StreamIn *streams, uint32_t n_streams, const StreamPl
 }
 
 void launch_dec_fse(const uint8_t *src, uint64_t src_total, const BlockDesc *blocks, uint32_t n_blocks,
-                    uint8_t *lit_out, LmdRec *lmd_out, BlockResult *results, uint32_t *order_hist, uint32_t *order, hipStream_t st) {
+                    uint8_t *lit_out, LmdRec *lmd_out, BlockResult *results, uint32_t *order_hist, uint32_t *order,
+                    const JumpFuse *jf, hipStream_t st) {
     if (!n_blocks) return;
     // order_hist: 64 zeroed words; order: n_blocks words
     hipLaunchKernelGGL(dec_order_count_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, st, blocks, n_blocks, order_hist);
     hipLaunchKernelGGL(dec_order_scan_kernel, dim3(1), dim3(64), 0, st, order_hist);
     hipLaunchKernelGGL(dec_order_place_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, st, blocks, n_blocks, order_hist, order);
-    hipLaunchKernelGGL(dec_fse_kernel, dim3(n_blocks), dim3(FSE_THREADS), 0, st, src, src_total, blocks,
-                       n_blocks, lit_out, lmd_out, results, order);
+    if (jf) {
+        hipLaunchKernelGGL(dec_fse_kernel<true>, dim3(n_blocks), dim3(FSE_THREADS), 0, st, src, src_total, blocks, n_blocks, lit_out, lmd_out,
+                           results, order, jf->streams, jf->plan, jf->dst, jf->origin, jf->jerr);
+    } else
+        hipLaunchKernelGGL(dec_fse_kernel<false>, dim3(n_blocks), dim3(FSE_THREADS), 0, st, src, src_total, blocks, n_blocks, lit_out, lmd_out,
+                           results, order, (const StreamIn *)nullptr, (const StreamPlan *)nullptr, (uint8_t *)nullptr, (uint32_t *)nullptr,
+                           (uint32_t *)nullptr);
 }
 
 void launch_dec_lz(int variant, const uint8_t *src, const StreamIn *streams, const StreamPlan *plan,
@@ -2248,13 +2293,11 @@ void launch_dec_lzp(int variant, uint32_t K, int lpt, const uint8_t *src, const 
 void launch_dec_jump(const uint8_t *src, const StreamIn *streams, const StreamPlan *plan, const StreamWalk *walk, uint32_t n_streams,
                      const BlockDesc *blocks, uint32_t n_blocks, const BlockResult *bres, const LmdRec *lmds, const uint8_t *lits,
                      uint8_t *dst, uint32_t *origin, uint64_t total, uint32_t *jerr, uint32_t *flags, StreamResult *sres,
-                     lzfse_mi_ctx *c, hipStream_t st) {
+                     lzfse_mi_ctx *c, bool init_done, hipStream_t st) {
     if (!n_blocks || !total) return;
-    {
+    if (!init_done) {
         StageTimer t(c, "dec_jump_init");
-        // Every origin entry is defined before the rounds read it: padding slots between streams, the bytes of blocks that
-        // failed and of bad-D matches are never written by the init kernel; all bits set = final, names nothing.
-        (void)hipMemsetAsync(origin, 0xFF, (size_t)total * 4, st);
+        // (every origin entry is defined before the rounds read it: jump_init_block)
         hipLaunchKernelGGL(dec_jump_init_kernel, dim3(n_blocks), dim3(JUMP_THREADS), 0, st, src, streams, plan, blocks, n_blocks, bres, lmds,
                            lits, dst, origin, jerr);
     }

@@ -112,8 +112,18 @@ void launch_dec_fastwalk(const uint8_t *src, const StreamIn *streams, const uint
                          uint32_t *count, uint2 *cand, StreamWalk *walk, BlockDesc *cache, uint32_t *settled, hipStream_t st);
 void launch_dec_emit(const StreamIn *streams, uint32_t n_streams, const StreamPlan *plan, const BlockDesc *cache, uint64_t cache_total,
                      BlockDesc *blocks, hipStream_t st);
+// jf != null: every stream of the call takes the pointer-jumping LZ path, and the entropy kernel's workgroups do that path's first
+// step (literals out, origins initialised) for their own block behind their entropy stage; launch_dec_jump is told (init_done)
+struct JumpFuse {
+    const StreamIn *streams;
+    const StreamPlan *plan;
+    uint8_t *dst;
+    uint32_t *origin, *jerr;
+    uint64_t total;
+};
 void launch_dec_fse(const uint8_t *src, uint64_t src_total, const BlockDesc *blocks, uint32_t n_blocks,
-                    uint8_t *lit_out, LmdRec *lmd_out, BlockResult *results, uint32_t *order_hist, uint32_t *order, hipStream_t st);
+                    uint8_t *lit_out, LmdRec *lmd_out, BlockResult *results, uint32_t *order_hist, uint32_t *order,
+                    const JumpFuse *jf, hipStream_t st);
 void launch_dec_lz(int variant, const uint8_t *src, const StreamIn *streams, const StreamPlan *plan,
                    uint32_t n_streams, const BlockDesc *blocks, const BlockResult *bres, const LmdRec *lmds,
                    const uint8_t *lits, uint8_t *dst, StreamResult *sres, hipStream_t st);
@@ -133,7 +143,7 @@ void launch_dec_lzp_selftest(uint32_t *buf, uint32_t *out, hipStream_t st);   //
 void launch_dec_jump(const uint8_t *src, const StreamIn *streams, const StreamPlan *plan, const StreamWalk *walk, uint32_t n_streams,
                      const BlockDesc *blocks, uint32_t n_blocks, const BlockResult *bres, const LmdRec *lmds, const uint8_t *lits,
                      uint8_t *dst, uint32_t *origin, uint64_t total, uint32_t *jerr, uint32_t *flags, StreamResult *sres,
-                     lzfse_mi_ctx *c, hipStream_t st);
+                     lzfse_mi_ctx *c, bool init_done, hipStream_t st);
 
 // ---- encode.hip ----
 struct EncScratch {
