@@ -2146,8 +2146,11 @@ __global__ __launch_bounds__(256) void dec_jump_round_kernel(uint32_t *__restric
         uint32_t cur = origin[q];
         if (cur & JUMP_FINAL) continue;
         // up to three hops; an entry carrying JUMP_FINAL holds the final byte of its chain (itself for a literal)
+#ifndef LZMI_JR_HOPS
+#define LZMI_JR_HOPS 3
+#endif
 #pragma unroll
-        for (int h = 0; h < 3; h++) {
+        for (int h = 0; h < LZMI_JR_HOPS; h++) {
             if (cur >= total) { cur = (uint32_t)q | JUMP_FINAL; break; }  // never taken: every entry is defined (see launch_dec_jump)
             cur = origin[cur];
             if (cur & JUMP_FINAL) break;
