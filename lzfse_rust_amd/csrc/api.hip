@@ -590,7 +590,6 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
         if (!c->d_ck.ensure(((nl >> 8) + nb + 2) * sizeof(uint2)) || !c->d_lzp.ensure(((size_t)LZP_STATE_WORDS * ns + mlist.size()) * 4)) return LZFSE_MI_IO;
         d_lzp_state = (uint32_t *)c->d_lzp.p;
         d_mlist = d_lzp_state + LZP_STATE_WORDS * (size_t)ns;
-        HIP_TRY(hipMemsetAsync(d_lzp_state, 0, (size_t)LZP_STATE_WORDS * ns * 4, st));
         HIP_TRY(hipMemcpyAsync(d_mlist, mlist.data(), mlist.size() * 4, hipMemcpyHostToDevice, st));
     }
     if (!c->d_blocks.ensure((nb + 1) * sizeof(BlockDesc)) || !c->d_bres.ensure((nb + 1) * sizeof(BlockResult)) ||
@@ -598,12 +597,17 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
         !c->d_jerr.ensure((size_t)ns * 4 + 128 * 4 + (nb + 1) * 4))
         return LZFSE_MI_IO;
     uint32_t *d_jerr = (uint32_t *)c->d_jerr.p, *d_jflags = d_jerr + ns;
-    HIP_TRY(hipMemsetAsync(d_jerr, 0xFF, (size_t)ns * 4, st));
     uint32_t *d_ohist = d_jflags + 64, *d_order = d_ohist + 64;   // FSE workgroup order (launch_dec_fse)
-    HIP_TRY(hipMemsetAsync(d_jflags, 0, 128 * 4, st));
+    {
+        // (one launch for the call's small fills: every launch of a small call is microseconds of an idle device)
+        static_assert(sizeof(BlockResult) % 4 == 0 && sizeof(StreamResult) % 4 == 0, "dword fills");
+        void *const fp[5] = {d_jerr, d_jflags, c->d_bres.p, c->d_sres.p, d_lzp_state};
+        const uint64_t fb[5] = {(uint64_t)ns * 4, 128 * 4, (nb + 1) * sizeof(BlockResult), ns * sizeof(StreamResult),
+                                d_lzp_state ? (uint64_t)LZP_STATE_WORDS * ns * 4 : 0};
+        const uint32_t fv[5] = {0xFFFFFFFFu, 0u, 0u, 0u, 0u};
+        launch_dec_fills(fp, fb, fv, 5, st);
+    }
     HIP_TRY(hipMemcpyAsync(c->d_plan.p, h_plan.data(), ns * sizeof(StreamPlan), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(c->d_bres.p, 0, (nb + 1) * sizeof(BlockResult), st));
-    HIP_TRY(hipMemsetAsync(c->d_sres.p, 0, ns * sizeof(StreamResult), st));
     {
         StageTimer t(c, "dec_walk");
         launch_dec_emit((const StreamIn *)c->d_streams.p, ns, (const StreamPlan *)c->d_plan.p, (const BlockDesc *)c->d_wcache.p,

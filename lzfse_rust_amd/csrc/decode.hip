@@ -469,6 +469,34 @@ __global__ void dec_order_place_kernel(const BlockDesc *__restrict__ blocks, uin
     if (b < n_blocks) order[atomicAdd(&hist[fse_order_key(blocks[b])], 1u)] = b;
 }
 
+// the three steps in ONE launch for a call of few blocks (a small call is a chain of launches, each a few microseconds of an
+// otherwise idle device: html x 16 decode 0.63 ms, 0.17 of it before the entropy kernel starts)
+constexpr uint32_t ORDER_ONE_MAX = 8192;
+__global__ __launch_bounds__(256) void dec_order_one_kernel(const BlockDesc *__restrict__ blocks, uint32_t n_blocks, uint32_t *__restrict__ order) {
+    __shared__ uint32_t hist[64];
+    if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += 256) atomicAdd(&hist[fse_order_key(blocks[b])], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64) { const uint32_t v = hist[threadIdx.x]; hist[threadIdx.x] = wave_incl_scan(v) - v; }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += 256) order[atomicAdd(&hist[fse_order_key(blocks[b])], 1u)] = b;
+}
+
+// Several small fills in one launch (the same reason): region k is n[k] dwords of value v[k]
+struct FillSet {
+    uint32_t *p[6];
+    uint32_t n[6], v[6];
+};
+__global__ __launch_bounds__(256) void dec_fill_kernel(const FillSet f) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        if (i < f.n[k]) { f.p[k][i] = f.v[k]; return; }
+        i -= f.n[k];
+    }
+}
+
 // One LDS block, the pool FIRST: the payload rings then sit at LDS addresses 0 and 512, inside the offset fields of
 // ds_read2_b32 / ds_read_b32, and a window fetch is one address register + two reads (no base add, no second move).
 struct FseLds {
@@ -2231,6 +2259,24 @@ void launch_dec_fastwalk(const uint8_t *src, const StreamIn *streams, const uint
     hipLaunchKernelGGL(dec_rank_kernel, dim3(n_elig), dim3(1024), 0, st, src, streams, elig, count, cand, walk, cache, settled);
 }
 
+// up to six fills of dwords in one launch (sizes in BYTES, multiples of 4; a null pointer or a size of 0 is skipped)
+void launch_dec_fills(void *const *ptrs, const uint64_t *bytes, const uint32_t *values, int count, hipStream_t st) {
+    FillSet f = {};
+    uint64_t total = 0;
+    int k = 0;
+    for (int q = 0; q < count; q++) {
+        if (!ptrs[q] || !bytes[q]) continue;
+        if (bytes[q] / 4 > 0x7FFFFFFFull || k == 6) { (void)hipMemsetD32Async((hipDeviceptr_t)ptrs[q], (int)values[q], bytes[q] / 4, st); continue; }
+        f.p[k] = (uint32_t *)ptrs[q]; f.n[k] = (uint32_t)(bytes[q] / 4); f.v[k] = values[q]; total += f.n[k]; k++;
+    }
+    if (!total) return;
+    if (total > 0xFFFFFFFFull - 512) {   // (cannot happen with the sizes of a decode call; plain fills then)
+        for (int q = 0; q < k; q++) (void)hipMemsetD32Async((hipDeviceptr_t)f.p[q], (int)f.v[q], f.n[q], st);
+        return;
+    }
+    hipLaunchKernelGGL(dec_fill_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, f);
+}
+
 void launch_dec_emit(const StreamIn *streams, uint32_t n_streams, const StreamPlan *plan, const BlockDesc *cache, uint64_t cache_total,
                      BlockDesc *blocks, hipStream_t st) {
     if (!cache_total) return;
@@ -2243,9 +2289,12 @@ void launch_dec_fse(const uint8_t *src, uint64_t src_total, const BlockDesc *blo
                     const JumpFuse *jf, hipStream_t st) {
     if (!n_blocks) return;
     // order_hist: 64 zeroed words; order: n_blocks words
-    hipLaunchKernelGGL(dec_order_count_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, st, blocks, n_blocks, order_hist);
-    hipLaunchKernelGGL(dec_order_scan_kernel, dim3(1), dim3(64), 0, st, order_hist);
-    hipLaunchKernelGGL(dec_order_place_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, st, blocks, n_blocks, order_hist, order);
+    if (n_blocks <= ORDER_ONE_MAX) hipLaunchKernelGGL(dec_order_one_kernel, dim3(1), dim3(256), 0, st, blocks, n_blocks, order);
+    else {
+        hipLaunchKernelGGL(dec_order_count_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, st, blocks, n_blocks, order_hist);
+        hipLaunchKernelGGL(dec_order_scan_kernel, dim3(1), dim3(64), 0, st, order_hist);
+        hipLaunchKernelGGL(dec_order_place_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, st, blocks, n_blocks, order_hist, order);
+    }
     if (jf) {
         hipLaunchKernelGGL(dec_fse_kernel<true>, dim3(n_blocks), dim3(FSE_THREADS), 0, st, src, src_total, blocks, n_blocks, lit_out, lmd_out,
                            results, order, jf->streams, jf->plan, jf->dst, jf->origin, jf->jerr);

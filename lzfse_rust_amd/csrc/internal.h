@@ -107,6 +107,7 @@ int ctx_diag_chain(lzfse_mi_ctx *c);  // LZFSE_MI_OPT_DIAG_CHAIN: 1 = every chai
 // ---- decode.hip ----
 void launch_dec_walk(bool emit, const uint8_t *src, const StreamIn *streams, uint32_t n_streams,
                      StreamWalk *walk, const StreamPlan *plan, BlockDesc *blocks, const uint32_t *settled, hipStream_t st);
+void launch_dec_fills(void *const *ptrs, const uint64_t *bytes, const uint32_t *values, int count, hipStream_t st);
 uint32_t fastwalk_cap();
 void launch_dec_fastwalk(const uint8_t *src, const StreamIn *streams, const uint32_t *elig, uint32_t n_elig, uint64_t max_len,
                          uint32_t *count, uint2 *cand, StreamWalk *walk, BlockDesc *cache, uint32_t *settled, hipStream_t st);
