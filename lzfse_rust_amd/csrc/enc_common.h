@@ -22,11 +22,26 @@ __host__ __device__ __forceinline__ uint32_t seg_ev_cap(uint32_t seg) { return (
 // 4 MiB stream -- a small window of the stream encoder -- enc_spec 0.48 -> 0.20, enc_stitch 0.03 -> 0.10 ms, the call 1.18 -> 0.98 ms,
 // hence 8 MiB and not 2); not for large batches: they are bound by the traffic of their records and events, to which more
 // walkers (each overrunning by OVER) only add (188 MB in 768 streams: no difference; 32 x 4 MiB: encode 27.2 -> 25.6 GB/s).
-__host__ __forceinline__ uint32_t seg_for(uint64_t positions, uint64_t longest) {
+// Round 4: a call of FEW streams gets the stitcher with several waves per stream (enc_stitch_kernel<STITCH_WAVES>, which takes
+// 64 boundaries per wave and step), and then quarter segments pay for large streams too: one 64 MiB stream, enc_spec + enc_stitch
+// 0.62 + 0.37 -> see DESIGN.md section 6 (up to 512 MiB of positions: the walkers' logs are 8 instead of 5 bytes per position).
+#ifndef LZMI_STITCH_WAVES
+#define LZMI_STITCH_WAVES 8
+#endif
+constexpr int STITCH_WAVES = LZMI_STITCH_WAVES;
+#ifndef LZMI_STITCH_FEW
+#define LZMI_STITCH_FEW 8
+#endif
+__host__ __forceinline__ int seg_stitch_waves(uint32_t n_streams) { return n_streams <= LZMI_STITCH_FEW ? STITCH_WAVES : 1; }
+__host__ __forceinline__ uint32_t seg_for(uint64_t positions, uint64_t longest, uint32_t n_streams) {
 #ifndef LZMI_SEG_SMALL_BATCH
 #define LZMI_SEG_SMALL_BATCH 24
 #define LZMI_SEG_SMALL_STREAM 8
 #endif
+#ifndef LZMI_SEG_FEW_MAX
+#define LZMI_SEG_FEW_MAX 32
+#endif
+    if (seg_stitch_waves(n_streams) > 1 && positions <= ((uint64_t)LZMI_SEG_FEW_MAX << 20)) return 512u;
     return (positions <= ((uint64_t)LZMI_SEG_SMALL_BATCH << 20) && longest <= ((uint64_t)LZMI_SEG_SMALL_STREAM << 20)) ? 512u : SEG;
 }
 constexpr uint32_t NONE = 0xFFFFFFFFu;      // no previous position

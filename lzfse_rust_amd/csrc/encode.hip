@@ -755,7 +755,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     // segment length of the speculative parse: one value for the batch (seg_for, enc_common.h)
     uint64_t batch_pos = 0;
     for (uint32_t si = 0; si < ns; si++) batch_pos += hs[si].n;
-    const uint32_t seg = seg_for(batch_pos, hs[0].n /* sorted: the longest */), ev_cap = seg_ev_cap(seg);
+    const uint32_t seg = seg_for(batch_pos, hs[0].n /* sorted: the longest */, ns), ev_cap = seg_ev_cap(seg);
     for (uint32_t si = 0; si < ns; si++) {
         EncStream &e = hs[si];
         e.pos_base = pos_total;

@@ -417,12 +417,13 @@ struct Stitch {
     uint32_t out_count;  // matches emitted so far
     uint32_t gap_open;   // first gap event of the currently open gap range
     int status;
+    bool writer;         // this wave stores what the functions below record (wave 0 of the stream's workgroup)
 };
 
 __device__ __forceinline__ void sx_add_range(Stitch &x, uint32_t kind, uint64_t begin, uint32_t count) {
     if (!count) return;
     if (x.n_ranges >= x.range_cap) { x.status = LZFSE_MI_IO; return; }
-    if (e_lane() == 0) {
+    if (e_lane() == 0 && x.writer) {
         RangeRec r;
         r.begin = begin; r.count = count; r.out_off = x.out_count; r.kind = kind;
         x.ranges[x.n_ranges] = r;
@@ -467,15 +468,24 @@ __device__ __forceinline__ void sx_mark_round(Stitch &x, uint32_t B) {
     x.g_marked = x.n_gaps;
 }
 
-// One wave per stream; control flow and values are wave-uniform.
-__global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
-                                                        uint32_t n_streams, uint32_t seg, const uint32_t *__restrict__ prev,
-                                                        const uint32_t *__restrict__ rec, const uint64_t *__restrict__ bitmap,
-                                                        const SpecEvent *__restrict__ logs, const SpecHeader *__restrict__ hdrs,
-                                                        const uint4 *__restrict__ sync, RangeRec *__restrict__ ranges,
-                                                        MatchRec *__restrict__ gaps, uint4 *__restrict__ gstate, EncStreamOut *__restrict__ outs) {
+// One wave per stream; control flow and values are wave-uniform. W > 1 (a call of few large streams, launch_enc_stitch): W waves
+// per stream. Following mode then takes 64 * W boundaries a step -- the max-plus maps compose across the waves as they do across
+// the lanes, every wave keeps its own copy of the (uniform) walk variables and all copies move alike -- and the true walk, which
+// is serial, is wave 0's alone: the others wait for what it leaves. With 512-position segments for such calls (seg_for) the
+// walkers of one 64 MiB stream are 2 048 waves instead of 512, each a fifth as long: enc_spec 0.62 -> 0.25 ms, and the four
+// times as many boundaries cost the stitcher less than the 32 768 did.
+template <int W>
+__global__ __launch_bounds__(64 * W) void enc_stitch_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
+                                                            uint32_t n_streams, uint32_t seg, const uint32_t *__restrict__ prev,
+                                                            const uint32_t *__restrict__ rec, const uint64_t *__restrict__ bitmap,
+                                                            const SpecEvent *__restrict__ logs, const SpecHeader *__restrict__ hdrs,
+                                                            const uint4 *__restrict__ sync, RangeRec *__restrict__ ranges,
+                                                            MatchRec *__restrict__ gaps, uint4 *__restrict__ gstate, EncStreamOut *__restrict__ outs) {
+    __shared__ int32_t s_cA[W], s_cB[W];          // a wave's composite map over the boundaries it may take
+    __shared__ uint32_t s_nb[W], s_nn[W], s_tot[W], s_st[8];
     const uint32_t si = blockIdx.x;
     if (si >= n_streams) return;
+    const int wv = W > 1 ? (int)(threadIdx.x >> 6) : 0;
     const EncStream &es = streams[si];
     const uint8_t *s = src + es.src_off;
     const uint32_t *pv = prev + es.pos_base;
@@ -495,6 +505,7 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
     x.gaps = gaps + es.match_base; x.n_gaps = 0; x.gap_cap = es.match_cap;
     x.gstate = gstate ? gstate + es.match_base : nullptr; x.g_marked = 0;
     x.out_count = 0; x.gap_open = 0; x.status = 0;
+    x.writer = wv == 0;
     uint32_t st_iters = 0, st_syncs = 0, st_fallbacks = 0;
     const uint64_t t_begin = __builtin_amdgcn_s_memtime();
 
@@ -508,71 +519,105 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
         walking = true;
         k = T.index / seg < K ? T.index / seg : K - 1;
     }
-    while (!done && !x.status) {
-        if (!walking) {
-            // Following mode, 64 boundaries per step (one per lane). With a = first not yet adopted event of the log
-            // being followed, a boundary synced at (i, j) hands over at i_eff = max(i, a - 1) and leaves
-            // a' = j + (i_eff - i) + 1 = max(j + 1, a + (j - i)): a max-plus map (A, B) = (j + 1, j - i). Such maps
-            // compose associatively, (A1, B1) then (A2, B2) = (max(A2, A1 + B2), B1 + B2), so the serial hand-over
-            // chain is a wave prefix scan and every lane writes its own range record.
-            const int lane = e_lane();
-            const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;
-            uint4 sy_l = make_uint4(0, 0, 0, 0);
-            if (k + lane + 1 < K) sy_l = sync[es.seg_base + k + lane];  // enc_sync_kernel: (found, i, j)
-            const uint64_t nf = __ballot(sy_l.x == 0);
-            const int nb = nf ? __builtin_ctzll(nf) : 64;  // boundaries before the first one without a sync point
-            if (nb > 0) {
-                const bool act = lane < nb;
-                const int32_t ii = (int32_t)sy_l.y, jj = (int32_t)sy_l.z;
-                // (identity of the composition: A = -inf, B = 0; the same six DPP steps as wave_incl_sum, earlier lanes on the left)
-                constexpr int32_t NEG = INT32_MIN / 2;
-                int32_t A = act ? jj + 1 : NEG, B = act ? jj - ii : 0;
+    // Following mode, 64 boundaries per wave and step (one per lane). With a = first not yet adopted event of the log
+    // being followed, a boundary synced at (i, j) hands over at i_eff = max(i, a - 1) and leaves
+    // a' = j + (i_eff - i) + 1 = max(j + 1, a + (j - i)): a max-plus map (A, B) = (j + 1, j - i). Such maps
+    // compose associatively, (A1, B1) then (A2, B2) = (max(A2, A1 + B2), B1 + B2), so the serial hand-over
+    // chain is a wave prefix scan and every lane writes its own range record.
+    auto follow = [&]() {
+        const int lane = e_lane();
+        const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+        const uint32_t kw = k + 64u * (uint32_t)wv;       // this wave's first boundary
+        uint4 sy_l = make_uint4(0, 0, 0, 0);
+        if (kw + lane + 1 < K) sy_l = sync[es.seg_base + kw + lane];  // enc_sync_kernel: (found, i, j)
+        const uint64_t nf = __ballot(sy_l.x == 0);
+        int nb = nf ? __builtin_ctzll(nf) : 64;  // boundaries before the first one without a sync point
+        const bool act0 = lane < nb;
+        const int32_t ii = (int32_t)sy_l.y, jj = (int32_t)sy_l.z;
+        // (identity of the composition: A = -inf, B = 0; the same six DPP steps as wave_incl_sum, earlier lanes on the left)
+        constexpr int32_t NEG = INT32_MIN / 2;
+        int32_t A = act0 ? jj + 1 : NEG, B = act0 ? jj - ii : 0;
 #define LZMI_MAXPLUS_STEP(CTRL, MASK)                                                                                   \
-                {                                                                                                        \
-                    const int32_t Al = (int32_t)dpp_take<CTRL, MASK>((uint32_t)NEG, (uint32_t)A), Bl = (int32_t)dpp_take<CTRL, MASK>(0u, (uint32_t)B); \
-                    const int32_t t = Al + B;                                                                            \
-                    A = A > t ? A : t; B = Bl + B;                                                                       \
-                }
-                LZMI_MAXPLUS_STEP(0x111, 0xF) LZMI_MAXPLUS_STEP(0x112, 0xF) LZMI_MAXPLUS_STEP(0x114, 0xF) LZMI_MAXPLUS_STEP(0x118, 0xF)
-                LZMI_MAXPLUS_STEP(0x142, 0xA) LZMI_MAXPLUS_STEP(0x143, 0xC)
-#undef LZMI_MAXPLUS_STEP
-                const int32_t a0 = (int32_t)a;
-                const int32_t a_out = A > a0 + B ? A : a0 + B;
-                const int32_t a_prev = (int32_t)dpp_take<0x138, 0xF>(0u, (uint32_t)a_out);   // wave_shr:1
-                const int32_t a_in = lane ? a_prev : a0;
-                const int32_t i_eff = (a_in > 0 && ii + 1 < a_in) ? a_in - 1 : ii;
-                const uint32_t cnt = (act && i_eff >= a_in) ? (uint32_t)(i_eff - a_in + 1) : 0u;
-                const uint32_t inc = wave_incl_sum(cnt);
-                const uint64_t hm = __ballot(cnt != 0);
-                const uint32_t n_new = (uint32_t)__popcll(hm), total = e_readlane(inc, 63);
-                if (x.n_ranges + n_new > x.range_cap) x.status = LZFSE_MI_IO;
-                else {
-                    if (cnt) {
-                        RangeRec r;
-                        r.begin = (uint64_t)(es.seg_base + k + lane) * ev_cap + (uint32_t)a_in;
-                        r.count = cnt; r.out_off = x.out_count + inc - cnt; r.kind = 0;
-                        x.ranges[x.n_ranges + (uint32_t)__popcll(hm & lt)] = r;
-                    }
-                    x.n_ranges += n_new;
-                    x.out_count += total;
-                    a = e_readlane((uint32_t)a_out, nb - 1);
-                    k += (uint32_t)nb;
-                    st_syncs += (uint32_t)nb;
-                }
-            }
-            if (nb < 64 && !x.status) {
-                // no sync point at boundary k: adopt the rest of log k and continue from its final state
-                const SpecHeader hk = H0[k];
-                if (hk.n_events > a) sx_add_range(x, 0, (uint64_t)(es.seg_base + k) * ev_cap + a, hk.n_events - a);
-                T.index = hk.f_index; T.lit = hk.f_lit; T.p_idx = hk.f_pidx; T.p_midx = hk.f_pmidx; T.p_len = hk.f_plen;
-                walking = true;
-                st_fallbacks++;
-                x.gap_open = x.n_gaps;
-            }
-            continue;
+        {                                                                                                                \
+            const int32_t Al = (int32_t)dpp_take<CTRL, MASK>((uint32_t)NEG, (uint32_t)A), Bl = (int32_t)dpp_take<CTRL, MASK>(0u, (uint32_t)B); \
+            const int32_t t = Al + B;                                                                                    \
+            A = A > t ? A : t; B = Bl + B;                                                                               \
         }
-        // ---- true walk (exact, scalar): frontend_bytes.rs:183-208 ----
-        if (T.index >= end) { done = true; break; }
+        LZMI_MAXPLUS_STEP(0x111, 0xF) LZMI_MAXPLUS_STEP(0x112, 0xF) LZMI_MAXPLUS_STEP(0x114, 0xF) LZMI_MAXPLUS_STEP(0x118, 0xF)
+        LZMI_MAXPLUS_STEP(0x142, 0xA) LZMI_MAXPLUS_STEP(0x143, 0xC)
+#undef LZMI_MAXPLUS_STEP
+        int32_t a0 = (int32_t)a;       // first not yet adopted event of the log this wave's first boundary hands over from
+        uint32_t consumed = (uint32_t)nb;
+        bool fail_here = nb < 64;      // the chain stops at a boundary of this step
+        if (W > 1) {
+            // the waves' composites, in order: a wave takes its boundaries only if every wave before it took all 64 of its own
+            if (lane == 0) {
+                s_cA[wv] = nb ? (int32_t)e_readlane((uint32_t)A, nb ? nb - 1 : 0) : NEG;
+                s_cB[wv] = nb ? (int32_t)e_readlane((uint32_t)B, nb ? nb - 1 : 0) : 0;
+                s_nb[wv] = (uint32_t)nb;
+            }
+            __syncthreads();
+            int32_t ac = (int32_t)a;
+            bool open = true;          // all waves before this one took 64
+            consumed = 0; fail_here = false;
+            for (int w = 0; w < W; w++) {
+                if (w == wv) { a0 = ac; if (!open) nb = 0; }
+                if (!open) continue;
+                const uint32_t nbw = s_nb[w];
+                if (nbw) { const int32_t t2 = ac + s_cB[w]; ac = s_cA[w] > t2 ? s_cA[w] : t2; }
+                consumed += nbw;
+                if (nbw < 64) { open = false; fail_here = true; }
+            }
+            a = (uint32_t)ac;          // (taken over below unless the step is refused)
+        }
+        const bool act = lane < nb;
+        const int32_t a_out = A > a0 + B ? A : a0 + B;
+        const int32_t a_prev = (int32_t)dpp_take<0x138, 0xF>(0u, (uint32_t)a_out);   // wave_shr:1
+        const int32_t a_in = lane ? a_prev : a0;
+        const int32_t i_eff = (a_in > 0 && ii + 1 < a_in) ? a_in - 1 : ii;
+        const uint32_t cnt = (act && i_eff >= a_in) ? (uint32_t)(i_eff - a_in + 1) : 0u;
+        const uint32_t inc = wave_incl_sum(cnt);
+        const uint64_t hm = __ballot(cnt != 0);
+        uint32_t n_new = (uint32_t)__popcll(hm), total = e_readlane(inc, 63);
+        uint32_t r_base = x.n_ranges, o_base = x.out_count;
+        if (W > 1) {
+            if (lane == 0) { s_nn[wv] = n_new; s_tot[wv] = total; }
+            __syncthreads();
+            n_new = 0; total = 0;
+            for (int w = 0; w < W; w++) {
+                if (w == wv) { r_base += n_new; o_base += total; }
+                n_new += s_nn[w]; total += s_tot[w];
+            }
+            __syncthreads();           // (the arrays are written again by the next step)
+        } else if (nb > 0) a = e_readlane((uint32_t)a_out, nb - 1);
+        if (consumed > 0) {
+            if (x.n_ranges + n_new > x.range_cap) x.status = LZFSE_MI_IO;
+            else {
+                if (cnt) {
+                    RangeRec rr;
+                    rr.begin = (uint64_t)(es.seg_base + kw + lane) * ev_cap + (uint32_t)a_in;
+                    rr.count = cnt; rr.out_off = o_base + inc - cnt; rr.kind = 0;
+                    x.ranges[r_base + (uint32_t)__popcll(hm & lt)] = rr;
+                }
+                x.n_ranges += n_new;
+                x.out_count += total;
+                k += consumed;
+                st_syncs += consumed;
+            }
+        }
+        if (fail_here && !x.status) {
+            // no sync point at boundary k: adopt the rest of log k and continue from its final state
+            const SpecHeader hk = H0[k];
+            if (hk.n_events > a) sx_add_range(x, 0, (uint64_t)(es.seg_base + k) * ev_cap + a, hk.n_events - a);
+            T.index = hk.f_index; T.lit = hk.f_lit; T.p_idx = hk.f_pidx; T.p_midx = hk.f_pmidx; T.p_len = hk.f_plen;
+            walking = true;
+            st_fallbacks++;
+            x.gap_open = x.n_gaps;
+        }
+    };
+    // ---- one step of the true walk (exact, scalar): frontend_bytes.rs:183-208 ----
+    auto walk_step = [&]() {
+        if (T.index >= end) { done = true; return; }
         uint32_t p = next_has_wave(bm, T.index, end);
         if (rounds) {
             // positions without a candidate are single steps of match_long: every round end B in (T.index, p] is reached
@@ -587,7 +632,7 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
                     sx_mark_round(x, B);
                 }
         }
-        if (p >= end) { T.index = end; done = true; break; }
+        if (p >= end) { T.index = end; done = true; return; }
         st_iters++;
         T.index = p;
         const uint32_t rr = r[p];
@@ -623,7 +668,7 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
         if (emitted) {
             sx_gap_event(x, lit_before, e_idx, e_len, e_idx - e_midx);
             T.lit = e_idx + e_len;
-            if (T.lit >= end) { T.index = end; done = true; break; }
+            if (T.lit >= end) { T.index = end; done = true; return; }
             T.index = (p + 1 > T.lit) ? p + 1 : T.lit;
         } else {
             T.index = p + 1;
@@ -645,7 +690,7 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
             // does the log of the segment we are in agree with this state?
             uint32_t kk = T.index / seg;
             if (kk >= K) kk = K - 1;
-            if (kk > k || (kk == k && false)) {
+            if (kk > k) {
                 const SpecHeader hh = H0[kk];
                 const SpecEvent *Lkk = L0 + (uint64_t)kk * ev_cap;
                 uint32_t j = ev_lower_bound(Lkk, hh.n_events, T.index);
@@ -659,7 +704,24 @@ __global__ __launch_bounds__(64) void enc_stitch_kernel(const uint8_t *__restric
                 }
             }
         }
+    };
+    while (!done && !x.status) {
+        if (!walking) { follow(); continue; }
+        if (W == 1) { walk_step(); continue; }
+        // the true walk is wave 0's; the others take over what it leaves
+        if (wv == 0) {
+            do walk_step(); while (walking && !done && !x.status);
+            if (e_lane() == 0) {
+                s_st[0] = k; s_st[1] = a; s_st[2] = x.n_ranges; s_st[3] = x.out_count; s_st[4] = (uint32_t)x.status;
+                s_st[5] = (walking ? 1u : 0u) | (done ? 2u : 0u);
+            }
+        }
+        __syncthreads();
+        k = s_st[0]; a = s_st[1]; x.n_ranges = s_st[2]; x.out_count = s_st[3]; x.status = (int)s_st[4];
+        walking = (s_st[5] & 1u) != 0; done = (s_st[5] & 2u) != 0;
+        __syncthreads();
     }
+    if (wv != 0) return;
     if (!x.status) {
         if (!walking) {
             // left the loop while following: cannot happen (the last segment always ends in walking mode)
@@ -1303,8 +1365,12 @@ void launch_enc_stitch(const uint8_t *src, const EncStream *streams, uint32_t ns
                        const uint32_t *rec, const uint64_t *bitmap, const SpecEvent *logs, const SpecHeader *hdrs, uint4 *sync,
                        RangeRec *ranges, MatchRec *gaps, uint4 *gstate, EncStreamOut *outs, hipStream_t st) {
     hipLaunchKernelGGL(enc_sync_kernel, dim3((n_segs + 63) / 64), dim3(64), 0, st, streams, segs, n_segs, seg, logs, hdrs, sync);
-    hipLaunchKernelGGL(enc_stitch_kernel, dim3(ns), dim3(64), 0, st, src, streams, ns, seg, prev, rec, bitmap, logs, hdrs, sync, ranges, gaps,
-                       gstate, outs);
+    if (seg_stitch_waves(ns) > 1)
+        hipLaunchKernelGGL(enc_stitch_kernel<STITCH_WAVES>, dim3(ns), dim3(64 * STITCH_WAVES), 0, st, src, streams, ns, seg, prev, rec, bitmap, logs,
+                           hdrs, sync, ranges, gaps, gstate, outs);
+    else
+        hipLaunchKernelGGL(enc_stitch_kernel<1>, dim3(ns), dim3(64), 0, st, src, streams, ns, seg, prev, rec, bitmap, logs, hdrs, sync, ranges, gaps,
+                           gstate, outs);
 }
 void launch_enc_cut(const EncStream *streams, uint32_t ns, const EncStreamOut *outs, const EncBlock *blocks, const RangeRec *ranges,
                     const SpecEvent *logs, const MatchRec *gaps, const uint4 *gstate, EncCut *cuts, hipStream_t st) {

@@ -223,6 +223,33 @@ def test_encode_random_structures_bit_exact(ctx, oracle):
         assert o.tobytes() == r
 
 
+def test_encode_few_streams_many_waves_per_stream(ctx, oracle, snappy_raw):
+    """Calls of at most 8 streams run the stitcher with 8 waves per stream (enc_stitch_kernel<8>: 512 boundaries a step, the
+    true walk by wave 0 while the others wait) and, up to 32 MiB, quarter segments: data whose segment logs do not meet
+    (runs, periods, deserts of noise between text) in calls of 1, 3 and 8 streams, both parses, and one call beyond 32 MiB
+    (2 048-position segments, still 8 waves)."""
+    rng = np.random.default_rng(99)
+    text = snappy_raw["lcet10.txt"] + snappy_raw["plrabn12.txt"]
+    noise = lambda n: rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+    kinds = [bytes(3 << 20),                                            # one run
+             (noise(1100) * 3000)[:3 << 20],                            # period 1 100
+             text[:700000] + noise(400000) + text[200000:900000] + bytes(300000) + text[:500000],
+             b"".join(bytes([int(v)]) * int(c) for v, c in zip(rng.integers(0, 256, 1500), rng.integers(1, 6000, 1500)))[:2500000],
+             text * 2, noise(1 << 20), (text[:65000] + noise(300)) * 40, text[:4097 + 64 * 1024]]
+    for ns in (1, 3, 8):
+        raws = kinds[:ns] if ns > 1 else [kinds[2]]
+        for ring in (False, True):
+            outs, st = ctx.encode_batch(raws, ring=ring)
+            assert all(e == 0 for e in st)
+            for r, o in zip(raws, outs):
+                assert o.tobytes() == (oracle.ring_encode(r) if ring else oracle.encode(r)), (ns, ring, len(r))
+    big = [text * 24, kinds[2] * 3]        # 39 MB in two streams: the large-call segments under the many-wave stitcher
+    outs, st = ctx.encode_batch(big)
+    assert all(e == 0 for e in st)
+    for r, o in zip(big, outs):
+        assert o.tobytes() == oracle.encode(r), len(r)
+
+
 def test_encode_tile_and_batch_edges_bit_exact(ctx, diag_ctx, oracle, snappy_raw):
     """Stream lengths around the edges of the match-finding kernels: the 65 472-position chain tile (last tile of 1, 2,
     63 positions; exactly full), the 2 048-position batch of the chain kernel (tail batch of 1 / 2 047 positions), the
