@@ -249,9 +249,12 @@ LZFSE_MI_API int lzfse_mi_encode_ring_batch_device(lzfse_mi_ctx *ctx, size_t cou
  * LZFSE_MI_STREAM_WINDOW, at least 1 MiB): the reference's ring encoder decides everything about a position from the 256 KiB
  * behind and ahead of it, so the blocks of a window that end more than that before its last byte are final -- they leave
  * through `write` during feed, and the object keeps only what the parse may still reach back to (328 KiB) plus the input it
- * has not finished with. Memory: about window + 600 KiB of input and one window's output, whatever the length of the
- * stream (inputs that are a few matches of many MiB each can take longer to yield a final block; the window grows then).
- * The bytes are those of lzfse_mi_encode_ring on the whole input, whatever the window and the pieces. Used once. */
+ * has not finished with. A window that is not the stream's last is encoded in the BACKGROUND (a helper thread of the object,
+ * a context of the library's own beside `ctx`), while feed returns and takes the next window's input: its blocks leave
+ * through `write` in a later feed, or in finish -- always on the caller's thread, in stream order -- and an error it met is
+ * returned by that call. Memory (pinned host memory): up to three windows of input and one window's output, whatever the
+ * length of the stream (inputs that are a few matches of many MiB each can take longer to yield a final block; the window
+ * grows then). The bytes are those of lzfse_mi_encode_ring on the whole input, whatever the window and the pieces. Used once. */
 typedef struct lzfse_mi_estream lzfse_mi_estream;
 LZFSE_MI_API int lzfse_mi_estream_create(lzfse_mi_ctx *ctx, size_t window, lzfse_mi_estream **out);
 LZFSE_MI_API int lzfse_mi_estream_feed(lzfse_mi_estream *s, const uint8_t *src, size_t n, lzfse_mi_write_fn write, void *user);

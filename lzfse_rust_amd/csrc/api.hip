@@ -59,48 +59,6 @@ struct HostBuf {  // pinned staging
 
 #define LZFSE_MI_MAX_LANES 4
 
-namespace {
-// One helper thread per shadow context, alive as long as the context: a split batch call hands it a sub-batch and
-// waits for it, instead of creating and joining threads per call.
-class LaneWorker {
-  public:
-    LaneWorker() : th_([this] { loop(); }) {}
-    ~LaneWorker() {
-        { std::lock_guard<std::mutex> g(m_); quit_ = true; }
-        cv_.notify_all();
-        if (th_.joinable()) th_.join();
-    }
-    void submit(std::function<void()> job) {
-        { std::lock_guard<std::mutex> g(m_); job_ = std::move(job); busy_ = true; }
-        cv_.notify_all();
-    }
-    void wait() {
-        std::unique_lock<std::mutex> g(m_);
-        cv_.wait(g, [&] { return !busy_; });
-    }
-  private:
-    void loop() {
-        for (;;) {
-            std::function<void()> job;
-            {
-                std::unique_lock<std::mutex> g(m_);
-                cv_.wait(g, [&] { return quit_ || (busy_ && job_); });
-                if (quit_) return;
-                job = std::move(job_);
-                job_ = nullptr;
-            }
-            job();
-            { std::lock_guard<std::mutex> g(m_); busy_ = false; }
-            cv_.notify_all();
-        }
-    }
-    std::mutex m_;
-    std::condition_variable cv_;
-    std::function<void()> job_;
-    bool busy_ = false, quit_ = false;
-    std::thread th_;   // last member: the thread starts when everything above exists
-};
-}  // namespace
 
 struct lzfse_mi_ctx {
     int device = 0;
@@ -150,6 +108,7 @@ struct lzfse_mi_ctx {
     std::mutex stream_refs_m;
     lzmi::EncWindow *window = nullptr;   // set for the duration of one window of a stream encode (stream.hip)
     bool pinned_out = false;             // ... of one window of either stream object: the destination is pinned memory
+    std::shared_ptr<lzmi::StreamBox> stream_box;   // where stream objects run windows in the background (internal.h)
     bool parse_ring = false;   // set for the duration of a ring / stream encode call (lzfse_mi_encode_ring*, lzfse_mi_estream_*)
     int diag_lz_jump = -1, diag_lz_variant = -1, diag_stats = 0, diag_chain = 0, diag_walk = 0, diag_pipe_scatter = 0;  // diagnostic build only
     uint64_t diag_last_lmds = 0;   // LMD records the entropy stage of the last decode pass on this context left in d_lmds (stage hook)
@@ -196,6 +155,22 @@ void ctx_detach(lzfse_mi_ctx *c, lzfse_mi_ctx **ref) {
 }
 void ctx_set_window(lzfse_mi_ctx *c, EncWindow *w) { c->window = w; }
 void ctx_set_pinned_out(lzfse_mi_ctx *c, bool on) { c->pinned_out = on; }
+std::shared_ptr<StreamBox> ctx_stream_box(lzfse_mi_ctx *c) {
+    std::lock_guard<std::mutex> g(c->stream_refs_m);
+    if (!c->stream_box) {
+        try { c->stream_box = std::make_shared<StreamBox>(); } catch (...) { return nullptr; }
+        c->stream_box->device = c->device;
+    }
+    return c->stream_box;
+}
+lzfse_mi_ctx *box_peer(StreamBox &b) {
+    if (b.dead) return nullptr;
+    if (!b.peer) {
+        if (lzfse_mi_create(b.device, &b.peer) != LZFSE_MI_OK) { b.peer = nullptr; return nullptr; }
+        b.peer->is_peer = true;
+    }
+    return b.peer;
+}
 int ctx_diag_chain(lzfse_mi_ctx *c) { return c->diag_chain; }
 }  // namespace lzmi
 
@@ -313,6 +288,13 @@ void lzfse_mi_destroy(lzfse_mi_ctx *c) {
         std::lock_guard<std::mutex> g(c->stream_refs_m);
         for (lzfse_mi_ctx **r : c->stream_refs) *r = nullptr;
         c->stream_refs.clear();
+    }
+    if (c->stream_box) {
+        // (a window in flight on the stream objects' context finishes first: its job holds the mutex)
+        std::lock_guard<std::mutex> g(c->stream_box->m);
+        c->stream_box->dead = true;
+        if (c->stream_box->peer) lzfse_mi_destroy(c->stream_box->peer);
+        c->stream_box->peer = nullptr;
     }
     for (auto &w : c->worker) { delete w; w = nullptr; }
     for (auto &s : c->shadow) { if (s) lzfse_mi_destroy(s); s = nullptr; }

@@ -5,6 +5,9 @@
 #include <algorithm>
 #include <chrono>
 #include <cstring>
+#include <functional>
+#include <memory>
+#include <thread>
 #include <condition_variable>
 #include <mutex>
 #include <vector>
@@ -12,6 +15,47 @@
 struct lzfse_mi_ctx;
 
 namespace lzmi {
+
+// One helper thread per shadow context, alive as long as the context: a split batch call hands it a sub-batch and
+// waits for it, instead of creating and joining threads per call.
+class LaneWorker {
+  public:
+    LaneWorker() : th_([this] { loop(); }) {}
+    ~LaneWorker() {
+        { std::lock_guard<std::mutex> g(m_); quit_ = true; }
+        cv_.notify_all();
+        if (th_.joinable()) th_.join();
+    }
+    void submit(std::function<void()> job) {
+        { std::lock_guard<std::mutex> g(m_); job_ = std::move(job); busy_ = true; }
+        cv_.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [&] { return !busy_; });
+    }
+  private:
+    void loop() {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return quit_ || (busy_ && job_); });
+                if (quit_) return;
+                job = std::move(job_);
+                job_ = nullptr;
+            }
+            job();
+            { std::lock_guard<std::mutex> g(m_); busy_ = false; }
+            cv_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::function<void()> job_;
+    bool busy_ = false, quit_ = false;
+    std::thread th_;   // last member: the thread starts when everything above exists
+};
 
 // brackets kernel launches with HIP events on the context's stream (lzfse_mi_get_timings)
 struct StageTimer {
@@ -99,6 +143,18 @@ StreamSpare &ctx_spare(lzfse_mi_ctx *c);
 // to freed memory nor runs a call on it (include/lzfse_mi.h: either order of destruction is allowed).
 void ctx_attach(lzfse_mi_ctx *c, lzfse_mi_ctx **ref);
 void ctx_detach(lzfse_mi_ctx *c, lzfse_mi_ctx **ref);
+// The context a stream object's windows run on when they run in the BACKGROUND (a window of the stream encoder is encoded by a
+// helper thread while the caller goes on feeding): a context of its own beside the caller's, made when first needed and shared by
+// the stream objects of that context, one window at a time (`m`). The box outlives whichever of context and stream objects goes
+// first: lzfse_mi_destroy takes `m`, destroys `peer` and marks the box dead.
+struct StreamBox {
+    std::mutex m;
+    lzfse_mi_ctx *peer = nullptr;
+    int device = 0;
+    bool dead = false;
+};
+std::shared_ptr<StreamBox> ctx_stream_box(lzfse_mi_ctx *c);
+lzfse_mi_ctx *box_peer(StreamBox &b);   // under b.m: the peer context (created here), null when dead or not to be had
 void ctx_set_window(lzfse_mi_ctx *c, EncWindow *w);
 // the destination of the host-pointer call that follows is pinned memory: its output travels straight there (stream.hip)
 void ctx_set_pinned_out(lzfse_mi_ctx *c, bool on);

@@ -293,17 +293,32 @@ LZFSE_MI_API int lzfse_mi_dstream_feed(lzfse_mi_dstream *s, const uint8_t *src, 
 struct lzfse_mi_estream {
     lzfse_mi_ctx *ctx = nullptr;
     size_t window = 0;            // new input bytes per device call
-    PinBuf buf;                   // the input from position `base` on: what the parse may still look at, and what it has not seen yet (pinned, like `out`)
-    uint64_t base = 0;            // position of buf[0] in the stream, a multiple of 16 KiB
+    PinBuf buf;                   // buf[head ..]: the input from position `base` on: what the parse may still look at, and what it has not seen yet (pinned, like `out`)
+    size_t head = 0;              // (what lies below it is dropped when the buffer is next put in order: never while a window is in flight)
+    size_t live() const { return buf.size - head; }
+    uint64_t base = 0;            // position of buf[head] in the stream, a multiple of 16 KiB
     bool have_state = false;      // a window has been cut: the parse goes on from `st` (positions relative to base)
     uint32_t st[5] = {};          // index, literal_index, pending (idx, match idx, len): encode/frontend_ring.rs' idx, literal_idx, pending
     uint32_t skip = 0;            // bytes of the first event the parse makes from there that have left already (a block ended inside it)
-    size_t next_at = 0;           // buf.size() at which the next window is tried
+    size_t next_at = 0;           // live() at which the next window is tried
     PinBuf out;                   // one window's bytes
     uint64_t total_in = 0, total_out = 0;
     int status = 0;               // sticky
     bool finished = false;
+    // A window that is not the last is encoded in the BACKGROUND, on the stream objects' own context (StreamBox), while the caller
+    // goes on feeding: the copy of a window's input into `buf` takes about as long as the device takes for the window before.
+    // What the window made leaves through `write` at the caller's next call that gets that far (es_complete); `buf` neither moves
+    // nor shrinks while a window is in flight, and bytes behind the window's end are the caller's to append.
+    std::shared_ptr<StreamBox> box;
+    LaneWorker *worker = nullptr;
+    bool pending = false;
+    size_t pend_n = 0, pend_len = 0;
+    int pend_st = 0;
+    EncWindow pend_w;
+    void wait_idle() { if (worker && pending) worker->wait(); }
     ~lzfse_mi_estream() {
+        wait_idle();
+        delete worker;
         if (!ctx) return;   // (the context went first)
         ctx_detach(ctx, &ctx);
         StreamSpare &sp = ctx_spare(ctx);
@@ -330,53 +345,97 @@ int es_write(lzfse_mi_estream *s, lzfse_mi_write_fn write, void *user, size_t le
     return 0;
 }
 
-// One device call over everything on hand. final: the input ends here. Otherwise the window is cut behind its last block
-// that no later byte can change (enc_cut_kernel, encode_parse.hip), those blocks leave through `write`, and the buffer
-// keeps what the parse still needs: E_KEEP bytes below the literal index of the cut, and everything from there on.
-int es_window(lzfse_mi_estream *s, bool final, lzfse_mi_write_fn write, void *user) {
-    const size_t n = s->buf.size;
-    struct PinnedOut {   // (the window's bytes land in `out`: pinned memory)
-        lzfse_mi_ctx *c;
-        explicit PinnedOut(lzfse_mi_ctx *ctx) : c(ctx) { ctx_set_pinned_out(c, true); }
-        ~PinnedOut() { ctx_set_pinned_out(c, false); }
-    } pinned(s->ctx);
-    if (final && !s->have_state) {
+// One device call over the first n bytes on hand, on context c. w: the window's state in, where it was cut out.
+int es_call(lzfse_mi_ctx *c, lzfse_mi_estream *s, size_t n, EncWindow *w, size_t cap, size_t *len) {
+    ctx_set_pinned_out(c, true);   // (the window's bytes land in `out`: pinned memory)
+    ctx_set_window(c, w);
+    const int st = lzfse_mi_encode_ring(c, s->buf.p + s->head, n, s->out.p, cap, len);
+    ctx_set_window(c, nullptr);
+    ctx_set_pinned_out(c, false);
+    return st;
+}
+
+// The input ends here: one call over everything on hand, on the caller's context (nothing is in flight).
+int es_final(lzfse_mi_estream *s, lzfse_mi_write_fn write, void *user) {
+    const size_t n = s->live();
+    const size_t cap = lzfse_mi_encode_bound(n);
+    if (es_out_room(s, cap ? cap : 1)) return LZFSE_MI_IO;
+    size_t len = 0;
+    if (!s->have_state) {
         // the whole input in one call (all size classes)
-        const size_t cap = lzfse_mi_encode_bound(n);
-        if (es_out_room(s, cap ? cap : 1)) return LZFSE_MI_IO;
-        size_t len = 0;
-        const int st = lzfse_mi_encode_ring(s->ctx, s->buf.p, n, s->out.p, cap, &len);
+        const int st = es_call(s->ctx, s, n, nullptr, cap, &len);
         return st ? st : es_write(s, write, user, len);
     }
     if (n > (size_t)0x7FFFFFFFu) return LZFSE_MI_UNSUPPORTED;   // positions are 31 bits on the device
-    const size_t cap = lzfse_mi_encode_bound(n);
-    if (es_out_room(s, cap)) return LZFSE_MI_IO;
     EncWindow w;
-    w.start = s->have_state; w.beyond = s->base != 0; w.final = final;
+    w.start = true; w.beyond = s->base != 0; w.final = true;
     for (int k = 0; k < 5; k++) w.st[k] = s->st[k];
     w.skip = s->skip;
-    size_t len = 0;
-    ctx_set_window(s->ctx, &w);
-    const int st = lzfse_mi_encode_ring(s->ctx, s->buf.p, n, s->out.p, cap, &len);
-    ctx_set_window(s->ctx, nullptr);
-    if (st) return st;
-    if (final) return es_write(s, write, user, len);
+    const int st = es_call(s->ctx, s, n, &w, cap, &len);
+    return st ? st : es_write(s, write, user, len);
+}
+
+// A window that is not the last: everything on hand goes to the device as one call, in the background. The window will be
+// cut behind its last block that no later byte can change (enc_cut_kernel, encode_parse.hip).
+int es_launch(lzfse_mi_estream *s) {
+    const size_t n = s->live();
+    if (n > (size_t)0x7FFFFFFFu) return LZFSE_MI_UNSUPPORTED;   // positions are 31 bits on the device
+    const size_t cap = lzfse_mi_encode_bound(n);
+    if (es_out_room(s, cap)) return LZFSE_MI_IO;
+    // The caller appends behind the window while it is in flight, so `buf` must neither move nor run out meanwhile: room for
+    // another window's worth behind what is on hand. The bytes of earlier windows that nothing needs any more (below `head`) are
+    // dropped here, when the room is short -- every other window with three windows of room -- and not after every window.
+    const size_t slack = s->window + ((size_t)1 << 16);
+    if (s->buf.size + slack > s->buf.cap) {
+        if (s->head) { s->buf.erase_front(s->head); s->head = 0; }
+        if (s->buf.size + slack > s->buf.cap && !s->buf.reserve(s->buf.size + 2 * slack)) return LZFSE_MI_IO;
+    }
+    if (!s->worker) {
+        try { s->worker = new (std::nothrow) LaneWorker(); } catch (...) { s->worker = nullptr; }
+    }
+    EncWindow &w = s->pend_w;
+    w = EncWindow();
+    w.start = s->have_state; w.beyond = s->base != 0; w.final = false;
+    for (int k = 0; k < 5; k++) w.st[k] = s->st[k];
+    w.skip = s->skip;
+    s->pend_n = n; s->pend_len = 0; s->pend_st = 0;
+    auto job = [s, n, cap] {
+        StreamBox *b = s->box.get();
+        if (!b) { s->pend_st = LZFSE_MI_IO; return; }
+        std::lock_guard<std::mutex> g(b->m);
+        lzfse_mi_ctx *c = box_peer(*b);
+        s->pend_st = c ? es_call(c, s, n, &s->pend_w, cap, &s->pend_len) : (b->dead ? LZFSE_MI_BAD_ARGUMENT : LZFSE_MI_IO);
+    };
+    s->pending = true;
+    if (s->worker) s->worker->submit(job);
+    else job();   // (no thread to be had: the window runs here)
+    return 0;
+}
+
+// What the window in flight made: its final blocks leave through `write`, and the buffer keeps what the parse still needs:
+// E_KEEP bytes below the literal index of the cut, and everything from there on.
+int es_complete(lzfse_mi_estream *s, lzfse_mi_write_fn write, void *user) {
+    s->wait_idle();
+    s->pending = false;
+    if (s->pend_st) return s->pend_st;
+    const EncWindow &w = s->pend_w;
+    const size_t n = s->pend_n;
     if (!w.found) {
         // no block of this window is final yet (few, very long matches: a block of 10 000 LMDs can span many MiB): more input first
         s->next_at = n + (n > s->window ? n : s->window);
         return 0;
     }
-    if (const int e = es_write(s, write, user, len)) return e;
+    if (const int e = es_write(s, write, user, s->pend_len)) return e;
     size_t keep = w.lit > E_KEEP ? (size_t)w.lit - E_KEEP : 0;
     keep &= ~(size_t)(0x4000 - 1);
-    s->buf.erase_front(keep);
+    s->head += keep;
     s->base += keep;
     const uint32_t k32 = (uint32_t)keep;
     s->st[0] = w.index - k32; s->st[1] = w.lit - k32;
     s->st[2] = w.p_len ? w.p_idx - k32 : 0; s->st[3] = w.p_len ? w.p_midx - k32 : 0; s->st[4] = w.p_len;
     s->skip = w.skip_out;
     s->have_state = true;
-    s->next_at = s->buf.size + s->window;
+    s->next_at = (n - keep) + s->window;
     return 0;
 }
 
@@ -390,6 +449,7 @@ int lzfse_mi_estream_create(lzfse_mi_ctx *ctx, size_t window, lzfse_mi_estream *
     if (!s) return LZFSE_MI_IO;
     s->ctx = ctx;
     ctx_attach(ctx, &s->ctx);
+    s->box = ctx_stream_box(ctx);
     s->window = window ? window : (size_t)LZFSE_MI_STREAM_WINDOW;
     if (s->window < E_MIN_WINDOW) s->window = E_MIN_WINDOW;
     if (s->window > ((size_t)1 << 30)) s->window = (size_t)1 << 30;
@@ -407,21 +467,28 @@ int lzfse_mi_estream_create(lzfse_mi_ctx *ctx, size_t window, lzfse_mi_estream *
 void lzfse_mi_estream_destroy(lzfse_mi_estream *s) { delete s; }
 
 // Write::write of LzfseWriter (encode/writer.rs:59-63): takes all of buf; whenever a window's worth of input is on hand the
-// device encodes it and the blocks that are final leave through `write`
+// device encodes it -- in the background, while this call and the next ones take more input -- and the blocks that are final
+// leave through `write` as soon as a call finds the window done
 int lzfse_mi_estream_feed(lzfse_mi_estream *s, const uint8_t *src, size_t n, lzfse_mi_write_fn write, void *user) {
     if (!s || (!src && n) || !write || s->finished) return LZFSE_MI_BAD_ARGUMENT;
     if (s->status) return s->status;
     if (!s->ctx) return s->status = LZFSE_MI_BAD_ARGUMENT;   // its context has been destroyed
     while (n) {
-        const size_t room = s->next_at > s->buf.size ? s->next_at - s->buf.size : 0;
+        // room: up to where the next window is tried; with a window in flight also no further than `buf` reaches without moving
+        size_t room = s->next_at > s->live() ? s->next_at - s->live() : 0;
+        if (s->pending && room > s->buf.cap - s->buf.size) room = s->buf.cap - s->buf.size;
+        if (room == 0) {
+            if (s->pending) { if (const int st = es_complete(s, write, user)) return s->status = st; continue; }
+            if (const int st = es_launch(s)) return s->status = st;
+            s->next_at = s->live() + s->window;        // (until the window says where it was cut)
+            continue;
+        }
         const size_t take = n < room ? n : room;
         // (room for the whole window at once, as soon as the input shows that it will be needed: growing step by step copies
         // the window's bytes again and again and pins twice the pages)
-        if (s->buf.cap < s->next_at && s->buf.size + take > ((size_t)4 << 20) && !s->buf.reserve(s->next_at + ((size_t)1 << 16))) return s->status = LZFSE_MI_IO;
+        if (!s->pending && s->buf.cap < s->head + s->next_at && s->buf.size + take > ((size_t)4 << 20) && !s->buf.reserve(s->head + s->next_at + ((size_t)1 << 16))) return s->status = LZFSE_MI_IO;
         if (!s->buf.append(src, take)) return s->status = LZFSE_MI_IO;
         src += take; n -= take; s->total_in += take;
-        if (s->buf.size >= s->next_at)
-            if (const int st = es_window(s, false, write, user)) return s->status = st;
     }
     return LZFSE_MI_OK;
 }
@@ -430,12 +497,14 @@ int lzfse_mi_estream_feed(lzfse_mi_estream *s, const uint8_t *src, size_t n, lzf
 int lzfse_mi_estream_finish(lzfse_mi_estream *s, lzfse_mi_write_fn write, void *user, uint64_t *bytes_in, uint64_t *bytes_out) {
     if (!s || !write || s->finished) return LZFSE_MI_BAD_ARGUMENT;
     s->finished = true;
-    if (s->status) return s->status;
-    if (!s->ctx) return s->status = LZFSE_MI_BAD_ARGUMENT;   // its context has been destroyed
-    const int st = es_window(s, true, write, user);
+    if (s->status) { s->wait_idle(); s->pending = false; return s->status; }
+    if (!s->ctx) { s->wait_idle(); s->pending = false; return s->status = LZFSE_MI_BAD_ARGUMENT; }   // its context has been destroyed
+    int st = 0;
+    if (s->pending) st = es_complete(s, write, user);
+    if (!st) st = es_final(s, write, user);
     if (bytes_in) *bytes_in = s->total_in;
     if (bytes_out) *bytes_out = st ? 0 : s->total_out;
-    s->buf.size = 0;   // (its room goes back to the context with the object)
+    s->buf.size = 0; s->head = 0;   // (its room goes back to the context with the object)
     return s->status = st;
 }
 
