@@ -210,10 +210,15 @@ LZFSE_MI_API size_t lzfse_mi_decode_headroom(const uint8_t *src, size_t n);
  * that completes the evidence (sticky afterwards). finish != 0 marks the end of the input: a stream that does not end
  * with bvx$ in its last 4 bytes is an error (decode/decoder.rs:93-95). `window` (0 = LZFSE_MI_STREAM_WINDOW) is the
  * number of raw bytes decoded per device call: a window's blocks are decoded when they are all there (or the input
- * ends), so output follows input by up to a window. `write` returns 0 to go on. */
+ * ends), so output follows input by up to a window. A full window with more input to come is decoded in the BACKGROUND (a
+ * helper thread of the object, a context of the library's own beside `ctx`): its bytes reach `write` -- on the caller's
+ * thread, in stream order -- in the feed call that sends the NEXT window off, or in the one that ends the input, so output
+ * follows input by up to two windows, and an error a window met is returned by that call (the windows before it have been
+ * written by then). Memory (pinned host memory): the input not yet decoded, a copy of the window in flight, and two windows
+ * of output. `write` returns 0 to go on. */
 /* (a window is ONE stream on the device, and one stream costs its latency floors -- a block's entropy chain, the header
- * walk -- whatever its size: through the Python mirror 64 MiB windows decode 256 MiB of text at 9.4 GB/s, 16 MiB windows at 5.5,
- * 4 MiB windows at 2.2; the slice call into a reused buffer reaches 15: profiles/r03_stream_bench.txt) */
+ * walk -- whatever its size: through the Python mirror 64 MiB windows decode 256 MiB of text at 11.6 GB/s, 16 MiB windows at 6.9,
+ * 4 MiB windows at 2.4; the slice call into a reused buffer reaches 15: profiles/r04_stream_bench.txt) */
 #define LZFSE_MI_STREAM_WINDOW ((size_t)64 << 20)
 typedef struct lzfse_mi_dstream lzfse_mi_dstream;
 typedef int (*lzfse_mi_write_fn)(void *user, const uint8_t *bytes, size_t n);

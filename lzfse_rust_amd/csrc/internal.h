@@ -132,9 +132,10 @@ struct PinBuf {
 };
 // Host buffers of the stream objects that outlive them: a stream object's window buffers are tens of MiB, and pinned pages
 // cost more to get than the window's decode -- the next stream object of the context takes over what the last one left
-// (0: decoder input, 1: decoder output, 2: encoder input, 3: encoder output).
+// (0: decoder input, 1: decoder output of a window decoded in the call, 2: encoder input, 3: encoder output, 4: the copy of a
+// window decoded in the background, 5 and 6: its two output buffers).
 struct StreamSpare {
-    PinBuf b[4];
+    PinBuf b[7];
     bool keep = true;   // LZFSE_MI_OPT_STREAM_SPARE
 };
 StreamSpare &ctx_spare(lzfse_mi_ctx *c);

@@ -11,6 +11,7 @@
 // (encode/frontend_ring.rs) is done by the device kernels (encode_parse.hip, st_ring_find and the round ends of the
 // stitcher), a window of input at a time; this file collects the pieces, cuts the windows and hands the stream out.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -34,15 +35,37 @@ struct lzfse_mi_dstream {
     uint8_t *far_dst = nullptr;    // ... unless a (damaged) header promises more than a GiB: malloc'd, never touched beyond what is written
     size_t far_cap = 0;
     uint8_t *out_p() const { return far_dst ? far_dst : dst.p; }
+    // A window that is full while more input is to come is decoded in the BACKGROUND (a helper thread, the stream objects' own
+    // context: StreamBox), from a copy of its blocks (`wsrc`: history block, blocks, bvx$) into the other of two output buffers,
+    // while the caller feeds the next window and takes the output of the one before: it is handed to `write` -- on the caller's
+    // thread, in stream order -- right after the next window has been sent off (dstream_advance).
+    PinBuf wsrc, adst[2];
+    int cur = 0;                   // adst[cur] takes the next window
+    std::shared_ptr<StreamBox> box;
+    LaneWorker *worker = nullptr;
+    bool pending = false;
+    int pend_st = 0, pend_buf = 0;
+    size_t pend_got = 0, pend_nh = 0, pend_len = 0;
+    uint64_t pend_cap = 0;
+    // (the helper copies the window's blocks out of `in` itself: until it has, `in` must neither move nor lose its front)
+    std::atomic<int> copied{1};
+    size_t pend_from = 0, pend_span = 0;
+    void wait_copied() { while (!copied.load(std::memory_order_acquire)) std::this_thread::yield(); }
+    void wait_idle() { if (worker && pending) worker->wait(); }
     ~lzfse_mi_dstream() {
         // (what this object's windows grew stays with the context for the next stream object -- if the context is still there
         // and keeps such buffers: ctx is null once lzfse_mi_destroy has run, LZFSE_MI_OPT_STREAM_SPARE)
+        wait_idle();
+        delete worker;
         std::free(far_dst);
         if (!ctx) return;
         ctx_detach(ctx, &ctx);
         StreamSpare &sp = ctx_spare(ctx);
         if (sp.keep && in.cap > sp.b[0].cap) { in.size = 0; sp.b[0].swap(in); }
         if (sp.keep && dst.cap > sp.b[1].cap) { dst.size = 0; sp.b[1].swap(dst); }
+        if (sp.keep && wsrc.cap > sp.b[4].cap) { wsrc.size = 0; sp.b[4].swap(wsrc); }
+        for (int k = 0; k < 2; k++)
+            if (sp.keep && adst[k].cap > sp.b[5 + k].cap) { adst[k].size = 0; sp.b[5 + k].swap(adst[k]); }
     }
     uint64_t total_in = 0, total_out = 0;
     int status = 0;                // sticky
@@ -180,6 +203,104 @@ int decode_span(lzfse_mi_dstream *s, size_t span, uint64_t raw, bool with_eos, l
     return 0;
 }
 
+// ---- windows in the background ----
+
+// the window in flight: its status; ptr / len: what it decoded (behind the history block), still to be handed to the sink
+int ds_complete(lzfse_mi_dstream *s, const uint8_t **ptr, size_t *len) {
+    *ptr = nullptr; *len = 0;
+    s->wait_idle();
+    s->pending = false;
+    if (s->pend_st) return s->pend_st;
+    if (s->pend_got < s->pend_nh) return LZFSE_MI_IO;
+    const uint8_t *base = s->adst[s->pend_buf].p;
+    const size_t got = s->pend_got;
+    *ptr = base + s->pend_nh; *len = got - s->pend_nh;
+    s->hist.assign(base + (got >= MAX_D_VALUE ? got - MAX_D_VALUE : 0), base + got);   // history for the next window
+    return 0;
+}
+
+int ds_sink(lzfse_mi_dstream *s, const uint8_t *ptr, size_t len, lzfse_mi_write_fn write, void *user) {
+    if (len && write && write(user, ptr, len)) return LZFSE_MI_IO;
+    s->total_out += len;
+    return 0;
+}
+
+// nothing in flight afterwards
+int ds_drain(lzfse_mi_dstream *s, lzfse_mi_write_fn write, void *user) {
+    if (!s->pending) return 0;
+    const uint8_t *p; size_t n;
+    if (const int st = ds_complete(s, &p, &n)) return st;
+    return ds_sink(s, p, n, write, user);
+}
+
+// in[in_pos .. in_pos + span) -- complete blocks holding `raw` bytes -- go to the device in the background (nothing is in
+// flight). -1: not this way (a window of more than a GiB, no helper to be had): the caller decodes it as before.
+int ds_launch(lzfse_mi_dstream *s, size_t span, uint64_t raw) {
+    const size_t nh = s->hist.size(), head = nh ? nh + 8 : 0, src_len = head + span + 4;
+    const uint64_t cap64 = nh + raw;
+    if (cap64 > ((uint64_t)1 << 30) || !s->box) return -1;
+    if (!s->worker) {
+        try { s->worker = new (std::nothrow) LaneWorker(); } catch (...) { s->worker = nullptr; }
+        if (!s->worker) return -1;
+    }
+    if (!s->wsrc.reserve(src_len + 64, false)) return LZFSE_MI_IO;
+    uint8_t *q = s->wsrc.p;
+    if (nh) {
+        const uint32_t m = MAGIC_RAW, n32 = (uint32_t)nh;
+        std::memcpy(q, &m, 4); std::memcpy(q + 4, &n32, 4);
+        std::memcpy(q + 8, s->hist.data(), nh);
+    }
+    { const uint32_t m = MAGIC_EOS; std::memcpy(q + head + span, &m, 4); }
+    s->pend_from = s->in_pos; s->pend_span = span;
+    s->copied.store(0, std::memory_order_relaxed);
+    PinBuf &d = s->adst[s->cur];
+    if (d.cap < cap64 + 64) {
+        // (with room to spare, as grow_dst)
+        const uint64_t want = cap64 + cap64 / 8 + ((uint64_t)1 << 20);
+        if (!d.reserve((size_t)want + 64, false) && !d.reserve((size_t)cap64 + 64, false)) return LZFSE_MI_IO;
+    }
+    s->pend_st = 0; s->pend_got = 0; s->pend_nh = nh; s->pend_buf = s->cur; s->pend_len = src_len; s->pend_cap = cap64;
+    s->pending = true;
+    s->worker->submit([s] {
+        std::memcpy(s->wsrc.p + (s->pend_nh ? s->pend_nh + 8 : 0), s->in.p + s->pend_from, s->pend_span);
+        s->copied.store(1, std::memory_order_release);
+        StreamBox *b = s->box.get();
+        std::lock_guard<std::mutex> g(b->m);
+        lzfse_mi_ctx *c = box_peer(*b);
+        if (!c) { s->pend_st = b->dead ? LZFSE_MI_BAD_ARGUMENT : LZFSE_MI_IO; return; }
+        PinBuf &dd = s->adst[s->pend_buf];
+        uint64_t cap = s->pend_cap;
+        size_t got = 0;
+        ctx_set_pinned_out(c, true);
+        int st = lzfse_mi_decode(c, s->wsrc.p, s->pend_len, dd.p, (size_t)cap, &got);
+        if (st == LZFSE_MI_BUFFER_OVERFLOW) {   // the sink is unbounded: find the error the reference's Vec would have met (decode_span)
+            cap += lzfse_mi_decode_headroom(s->wsrc.p, s->pend_len);
+            if (!dd.reserve((size_t)cap + 64, false)) st = LZFSE_MI_IO;
+            else st = lzfse_mi_decode(c, s->wsrc.p, s->pend_len, dd.p, (size_t)cap, &got);
+        }
+        ctx_set_pinned_out(c, false);
+        s->pend_st = st; s->pend_got = got;
+    });
+    s->cur ^= 1;
+    s->scan_span = 0; s->scan_raw = 0;
+    s->in_pos += span;
+    s->total_in += span;
+    return 0;
+}
+
+// A full window with more input to come: the one in flight is taken back, this one sent off, and what the former decoded handed
+// to the sink while the device works on this one.
+int ds_advance(lzfse_mi_dstream *s, size_t span, uint64_t raw, lzfse_mi_write_fn write, void *user) {
+    const uint8_t *p = nullptr; size_t n = 0;
+    if (s->pending)
+        if (const int st = ds_complete(s, &p, &n)) return st;
+    const int e = ds_launch(s, span, raw);
+    if (const int st = ds_sink(s, p, n, write, user)) return st;
+    if (e > 0) return e;
+    if (e < 0) return decode_span(s, span, raw, true, write, user);
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -211,12 +332,15 @@ LZFSE_MI_API int lzfse_mi_dstream_create(lzfse_mi_ctx *ctx, size_t window, lzfse
     if (!s) return LZFSE_MI_IO;
     s->ctx = ctx;
     ctx_attach(ctx, &s->ctx);
+    s->box = ctx_stream_box(ctx);
     s->window = window ? window : (size_t)LZFSE_MI_STREAM_WINDOW;
     {
         StreamSpare &sp = ctx_spare(ctx);
         s->in.swap(sp.b[0]);
         s->dst.swap(sp.b[1]);
-        s->in.size = 0; s->dst.size = 0;
+        s->wsrc.swap(sp.b[4]);
+        s->adst[0].swap(sp.b[5]); s->adst[1].swap(sp.b[6]);
+        s->in.size = 0; s->dst.size = 0; s->wsrc.size = 0; s->adst[0].size = 0; s->adst[1].size = 0;
     }
     *out = s;
     return LZFSE_MI_OK;
@@ -239,7 +363,8 @@ LZFSE_MI_API int lzfse_mi_dstream_feed(lzfse_mi_dstream *s, const uint8_t *src, 
         // (consumed input is dropped now and then; MAX_D_VALUE + 8 bytes of it stay in front of the rest: the next window's
         // history block is written there, decode_span)
         constexpr size_t KEEP = (size_t)MAX_D_VALUE + 8;
-        if (s->in_pos > KEEP && s->in_pos - KEEP >= s->in.size / 2) { s->in.erase_front(s->in_pos - KEEP); s->in_pos = KEEP; }
+        if (s->in_pos > KEEP && s->in_pos - KEEP >= s->in.size / 2) { s->wait_copied(); s->in.erase_front(s->in_pos - KEEP); s->in_pos = KEEP; }
+        if (s->in.size + n > s->in.cap) s->wait_copied();   // (the buffer is about to move)
         if (!s->in.append(src, n)) return s->status = LZFSE_MI_IO;
     }
     for (;;) {
@@ -261,13 +386,14 @@ LZFSE_MI_API int lzfse_mi_dstream_feed(lzfse_mi_dstream *s, const uint8_t *src, 
         }
         if (why == 0) {
             // bvx$ follows the run: decode the run, consume the magic; whether it ends the input shows at once or later
+            if (const int st = ds_drain(s, write, user)) return s->status = st;
             if (span) { const int st = decode_span(s, span, raw, true, write, user); if (st) return s->status = st; }
             s->in_pos += 4;
             s->total_in += 4;
             s->eos_seen = true;
             continue;
         }
-        if (why == 3) { const int st = decode_span(s, span, raw, true, write, user); if (st) return s->status = st; continue; }
+        if (why == 3) { const int st = ds_advance(s, span, raw, write, user); if (st) return s->status = st; continue; }
         if (why == 1 && !finish) {
             // wait for more input (a window is decoded when it is full, or when the input ends)
             s->scan_span = span; s->scan_raw = raw;
@@ -278,6 +404,7 @@ LZFSE_MI_API int lzfse_mi_dstream_feed(lzfse_mi_dstream *s, const uint8_t *src, 
         // The sound blocks in front of it go first, as a window of their own: what the sink holds and what the totals say
         // when the error comes must not depend on how the input was cut into feeds (the reference has written those
         // blocks by then: decoder.rs:76-99 decodes block by block).
+        if (const int st = ds_drain(s, write, user)) return s->status = st;
         if (span) { const int st = decode_span(s, span, raw, true, write, user); if (st) return s->status = st; }
         {
             const int st = decode_span(s, s->in.size - s->in_pos, 0, false, write, user);
