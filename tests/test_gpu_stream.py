@@ -345,3 +345,55 @@ def test_writer_pieces_are_views_released_after_the_call(ctx, oracle, snappy_raw
     out = io.BytesIO()
     m.LzfseRingDecoder(context=ctx, window=1 << 16).decode(PieceReader(enc, [9000]), out)
     assert out.getvalue() == raw
+
+
+def test_windows_in_the_background(oracle, snappy_raw):
+    """Round 4: a stream object hands a full window to a helper thread and returns (stream.hip). Two stream objects of one context
+    with windows in flight at the same time (a decoder whose sink is an encoder: transcoding, window sizes that do not line
+    up), objects dropped and contexts destroyed while a window is in flight, and an error that a background window met: it
+    arrives at a later call, after the windows before it have been written."""
+    import lzfse_rust_amd as m
+    from lzfse_rust_amd import _native
+    raw = (snappy_raw["lcet10.txt"] + snappy_raw["plrabn12.txt"] + snappy_raw["alice29.txt"]) * 9      # 9.5 MB
+    enc = oracle.encode(raw)
+    c = m.Context(0)
+    out = bytearray()
+    w = m.LzfseRingEncoder(context=c, window=3 << 20).writer_bytes(out)
+    u, v = m.LzfseRingDecoder(context=c, window=1 << 20).decode(PieceReader(enc, [300000, 17, 1 << 20]), w)
+    w.finalize()
+    assert (u, v) == (len(enc), len(raw)) and bytes(out) == oracle.ring_encode(raw)
+    # dropped with a window in flight (no finalize): the object waits for its helper and goes
+    w2 = m.LzfseRingEncoder(context=c, window=1 << 20).writer_bytes(bytearray())
+    w2.write(raw[:4 << 20])
+    del w2
+    # the context destroyed with windows in flight: they finish (or are refused), later calls say BAD_ARGUMENT
+    lib = c._lib
+    d, e = C.c_void_p(), C.c_void_p()
+    assert lib.lzfse_mi_dstream_create(c._h, 1 << 20, C.byref(d)) == 0
+    assert lib.lzfse_mi_estream_create(c._h, 1 << 20, C.byref(e)) == 0
+    cb = _native.WRITE_FN(lambda _u, p, n: 0)
+    a = np.frombuffer(enc, dtype=np.uint8)
+    r = np.frombuffer(raw, dtype=np.uint8)
+    assert lib.lzfse_mi_dstream_feed(d, a.ctypes.data, a.size * 2 // 3, 0, cb, None) == 0
+    assert lib.lzfse_mi_estream_feed(e, r.ctypes.data, 5 << 20, cb, None) == 0
+    c.close()
+    assert lib.lzfse_mi_dstream_feed(d, a.ctypes.data, 16, 1, cb, None) == 11
+    assert lib.lzfse_mi_estream_feed(e, r.ctypes.data, 16, cb, None) == 11
+    lib.lzfse_mi_dstream_destroy(d)
+    lib.lzfse_mi_estream_destroy(e)
+    # a damaged block far into the stream: the windows before it reach the sink, then the slice path's status
+    c = m.Context(0)
+    got = bytearray()
+
+    class Keep:
+        def write(self, b):
+            got.extend(bytes(b))
+
+    cut = bytearray(enc)
+    at = len(enc) * 2 // 3
+    cut[at:at + 4] = b"bvxQ"        # (four bytes of some block's payload)
+    with pytest.raises(m.LzfseError) as ei:
+        m.LzfseRingDecoder(context=c, window=1 << 20).decode(PieceReader(bytes(cut), [1 << 20]), Keep())
+    assert ei.value.status == oracle.decode_status(bytes(cut), len(raw) + 64)
+    assert len(got) >= 4 << 20 and raw.startswith(bytes(got))
+    c.close()
