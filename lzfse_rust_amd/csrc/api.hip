@@ -617,6 +617,7 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
         // streams per CU in flight (Snappy files x R, dec_lz ms: 1 080 streams 1.45 / 2.20, 1 536: 1.94 / 2.23, 2 040: 2.62 / 2.26)
         int variant = (uint64_t)ns * (uint64_t)std::max(1, c->lane_share) >= 1792 ? 0 : 1;
         if (c->diag_lz_variant >= 0) variant = c->diag_lz_variant;
+        if (!jump_fused)   // (all on the pointer-jumping path: nothing for the tile kernel)
         launch_dec_lz(variant, (const uint8_t *)d_src, (const StreamIn *)c->d_streams.p,
                       (const StreamPlan *)c->d_plan.p, ns, (const BlockDesc *)c->d_blocks.p,
                       (const BlockResult *)c->d_bres.p, (const LmdRec *)c->d_lmds.p, (const uint8_t *)c->d_lits.p,

@@ -508,6 +508,9 @@ struct FseLds {
     uint2 v_tab[L_STATES + M_STATES + D_STATES];
     int status[2];
     uint32_t sums[3];
+    // dec_fse_kernel<true>: LMD records stored and visible / the LMD wave is through / records whose origins the literal wave
+    // has written / it met a bad D (jump_consume_wave)
+    uint32_t jready, jfin, jdone, jbad, jrun_out, jrun_lit;   // (... and the bytes / literals those records cover)
 };
 
 // Weights and decode tables of one bvx1 / bvx2 block into `lds` (weights.rs:66-105,189-200, decoder.rs:244-335), by the whole
@@ -665,7 +668,10 @@ template <int NT>
 __device__ __forceinline__ void jump_init_block(const uint32_t b, const BlockDesc &d, const StreamPlan &pl, const BlockResult &br,
                                                 const uint8_t *__restrict__ src, const StreamIn *__restrict__ streams,
                                                 const LmdRec *__restrict__ lmds, const uint8_t *__restrict__ lits, uint8_t *dst_all,
-                                                uint32_t *__restrict__ origin, uint32_t *__restrict__ jerr, uint32_t *sh);
+                                                uint32_t *__restrict__ origin, uint32_t *__restrict__ jerr, uint32_t *sh,
+                                                uint32_t lmds_done, uint32_t done_out, uint32_t done_lit, bool pre_bad);
+__device__ void jump_consume_wave(volatile uint32_t *jready, volatile uint32_t *jfin, uint32_t *jdone, const LmdRec *bl, const uint8_t *blit,
+                                  uint32_t n_raw, uint32_t n_lit, uint32_t o0, uint8_t *dst, uint32_t *org, uint32_t jb);
 
 // JUMP: every stream of the call takes the pointer-jumping LZ path, and a block's workgroup goes on with that path's first step
 // for its block (jump_init_block below) as soon as its entropy stage is done -- blocks of other kinds (raw) included
@@ -708,6 +714,7 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
     const bool lit_short = avail < (uint64_t)h.hdr_size + h.lit_payload;
     const bool lmd_short = avail < (uint64_t)h.hdr_size + h.lit_payload + h.lmd_payload;
     if (tid < 2) sh_status[tid] = 0;
+    if (JUMP && tid == 2) { lds.jready = 0; lds.jfin = 0; lds.jdone = 0; lds.jbad = 0; lds.jrun_out = 0; lds.jrun_lit = 0; }
 
     // ---- weights and decode tables ----
     {
@@ -799,6 +806,16 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
         uint32_t s0 = read_lane(state, 0) | read_lane(state, 1) | read_lane(state, 2) | read_lane(state, 3);
         if (!e && s0 != 0) e = LZFSE_MI_FSE_BAD_LMD_PAYLOAD;  // literals.rs:78-88
         if (lane == 0) sh_status[1] = e;
+        if (JUMP) {
+            // The literal stream of a block is shorter than its LMD stream more often than not (text: 5 800 against 10 000 steps):
+            // this wave spends what is left of the block's time on the origins of the LMD records the other wave has stored so
+            // far, and follows it to the end -- the pointer-jumping path's first step then has only the literal BYTES left to do.
+            const StreamPlan pl = plan[d.stream];
+            // (only behind a literal stream that decoded cleanly: the bytes are copied from it)
+            if (!pl.skip && pl.jump && !e)
+                jump_consume_wave(&lds.jready, &lds.jfin, &lds.jdone, lmd_out + d.lmd_base, lit_out + d.lit_base, d.n_raw, h.lit_num,
+                                  (uint32_t)d.dst_rel, dst_all + streams[d.stream].dst_off, origin + pl.jbase, (uint32_t)pl.jbase);
+        }
     } else {
         // fse_core.rs:91-141 (entropy part): L, M, D in lanes 0, 1, 2
         BitWindow w;
@@ -823,6 +840,11 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
             const uint64_t upto = nz & (lane == 63 ? ~0ull : ((2ull << lane) - 1));
             const uint32_t from = __shfl(vd, upto ? 63 - __builtin_clzll(upto) : lane);
             const uint32_t dv = upto ? from : carry_d;
+            if (JUMP) {
+                // (the records of the batches BEFORE this one were stored 64 steps ago: the fence finds them done; the other wave may take them)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) *(volatile uint32_t *)&lds.jready = base;
+            }
             if (have) out[base + lane] = make_uint2(vl | (vm << 16), dv);
             const uint32_t il = wave_incl_scan(vl);
             const uint64_t ov = __ballot(have && cum_l + il > LITERALS_PER_BLOCK);
@@ -904,6 +926,11 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
             }
         }
         if (lane == 0) { sh_status[0] = e; sh_sums[0] = sum_l; sh_sums[1] = sum_m; sh_sums[2] = ok_until; }
+        if (JUMP) {
+            // (every path of this wave ends here: the other wave waits for jfin)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) { *(volatile uint32_t *)&lds.jready = n; *(volatile uint32_t *)&lds.jfin = 1u; }
+        }
     }
     __syncthreads();
     BlockResult r;
@@ -917,7 +944,9 @@ __global__ __launch_bounds__(FSE_THREADS) void dec_fse_kernel(
     if (JUMP) {
         // (the block's literal and LMD arrays were stored by this workgroup's two waves: drained and visible to both)
         __syncthreads();
-        jump_init_block<FSE_THREADS>(b, d, plan[d.stream], br, src, streams, lmd_out, lit_out, dst_all, origin, jerr, pool);
+        const bool took = is_fse && !br.status;
+        jump_init_block<FSE_THREADS>(b, d, plan[d.stream], br, src, streams, lmd_out, lit_out, dst_all, origin, jerr, pool,
+                                     took ? lds.jdone : 0u, took ? lds.jrun_out : 0u, took ? lds.jrun_lit : 0u, took && lds.jbad != 0);
     }
 }
 
@@ -2021,23 +2050,106 @@ constexpr int JUMP_THREADS = 256;
 // never visited again, so a round costs gathers only for the bytes that are still on a chain
 constexpr uint32_t JUMP_FINAL = 0x80000000u;
 
+// The origin entries of one LMD per lane, by a whole wave (`on`: this lane has one whose origins are wanted): o = stream-relative
+// position of its first byte, literals first. A literal names itself and is final; a match byte names the byte dd back -- or, for a
+// match that overlaps itself (dd < m), byte k mod dd of the dd bytes IN FRONT of the match (lz/object.rs:60-74): every byte of it
+// points there directly, so that a run of zeros is one hop per match, not one per byte; the bytes of a match with a bad D name
+// nothing. Long runs: the whole wave works on one lane's run at a time.
+__device__ __forceinline__ void jump_origins_wave(uint32_t *org, uint32_t jb, bool on, uint32_t o, uint32_t l, uint32_t m, uint32_t dd, bool bad_d) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t p = o + l;
+    const bool l_long = on && l > 32, m_long = on && m > 32 && !bad_d;
+    if (on && !l_long) for (uint32_t k = 0; k < l; k++) org[o + k] = (jb + o + k) | JUMP_FINAL;
+    if (on && !m_long && !bad_d) {
+        uint32_t rr = 0;
+        for (uint32_t k = 0; k < m; k++) { org[p + k] = jb + p - dd + rr; if (++rr == dd) rr = 0; }
+    }
+    if (on && bad_d) for (uint32_t k = 0; k < m; k++) org[p + k] = 0xFFFFFFFFu;
+    uint64_t ql = __ballot(l_long);
+    while (ql) {
+        const int L = __builtin_ctzll(ql); ql &= ql - 1;
+        const uint32_t qo = read_lane(o, L), qn = read_lane(l, L);
+        for (uint32_t k = lane; k < qn; k += 64) org[qo + k] = (jb + qo + k) | JUMP_FINAL;
+    }
+    uint64_t qm = __ballot(m_long);
+    while (qm) {
+        const int L = __builtin_ctzll(qm); qm &= qm - 1;
+        const uint32_t qp = read_lane(p, L), qn = read_lane(m, L), qd = read_lane(dd, L);
+        if (qd >= qn) for (uint32_t k = lane; k < qn; k += 64) org[qp + k] = jb + qp + k - qd;
+        else {   // (overlaps itself: k mod qd, stepped by 64 mod qd per turn)
+            const uint32_t step = 64u % qd;
+            uint32_t rr = (uint32_t)lane % qd;
+            for (uint32_t k = lane; k < qn; k += 64) { org[qp + k] = jb + qp - qd + rr; rr += step; if (rr >= qd) rr -= qd; }
+        }
+    }
+}
+
+// dec_fse_kernel<true>, the literal wave once its own stream is decoded (cleanly): the pointer-jumping path's first step for the
+// block's LMD records, 64 at a time, as the LMD wave stores them (jready: records stored and visible; jfin: that wave is through)
+// -- literal bytes to their places, origins of everything. jdone[0..4) = records taken, a bad D met, bytes and literals they cover:
+// the workgroup's first step goes on from there. It stops at a record that would leave the block's bytes or its literals -- such
+// a block fails as a whole and its range is filled by the first step.
+__device__ void jump_consume_wave(volatile uint32_t *jready, volatile uint32_t *jfin, uint32_t *jdone, const LmdRec *bl, const uint8_t *blit,
+                                  uint32_t n_raw, uint32_t n_lit, uint32_t o0, uint8_t *dst, uint32_t *org, uint32_t jb) {
+    const int lane = threadIdx.x & 63;
+    uint32_t done = 0, run_out = 0, run_lit = 0;
+    bool bad = false;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (this wave's own literal bytes: stored before they are read back)
+    for (;;) {
+        const uint32_t fin = *jfin;       // (before jready: once it is set, jready is final)
+        const uint32_t ready = *jready;
+        const uint32_t avail = ready - done;
+        if (avail >= 64 || (fin && avail)) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const uint32_t cnt = avail < 64 ? avail : 64u;
+            const bool valid = (uint32_t)lane < cnt;
+            const LmdRec r = valid ? bl[done + lane] : make_uint2(0, 0);
+            const uint32_t l = r.x & 0xFFFF, m = r.x >> 16, dd = r.y;
+            const uint32_t incl = wave_incl_scan(l + m), tot = read_lane(incl, 63);
+            const uint32_t il = wave_incl_scan(l), tot_l = read_lane(il, 63);
+            if (tot > n_raw - run_out || tot_l > n_lit - run_lit) break;
+            const uint32_t o = o0 + run_out + incl - (l + m);
+            const bool bad_d = valid && m != 0 && (dd == 0 || dd > o + l);  // lz/writer.rs:156-178
+            bad |= bad_d;
+            // the literal bytes
+            const uint8_t *ls = blit + run_lit + il - l;
+            const bool l_long = l > 32;
+            if (!l_long) for (uint32_t k = 0; k < l; k++) dst[o + k] = ls[k];
+            uint64_t ql = __ballot(l_long);
+            while (ql) {
+                const int L = __builtin_ctzll(ql); ql &= ql - 1;
+                const uint32_t qo = read_lane(o, L), qn = read_lane(l, L);
+                const uint64_t qs = ((uint64_t)read_lane((uint32_t)((uintptr_t)ls >> 32), L) << 32) | read_lane((uint32_t)(uintptr_t)ls, L);
+                const uint8_t *q_ls = (const uint8_t *)(uintptr_t)qs;
+                for (uint32_t k = lane; k < qn; k += 64) dst[qo + k] = q_ls[k];
+            }
+            jump_origins_wave(org, jb, valid, o, l, m, dd, bad_d);
+            run_out += tot; run_lit += tot_l; done += cnt;
+        } else if (fin) break;
+        else __builtin_amdgcn_s_sleep(8);
+    }
+    const bool any_bad = __any(bad);
+    if (lane == 0) { jdone[0] = done; jdone[1] = any_bad ? 1u : 0u; jdone[2] = run_out; jdone[3] = run_lit; }
+}
+
 // One block's part of the pointer-jumping path's first step: literals (and raw blocks) are written, origins initialised.
 // By a whole workgroup of NT threads (uniform arguments): dec_jump_init_kernel's, or -- when every stream of the call takes
-// this path -- the block's own dec_fse workgroup right after its entropy stage (dec_fse_kernel<true>: the FSE stage of a lone
-// stream is one block's chain long whatever else runs beside it, so this work costs nothing there; text64m decode 22.4 -> see DESIGN.md).
+// this path -- the block's own dec_fse workgroup right after its entropy stage (dec_fse_kernel<true>), whose literal wave has
+// then done the first lmds_done LMDs already (jump_consume_wave: done_out bytes with done_lit literals; pre_bad: it met a bad D).
 // br: the block's entropy result (not read for raw blocks); sh: 2 * NT / 64 + 4 words of LDS.
 template <int NT>
 __device__ __forceinline__ void jump_init_block(const uint32_t b, const BlockDesc &d, const StreamPlan &pl, const BlockResult &br,
                                                 const uint8_t *__restrict__ src, const StreamIn *__restrict__ streams,
                                                 const LmdRec *__restrict__ lmds, const uint8_t *__restrict__ lits, uint8_t *dst_all,
-                                                uint32_t *__restrict__ origin, uint32_t *__restrict__ jerr, uint32_t *sh) {
+                                                uint32_t *__restrict__ origin, uint32_t *__restrict__ jerr, uint32_t *sh,
+                                                uint32_t lmds_done, uint32_t done_out, uint32_t done_lit, bool pre_bad) {
     if (pl.skip || !pl.jump) return;
     const StreamIn in = streams[d.stream];
     uint8_t *dst = dst_all + in.dst_off;
     uint32_t *org = origin + pl.jbase;
     const uint32_t jb = (uint32_t)pl.jbase;
     const uint32_t bi = b - (uint32_t)pl.blk_base;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t o0 = (uint32_t)d.dst_rel;
     // Every origin entry is defined before the rounds read it (all bits set = final, names nothing), and by the workgroup of the
     // block it lies in -- round 4; a fill of the whole array before: 0.09 ms for a 64 MiB stream: the up to three padding entries
@@ -2060,9 +2172,9 @@ __device__ __forceinline__ void jump_init_block(const uint32_t b, const BlockDes
         return;
     }
     const uint8_t *blit = lits + d.lit_base;
-    uint32_t run_lit = 0, run_out = 0;
-    bool bad = false;
-    for (uint32_t g0 = 0; g0 < d.n_lmd; g0 += NT) {
+    uint32_t run_lit = done_lit, run_out = done_out;
+    bool bad = pre_bad;
+    for (uint32_t g0 = lmds_done; g0 < d.n_lmd; g0 += NT) {
         const uint32_t idx = g0 + tid;
         const bool valid = idx < d.n_lmd;
         const LmdRec r = valid ? bl[idx] : make_uint2(0, 0);
@@ -2073,41 +2185,23 @@ __device__ __forceinline__ void jump_init_block(const uint32_t b, const BlockDes
         const uint32_t p = o + l;                     // ... of its match
         const bool bad_d = valid && m != 0 && (dd == 0 || dd > p);  // lz/writer.rs:156-178
         bad |= bad_d;
+        // the literal bytes
         const uint8_t *ls = blit + run_lit + ex_l;
-        const bool l_long = l > 32, m_long = m > 32 && !bad_d;
-        if (!l_long) for (uint32_t k = 0; k < l; k++) { dst[o + k] = ls[k]; org[o + k] = (jb + o + k) | JUMP_FINAL; }
-        // A match that overlaps itself (dd < m) repeats its first dd bytes: byte k is byte k mod dd of the dd bytes IN FRONT of the
-        // match (lz/object.rs:60-74), so every byte of it points there directly instead of dd bytes back -- a run of zeros is
-        // then one hop per match, not one per byte
-        if (!m_long && !bad_d) {
-            uint32_t rr = 0;
-            for (uint32_t k = 0; k < m; k++) { org[p + k] = jb + p - dd + rr; if (++rr == dd) rr = 0; }
-        }
-        if (bad_d) for (uint32_t k = 0; k < m; k++) org[p + k] = 0xFFFFFFFFu;
-        // long runs: the whole wave works on one lane's run at a time
+        const bool l_long = l > 32;
+        if (!l_long) for (uint32_t k = 0; k < l; k++) dst[o + k] = ls[k];
         uint64_t ql = __ballot(l_long);
         while (ql) {
             const int L = __builtin_ctzll(ql); ql &= ql - 1;
             const uint32_t qo = read_lane(o, L), qn = read_lane(l, L);
             const uint64_t qs = ((uint64_t)read_lane((uint32_t)((uintptr_t)ls >> 32), L) << 32) | read_lane((uint32_t)(uintptr_t)ls, L);
             const uint8_t *q_ls = (const uint8_t *)(uintptr_t)qs;
-            for (uint32_t k = lane; k < qn; k += 64) { dst[qo + k] = q_ls[k]; org[qo + k] = (jb + qo + k) | JUMP_FINAL; }
+            for (uint32_t k = lane; k < qn; k += 64) dst[qo + k] = q_ls[k];
         }
-        uint64_t qm = __ballot(m_long);
-        while (qm) {
-            const int L = __builtin_ctzll(qm); qm &= qm - 1;
-            const uint32_t qp = read_lane(p, L), qn = read_lane(m, L), qd = read_lane(dd, L);
-            if (qd >= qn) for (uint32_t k = lane; k < qn; k += 64) org[qp + k] = jb + qp + k - qd;
-            else {   // (overlaps itself: k mod qd, stepped by 64 mod qd per turn)
-                const uint32_t step = 64u % qd;
-                uint32_t rr = (uint32_t)lane % qd;
-                for (uint32_t k = lane; k < qn; k += 64) { org[qp + k] = jb + qp - qd + rr; rr += step; if (rr >= qd) rr -= qd; }
-            }
-        }
+        // the origins
+        jump_origins_wave(org, jb, valid, o, l, m, dd, bad_d);
         run_lit += tot_l; run_out += tot_s;
     }
     if (__any(bad) && lane == 0) atomicMin(&jerr[d.stream], (bi << 8) | (uint32_t)LZFSE_MI_BAD_D_VALUE);
-    (void)wave;
 }
 
 // one workgroup per block
@@ -2120,7 +2214,7 @@ __global__ __launch_bounds__(JUMP_THREADS) void dec_jump_init_kernel(
     const uint32_t b = blockIdx.x;
     if (b >= n_blocks) return;
     const BlockDesc d = blocks[b];
-    jump_init_block<JUMP_THREADS>(b, d, plan[d.stream], bres[b], src, streams, lmds, lits, dst_all, origin, jerr, sh);
+    jump_init_block<JUMP_THREADS>(b, d, plan[d.stream], bres[b], src, streams, lmds, lits, dst_all, origin, jerr, sh, 0u, 0u, 0u, false);
 }
 
 // Chains collapsed chunk by chunk in LDS before the global rounds: a workgroup takes 16 Ki consecutive origins (64 KB of
