@@ -94,9 +94,11 @@ enum {
                                        1 never, else K | variant << 8: K workgroups (2..64) for every stream of the tile
                                        kernel, variant 0 = 256 threads / 8 KiB tiles, 1 = 1024 threads / 32 KiB tiles */
     LZFSE_MI_OPT_STREAM_SPARE = 5,  /* 1 (default): the window buffers of a destroyed stream object (lzfse_mi_dstream / _estream)
-                                       stay with the context for the next one -- pinned host memory, up to about window x (1 + 1.125)
-                                       for a decoder and window x (1 + 1.75) for an encoder, ~300 MiB at the default window,
-                                       until lzfse_mi_destroy; 0: free what is held now and keep nothing from now on */
+                                       stay with the context for the next one -- pinned host memory, about 4.5 windows for a decoder
+                                       (its input, the copy of the window in flight, two windows of output and one for a window
+                                       decoded in the call) and 4.75 for an encoder (three of input, 1.75 of output): ~300 MiB each
+                                       at the default window, until lzfse_mi_destroy; 0: free what is held now and keep nothing
+                                       from now on */
     LZFSE_MI_OPT_DIAG_LZ_PATH = 100, /* -1: by cost, 0: tile kernel only, 1: pointer jumping for every stream */
     LZFSE_MI_OPT_DIAG_LZ_TILE = 101, /* -1: by stream count, 0: 256-thread / 8 KiB tile, 1: 1024-thread / 32 KiB tile */
     LZFSE_MI_OPT_DIAG_STATS = 102,   /* bit mask: per-stage statistics on stderr */
