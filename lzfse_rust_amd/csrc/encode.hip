@@ -273,15 +273,26 @@ __global__ __launch_bounds__(BLK_THREADS) __attribute__((amdgpu_waves_per_eu(BLK
     __syncthreads();
 
     // ---- literal gather + LMD symbol histograms ----
+    // Two passes in flight (round 4): a pass's source addresses come out of a block scan, and its loads used to be waited for
+    // before the next pass's scan began -- one memory round trip per 256 LMDs with nothing under it. Now pass g + 1 is scanned and
+    // its loads are issued (prep) before pass g's bytes are stored (fin).
     {
         uint32_t run_lit = 0, run_src = blk.src_start;
         uint2 r_next = (uint32_t)tid < blk.n_lmd ? bl[tid] : make_uint2(0, 0);  // records are fetched one pass ahead
-        for (uint32_t g0 = 0; g0 < blk.n_lmd; g0 += BLK_THREADS) {
-            uint32_t idx = g0 + tid;
-            bool valid = idx < blk.n_lmd;
+        struct Pass {
+            uint64_t w0, w1, w2;
+            const uint8_t *ls;
+            uint8_t *ld;
+            uint32_t l;
+            bool valid, wide, l_long;
+        };
+        auto prep = [&](uint32_t g0) -> Pass {
+            Pass P;
+            const uint32_t idx = g0 + tid;
+            P.valid = idx < blk.n_lmd;
             const uint2 r = r_next;
             r_next = idx + BLK_THREADS < blk.n_lmd ? bl[idx + BLK_THREADS] : make_uint2(0, 0);
-            uint32_t l = r.x & 0xFFFF, m = r.x >> 16, d = r.y;
+            const uint32_t l = r.x & 0xFFFF, m = r.x >> 16, d = r.y;
             // block exclusive scan of l and l + m
             uint32_t il = wave_incl_sum(l), is = wave_incl_sum(l + m);
             if (lane == 63) { scan_sh[wave] = il; scan_sh[BLK_THREADS / 64 + wave] = is; }
@@ -292,47 +303,68 @@ __global__ __launch_bounds__(BLK_THREADS) __attribute__((amdgpu_waves_per_eu(BLK
                 if (wv < wave) { ol += a; os += b2; }
                 tl += a; ts += b2;
             }
-            uint32_t ex_l = ol + il - l, ex_s = os + is - (l + m);
-            const uint8_t *ls = s + run_src + ex_s;
-            uint8_t *ld = lit + run_lit + ex_l;
-            const bool l_long = valid && l > 24;
-            if (valid) {
-                if (!l_long && l) {
-                    // three 8-byte loads in flight, then byte stores (the run is followed by >= 4 match or
-                    // literal bytes of the same stream, except at its very end)
-                    const bool wide = run_src + ex_s + 24 <= st.n;
-                    if (wide) {
-                        // exactly l bytes in at most five LDS stores of 8 / 8 / 4 / 2 / 1 bytes at byte alignment (gfx950 runs
-                        // LDS in unaligned access mode; a byte loop costs the wave its longest run in iterations)
-                        const uint64_t w0 = ld_u64(ls), w1 = l > 8 ? ld_u64(ls + 8) : 0, w2 = l > 16 ? ld_u64(ls + 16) : 0;
-                        uint64_t cur = w0;
-                        uint8_t *q = ld;
-                        if (l >= 8) { __builtin_memcpy(q, &w0, 8); q += 8; cur = w1; }
-                        if (l >= 16) { __builtin_memcpy(q, &w1, 8); q += 8; cur = w2; }
-                        if (l == 24) { __builtin_memcpy(q, &w2, 8); }
-                        else {
-                            if (l & 4) { const uint32_t c4 = (uint32_t)cur; __builtin_memcpy(q, &c4, 4); q += 4; cur >>= 32; }
-                            if (l & 2) { const uint16_t c2 = (uint16_t)cur; __builtin_memcpy(q, &c2, 2); q += 2; cur >>= 16; }
-                            if (l & 1) *q = (uint8_t)cur;
-                        }
-                    } else {
-                        for (uint32_t k = 0; k < l; k++) ld[k] = ls[k];
-                    }
-                }
+            const uint32_t ex_l = ol + il - l, ex_s = os + is - (l + m);
+            P.ls = s + run_src + ex_s;
+            P.ld = lit + run_lit + ex_l;
+            P.l = l;
+            P.l_long = P.valid && l > 24;
+            // three 8-byte loads in flight (the run is followed by >= 4 match or literal bytes of the same stream, except at
+            // its very end)
+            P.wide = P.valid && !P.l_long && l != 0 && run_src + ex_s + 24 <= st.n;
+            P.w0 = 0; P.w1 = 0; P.w2 = 0;
+            if (P.wide) { P.w0 = ld_u64(P.ls); P.w1 = l > 8 ? ld_u64(P.ls + 8) : 0; P.w2 = l > 16 ? ld_u64(P.ls + 16) : 0; }
+            if (P.valid) {
                 atomicAdd(&hist[l_sym_of(l)], 1u);
                 atomicAdd(&hist[20 + m_sym_of(m)], 1u);
                 atomicAdd(&hist[40 + d_sym_of(d)], 1u);
             }
+            run_lit += tl; run_src += ts;
+            lds_barrier();
+            return P;
+        };
+        auto fin = [&](const Pass &P) {
+            const uint32_t l = P.l;
+            if (P.valid && !P.l_long && l) {
+                if (P.wide) {
+                    // exactly l bytes in at most five stores of 8 / 8 / 4 / 2 / 1 bytes at byte alignment (a byte loop costs the
+                    // wave its longest run in iterations)
+                    const uint64_t w0 = P.w0, w1 = P.w1, w2 = P.w2;
+                    uint64_t cur = w0;
+                    uint8_t *q = P.ld;
+                    if (l >= 8) { __builtin_memcpy(q, &w0, 8); q += 8; cur = w1; }
+                    if (l >= 16) { __builtin_memcpy(q, &w1, 8); q += 8; cur = w2; }
+                    if (l == 24) { __builtin_memcpy(q, &w2, 8); }
+                    else {
+                        if (l & 4) { const uint32_t c4 = (uint32_t)cur; __builtin_memcpy(q, &c4, 4); q += 4; cur >>= 32; }
+                        if (l & 2) { const uint16_t c2 = (uint16_t)cur; __builtin_memcpy(q, &c2, 2); q += 2; cur >>= 16; }
+                        if (l & 1) *q = (uint8_t)cur;
+                    }
+                } else {
+                    for (uint32_t k = 0; k < l; k++) P.ld[k] = P.ls[k];
+                }
+            }
             // long runs: the whole wave copies one lane's run at a time
-            uint64_t ql = __ballot(l_long);
+            uint64_t ql = __ballot(P.l_long);
             while (ql) {
                 const int L = __builtin_ctzll(ql);
                 ql &= ql - 1;
-                const uint32_t q_src = e_readlane(run_src + ex_s, L), q_dst = e_readlane(run_lit + ex_l, L), q_n = e_readlane(l, L);
-                for (uint32_t k = lane; k < q_n; k += 64) lit[q_dst + k] = s[q_src + k];
+                const uint64_t qs = ((uint64_t)e_readlane((uint32_t)((uintptr_t)P.ls >> 32), L) << 32) | e_readlane((uint32_t)(uintptr_t)P.ls, L);
+                const uint64_t qd = ((uint64_t)e_readlane((uint32_t)((uintptr_t)P.ld >> 32), L) << 32) | e_readlane((uint32_t)(uintptr_t)P.ld, L);
+                const uint32_t q_n = e_readlane(l, L);
+                const uint8_t *q_src = (const uint8_t *)(uintptr_t)qs;
+                uint8_t *q_dst = (uint8_t *)(uintptr_t)qd;
+                for (uint32_t k = lane; k < q_n; k += 64) q_dst[k] = q_src[k];
             }
-            run_lit += tl; run_src += ts;
-            lds_barrier();
+        };
+        if (blk.n_lmd) {
+            Pass P0 = prep(0);
+            for (uint32_t g0 = 0; g0 < blk.n_lmd; g0 += BLK_THREADS) {
+                const bool more = g0 + BLK_THREADS < blk.n_lmd;
+                Pass P1 = P0;
+                if (more) P1 = prep(g0 + BLK_THREADS);
+                fin(P0);
+                P0 = P1;
+            }
         }
     }
     __syncthreads();   // (the literal bytes are global stores: drained and visible to the workgroup)
