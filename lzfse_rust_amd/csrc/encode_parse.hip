@@ -61,27 +61,20 @@ __device__ __forceinline__ uint32_t next_has_wave(const uint64_t *bm, uint32_t i
 }
 
 // Match::select::<40> (match_object.rs:12-33) on an incoming match; returns true on emit
+// (without branches: the segment walkers run it for 64 lanes in lockstep, where every branch is a pair of exec-mask instructions
+// whichever lanes take it, and a lone walker wave pays ~5 cycles for any instruction)
 __device__ __forceinline__ bool select40(WState &st, uint32_t i_idx, uint32_t i_midx, uint32_t i_len,
                                          uint32_t &e_idx, uint32_t &e_midx, uint32_t &e_len) {
-    if (i_len >= GOOD_MATCH_LEN) {
-        e_idx = i_idx; e_midx = i_midx; e_len = i_len; st.p_len = 0;
-        return true;
-    }
-    if (st.p_len == 0) {
-        st.p_idx = i_idx; st.p_midx = i_midx; st.p_len = i_len;
-        return false;
-    }
-    if (st.p_idx + st.p_len <= i_idx) {
-        e_idx = st.p_idx; e_midx = st.p_midx; e_len = st.p_len;
-        st.p_idx = i_idx; st.p_midx = i_midx; st.p_len = i_len;
-        return true;
-    }
-    if (i_len > st.p_len) {
-        e_idx = i_idx; e_midx = i_midx; e_len = i_len; st.p_len = 0;
-        return true;
-    }
-    e_idx = st.p_idx; e_midx = st.p_midx; e_len = st.p_len; st.p_len = 0;
-    return true;
+    const bool good = i_len >= GOOD_MATCH_LEN;                 // the incoming match is emitted as it is
+    const bool none = st.p_len == 0;                           // nothing pending: the incoming one waits
+    const bool apart = st.p_idx + st.p_len <= i_idx;           // the pending one ends before the incoming one: emit it, keep the new one
+    const bool longer = i_len > st.p_len;                      // they overlap: the longer one is emitted, the other dropped
+    const bool emit = good || !none;
+    const bool emit_in = good || (!none && !apart && longer);
+    const bool keep_in = !good && (none || apart);
+    e_idx = emit_in ? i_idx : st.p_idx; e_midx = emit_in ? i_midx : st.p_midx; e_len = emit_in ? i_len : st.p_len;
+    st.p_idx = keep_in ? i_idx : st.p_idx; st.p_midx = keep_in ? i_midx : st.p_midx; st.p_len = keep_in ? i_len : 0u;
+    return emit;
 }
 
 // ------------------------------------------------------------------------------------ speculative walk
