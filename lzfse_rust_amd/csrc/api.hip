@@ -108,6 +108,15 @@ struct lzfse_mi_ctx {
     std::mutex stream_refs_m;
     lzmi::EncWindow *window = nullptr;   // set for the duration of one window of a stream encode (stream.hip)
     bool pinned_out = false;             // ... of one window of either stream object: the destination is pinned memory
+    // ... of the stream decoder, in the background: the window's output is left to travel on a stream of its own while the call
+    // returns (all but its last 262 139 bytes, which the next window needs at once): two device output buffers in turn, an event each
+    bool defer_out = false;
+    DevBuf d_out2;
+    int out_flip = 0;
+    hipStream_t xfer_stream = nullptr;
+    hipEvent_t defer_ev[2] = {nullptr, nullptr};
+    bool defer_pending[2] = {false, false};
+    hipEvent_t defer_last = nullptr;     // the event of the last call's deferred transfer (null: there was none)
     std::shared_ptr<lzmi::StreamBox> stream_box;   // where stream objects run windows in the background (internal.h)
     bool parse_ring = false;   // set for the duration of a ring / stream encode call (lzfse_mi_encode_ring*, lzfse_mi_estream_*)
     int diag_lz_jump = -1, diag_lz_variant = -1, diag_stats = 0, diag_chain = 0, diag_walk = 0, diag_pipe_scatter = 0;  // diagnostic build only
@@ -155,6 +164,8 @@ void ctx_detach(lzfse_mi_ctx *c, lzfse_mi_ctx **ref) {
 }
 void ctx_set_window(lzfse_mi_ctx *c, EncWindow *w) { c->window = w; }
 void ctx_set_pinned_out(lzfse_mi_ctx *c, bool on) { c->pinned_out = on; }
+void ctx_set_defer_out(lzfse_mi_ctx *c, bool on) { c->defer_out = on; c->defer_last = nullptr; }
+void *ctx_deferred_event(lzfse_mi_ctx *c) { return (void *)c->defer_last; }
 std::shared_ptr<StreamBox> ctx_stream_box(lzfse_mi_ctx *c) {
     std::lock_guard<std::mutex> g(c->stream_refs_m);
     if (!c->stream_box) {
@@ -296,6 +307,12 @@ void lzfse_mi_destroy(lzfse_mi_ctx *c) {
         if (c->stream_box->peer) lzfse_mi_destroy(c->stream_box->peer);
         c->stream_box->peer = nullptr;
     }
+    if (c->xfer_stream) {
+        (void)hipStreamSynchronize(c->xfer_stream);
+        (void)hipStreamDestroy(c->xfer_stream);
+        for (auto &e : c->defer_ev) if (e) (void)hipEventDestroy(e);
+    }
+    c->d_out2.release();
     for (auto &w : c->worker) { delete w; w = nullptr; }
     for (auto &s : c->shadow) { if (s) lzfse_mi_destroy(s); s = nullptr; }
     (void)hipSetDevice(c->device);
@@ -1116,7 +1133,16 @@ static int host_batch_one(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, s
             if ((caps[i] >= direct_out) == (big != 0)) { dof[i] = out_total; dc[i] = caps[i]; out_total += (caps[i] + 255) & ~(uint64_t)255; }
         if (!big) out_staged = out_total;
     }
-    if (!c->d_in.ensure(in_total + 256) || !c->d_out.ensure(out_total + 256) || !c->h_in.ensure(in_staged + 256))
+    // (a deferred transfer, see below: this call's device output buffer is the one of the call before last, whose transfer is over)
+    const bool defer = c->defer_out && count == 1 && !pack_outputs;
+    const int ob = defer ? c->out_flip : 0;
+    DevBuf &dout = ob ? c->d_out2 : c->d_out;
+    c->defer_last = nullptr;
+    if (defer) {
+        if (c->defer_pending[ob]) { HIP_TRY(hipEventSynchronize(c->defer_ev[ob])); c->defer_pending[ob] = false; }
+        c->out_flip ^= 1;
+    } else if (c->defer_pending[0]) { HIP_TRY(hipEventSynchronize(c->defer_ev[0])); c->defer_pending[0] = false; }
+    if (!c->d_in.ensure(in_total + 256) || !dout.ensure(out_total + 256) || !c->h_in.ensure(in_staged + 256))
         return LZFSE_MI_IO;
     std::vector<CopyJob> jobs;
     std::vector<uint64_t> pre, stage;   // per job: first byte in the concatenation, offset in the staging buffer
@@ -1149,7 +1175,7 @@ static int host_batch_one(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, s
         pop.add(dsts[i], want);
     }
     pop.start(c);
-    int r = fn(c, count, c->d_in.p, so.data(), sl.data(), c->d_out.p, dof.data(), dc.data(), ol.data(), statuses);
+    int r = fn(c, count, c->d_in.p, so.data(), sl.data(), dout.p, dof.data(), dc.data(), ol.data(), statuses);
     pop.finish();
     if (r) return r;
     // ---- out: where each stream's bytes are on the device (packed first when they fill little of their capacity) ----
@@ -1163,7 +1189,7 @@ static int host_batch_one(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, s
         if (out_lens[i]) { produced += out_lens[i]; hi_off = std::max(hi_off, dof[i] + ol[i]); }
     }
     if (!produced) return LZFSE_MI_OK;
-    const uint8_t *d_from = (const uint8_t *)c->d_out.p;
+    const uint8_t *d_from = (const uint8_t *)dout.p;
     uint64_t staged_span = out_staged;      // the staged outputs lie in [0, staged_span) of the buffer that travels
     std::vector<uint8_t> big_out(count);    // which outputs travel by a transfer of their own: by capacity (the layout) ...
     for (size_t i = 0; i < count; i++) big_out[i] = caps[i] >= direct_out;
@@ -1190,7 +1216,7 @@ static int host_batch_one(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, s
         if (c->d_in.ensure((size_t)desc_at + desc.size() * sizeof(SmallDesc) + 256)) {
             SmallDesc *d_desc = (SmallDesc *)((uint8_t *)c->d_in.p + desc_at);
             HIP_TRY(hipMemcpyAsync(d_desc, desc.data(), desc.size() * sizeof(SmallDesc), hipMemcpyHostToDevice, c->stream));
-            hipLaunchKernelGGL(small_copy_kernel, dim3((uint32_t)desc.size()), dim3(256), 0, c->stream, (const uint8_t *)c->d_out.p,
+            hipLaunchKernelGGL(small_copy_kernel, dim3((uint32_t)desc.size()), dim3(256), 0, c->stream, (const uint8_t *)dout.p,
                                (uint8_t *)c->d_in.p, (const SmallDesc *)d_desc, (uint32_t)desc.size());
             HIP_TRY(hipStreamSynchronize(c->stream));   // (`desc` is pageable memory of this scope)
             d_from = (const uint8_t *)c->d_in.p;
@@ -1221,6 +1247,29 @@ static int host_batch_one(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, s
     // the large streams go straight into the caller's buffers (behind the granules on the stream: those are unpacked by the
     // helper threads while these travel)
     bool any_direct = false;
+    if (defer && out_lens[0] && big_out[0] && n_gran == 0) {
+        // The stream decoder's window in the background: the kernels are through (fn has waited for them). The last bytes of the
+        // output -- the next window's history -- come at once; the rest travels on a stream of its own while this call returns
+        // and the next window's call uploads and decodes: whoever wants the bytes waits for the event first (ctx_deferred_event).
+        if (!c->xfer_stream) {
+            if (hipStreamCreateWithFlags(&c->xfer_stream, hipStreamNonBlocking) != hipSuccess) c->xfer_stream = nullptr;
+            else
+                for (auto &e : c->defer_ev)
+                    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+        }
+        if (c->xfer_stream && c->defer_ev[ob]) {
+            const size_t tail = out_lens[0] < ((size_t)1 << 18) ? out_lens[0] : (size_t)1 << 18, body = out_lens[0] - tail;
+            HIP_TRY(hipMemcpyAsync(dsts[0] + body, d_from + at[0] + body, tail, hipMemcpyDeviceToHost, c->stream));
+            if (body) {
+                HIP_TRY(hipMemcpyAsync(dsts[0], d_from + at[0], body, hipMemcpyDeviceToHost, c->xfer_stream));
+                HIP_TRY(hipEventRecord(c->defer_ev[ob], c->xfer_stream));
+                c->defer_pending[ob] = true;
+                c->defer_last = c->defer_ev[ob];
+            }
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            return LZFSE_MI_OK;
+        }
+    }
     for (size_t i = 0; i < count; i++)
         if (out_lens[i] && big_out[i]) {
             HIP_TRY(hipMemcpyAsync(dsts[i], d_from + at[i], out_lens[i], hipMemcpyDeviceToHost, c->stream));

@@ -159,6 +159,10 @@ lzfse_mi_ctx *box_peer(StreamBox &b);   // under b.m: the peer context (created 
 void ctx_set_window(lzfse_mi_ctx *c, EncWindow *w);
 // the destination of the host-pointer call that follows is pinned memory: its output travels straight there (stream.hip)
 void ctx_set_pinned_out(lzfse_mi_ctx *c, bool on);
+// ... and may be left to travel while the call returns (a single decoded stream; all but its last 256 KiB): what
+// ctx_deferred_event gives after the call (a hipEvent_t, or null) is to be waited for before the bytes are read
+void ctx_set_defer_out(lzfse_mi_ctx *c, bool on);
+void *ctx_deferred_event(lzfse_mi_ctx *c);
 int ctx_diag_chain(lzfse_mi_ctx *c);  // LZFSE_MI_OPT_DIAG_CHAIN: 1 = every chain tile through the ballot kernel
 
 // ---- decode.hip ----

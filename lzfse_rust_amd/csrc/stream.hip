@@ -47,6 +47,7 @@ struct lzfse_mi_dstream {
     int pend_st = 0, pend_buf = 0;
     size_t pend_got = 0, pend_nh = 0, pend_len = 0;
     uint64_t pend_cap = 0;
+    void *pend_ev = nullptr;       // the window's bytes are still on their way (all but the last 256 KiB): wait for this hipEvent_t first
     // (the helper copies the window's blocks out of `in` itself: until it has, `in` must neither move nor lose its front)
     std::atomic<int> copied{1};
     size_t pend_from = 0, pend_span = 0;
@@ -56,6 +57,9 @@ struct lzfse_mi_dstream {
         // (what this object's windows grew stays with the context for the next stream object -- if the context is still there
         // and keeps such buffers: ctx is null once lzfse_mi_destroy has run, LZFSE_MI_OPT_STREAM_SPARE)
         wait_idle();
+        // (a window's bytes may still be travelling into adst[]: not to be freed under them. Once the context is gone -- ctx is null --
+        // so is the stream they travelled on, which lzfse_mi_destroy has waited for)
+        if (ctx && pend_ev) (void)hipEventSynchronize((hipEvent_t)pend_ev);
         delete worker;
         std::free(far_dst);
         if (!ctx) return;
@@ -206,10 +210,12 @@ int decode_span(lzfse_mi_dstream *s, size_t span, uint64_t raw, bool with_eos, l
 // ---- windows in the background ----
 
 // the window in flight: its status; ptr / len: what it decoded (behind the history block), still to be handed to the sink
-int ds_complete(lzfse_mi_dstream *s, const uint8_t **ptr, size_t *len) {
+int ds_complete(lzfse_mi_dstream *s, const uint8_t **ptr, size_t *len, void **ev) {
     *ptr = nullptr; *len = 0;
     s->wait_idle();
     s->pending = false;
+    *ev = s->pend_ev;     // (the next window's helper writes the field again)
+    s->pend_ev = nullptr;
     if (s->pend_st) return s->pend_st;
     if (s->pend_got < s->pend_nh) return LZFSE_MI_IO;
     const uint8_t *base = s->adst[s->pend_buf].p;
@@ -219,7 +225,8 @@ int ds_complete(lzfse_mi_dstream *s, const uint8_t **ptr, size_t *len) {
     return 0;
 }
 
-int ds_sink(lzfse_mi_dstream *s, const uint8_t *ptr, size_t len, lzfse_mi_write_fn write, void *user) {
+int ds_sink(lzfse_mi_dstream *s, const uint8_t *ptr, size_t len, void *ev, lzfse_mi_write_fn write, void *user) {
+    if (ev && hipEventSynchronize((hipEvent_t)ev) != hipSuccess) return LZFSE_MI_IO;   // (the window's bytes: over by now, as a rule)
     if (len && write && write(user, ptr, len)) return LZFSE_MI_IO;
     s->total_out += len;
     return 0;
@@ -228,9 +235,9 @@ int ds_sink(lzfse_mi_dstream *s, const uint8_t *ptr, size_t len, lzfse_mi_write_
 // nothing in flight afterwards
 int ds_drain(lzfse_mi_dstream *s, lzfse_mi_write_fn write, void *user) {
     if (!s->pending) return 0;
-    const uint8_t *p; size_t n;
-    if (const int st = ds_complete(s, &p, &n)) return st;
-    return ds_sink(s, p, n, write, user);
+    const uint8_t *p; size_t n; void *ev;
+    if (const int st = ds_complete(s, &p, &n, &ev)) return st;
+    return ds_sink(s, p, n, ev, write, user);
 }
 
 // in[in_pos .. in_pos + span) -- complete blocks holding `raw` bytes -- go to the device in the background (nothing is in
@@ -271,13 +278,18 @@ int ds_launch(lzfse_mi_dstream *s, size_t span, uint64_t raw) {
         PinBuf &dd = s->adst[s->pend_buf];
         uint64_t cap = s->pend_cap;
         size_t got = 0;
+        // (the output may still be travelling when the call returns -- on a stream of its own, under the next window's call:
+        // ds_complete's caller waits for pend_ev before it hands the bytes on)
         ctx_set_pinned_out(c, true);
+        ctx_set_defer_out(c, true);
         int st = lzfse_mi_decode(c, s->wsrc.p, s->pend_len, dd.p, (size_t)cap, &got);
         if (st == LZFSE_MI_BUFFER_OVERFLOW) {   // the sink is unbounded: find the error the reference's Vec would have met (decode_span)
             cap += lzfse_mi_decode_headroom(s->wsrc.p, s->pend_len);
             if (!dd.reserve((size_t)cap + 64, false)) st = LZFSE_MI_IO;
             else st = lzfse_mi_decode(c, s->wsrc.p, s->pend_len, dd.p, (size_t)cap, &got);
         }
+        s->pend_ev = st ? nullptr : ctx_deferred_event(c);
+        ctx_set_defer_out(c, false);
         ctx_set_pinned_out(c, false);
         s->pend_st = st; s->pend_got = got;
     });
@@ -291,11 +303,11 @@ int ds_launch(lzfse_mi_dstream *s, size_t span, uint64_t raw) {
 // A full window with more input to come: the one in flight is taken back, this one sent off, and what the former decoded handed
 // to the sink while the device works on this one.
 int ds_advance(lzfse_mi_dstream *s, size_t span, uint64_t raw, lzfse_mi_write_fn write, void *user) {
-    const uint8_t *p = nullptr; size_t n = 0;
+    const uint8_t *p = nullptr; size_t n = 0; void *ev = nullptr;
     if (s->pending)
-        if (const int st = ds_complete(s, &p, &n)) return st;
+        if (const int st = ds_complete(s, &p, &n, &ev)) return st;
     const int e = ds_launch(s, span, raw);
-    if (const int st = ds_sink(s, p, n, write, user)) return st;
+    if (const int st = ds_sink(s, p, n, ev, write, user)) return st;
     if (e > 0) return e;
     if (e < 0) return decode_span(s, span, raw, true, write, user);
     return 0;
