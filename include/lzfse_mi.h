@@ -219,8 +219,8 @@ LZFSE_MI_API size_t lzfse_mi_decode_headroom(const uint8_t *src, size_t n);
  * written by then). Memory (pinned host memory): the input not yet decoded, a copy of the window in flight, and two windows
  * of output. `write` returns 0 to go on. */
 /* (a window is ONE stream on the device, and one stream costs its latency floors -- a block's entropy chain, the header
- * walk -- whatever its size: through the Python mirror 64 MiB windows decode 256 MiB of text at 11.8 GB/s, 16 MiB windows at 7.5,
- * 4 MiB windows at 2.75; the slice call into a reused buffer reaches 15: profiles/r04_stream_bench.txt) */
+ * walk -- whatever its size: through the Python mirror 64 MiB windows decode 256 MiB of text at 13.5 GB/s, 16 MiB windows at 8.5,
+ * 4 MiB windows at 2.9; the slice call into a reused buffer reaches 15: profiles/r04_stream_bench.txt) */
 #define LZFSE_MI_STREAM_WINDOW ((size_t)64 << 20)
 typedef struct lzfse_mi_dstream lzfse_mi_dstream;
 typedef int (*lzfse_mi_write_fn)(void *user, const uint8_t *bytes, size_t n);
