@@ -360,6 +360,7 @@ def main():
                 ctx.enable_timing(False)
                 out["html"] = html_rows(ctx, torch, dev, lz, raws[names.index("html")])
                 out["per_file"] = per_file_compact(ctx, torch, dev, lz, names, raws)
+                out["stream"] = stream_rows(ctx, lz)
         if not args.no_cpu_baseline:
             sample = batch_raw[:12] if args.workload == "snappy" else [batch_raw[0][:8 << 20]]
             out["cpu_baseline"] = cpu_baseline(sample)
@@ -611,6 +612,51 @@ def html_rows(ctx, torch, dev, lz, raw):
     rows["what"] = (f"data/snappy/html ({len(raw)} B) alone as a batch of R independent copies resident in HBM, wall time of the "
                     "batch call, 2 warm-up + 20 (x256) / 5 (x16) samples")
     return rows
+
+
+def stream_rows(ctx, lz, mib=128):
+    """SURVEY section 8f rank 3 inside the default line: LzfseRingEncoder::encode / LzfseRingDecoder::decode over a reader and a
+    writer (host memory on both sides, 1 MiB reads), synthetic text, by the window (scripts/stream_bench.py has all the rows)."""
+    import io
+
+    class Count:
+        def __init__(self):
+            self.n = 0
+
+        def write(self, b):
+            self.n += len(b)
+
+    raw = bytes(synth_text(mib << 20))
+    rows = {}
+    enc = None
+    for window in (64 << 20, 16 << 20):
+        best_e = best_d = 1e9
+        for _ in range(2):
+            out = bytearray()
+            w = lz.LzfseRingEncoder(context=ctx, window=window, read_size=1 << 20)
+            t0 = time.perf_counter()
+            u, v = w.encode(io.BytesIO(raw), _Appender(out))
+            best_e = min(best_e, time.perf_counter() - t0)
+            assert u == len(raw)
+            enc = bytes(out)
+        for _ in range(2):
+            sink = Count()
+            t0 = time.perf_counter()
+            u, v = lz.LzfseRingDecoder(context=ctx, window=window, read_size=1 << 20).decode(io.BytesIO(enc), sink)
+            best_d = min(best_d, time.perf_counter() - t0)
+            assert (u, v, sink.n) == (len(enc), len(raw), len(raw))
+        rows[f"window_{window >> 20}MiB"] = {"encode_GBps": round(len(raw) / best_e / 1e9, 2), "decode_GBps": round(len(raw) / best_d / 1e9, 2)}
+    rows["what"] = (f"{mib} MiB of synthetic text through LzfseRingEncoder.encode(reader, writer) / LzfseRingDecoder.decode(reader, writer) "
+                    "(the Python mirrors over lzfse_mi_estream_* / _dstream_*; host buffers, 1 MiB reads, best of 2); the ring parse's bytes")
+    return rows
+
+
+class _Appender:
+    def __init__(self, out):
+        self.out = out
+
+    def write(self, b):
+        self.out += b
 
 
 def per_file_compact(ctx, torch, dev, lz, names, raws, R=256, samples=20):
