@@ -265,6 +265,13 @@ LZFSE_MI_API int lzfse_mi_encode_ring_batch_device(lzfse_mi_ctx *ctx, size_t cou
 typedef struct lzfse_mi_estream lzfse_mi_estream;
 LZFSE_MI_API int lzfse_mi_estream_create(lzfse_mi_ctx *ctx, size_t window, lzfse_mi_estream **out);
 LZFSE_MI_API int lzfse_mi_estream_feed(lzfse_mi_estream *s, const uint8_t *src, size_t n, lzfse_mi_write_fn write, void *user);
+/* feed without the copy, for LzfseRingEncoder::encode(reader, writer) (encode/ring_encoder.rs:55-67: its copy(reader) reads
+ * straight into the ring): reserve says where the next input bytes go and how many fit (1 <= *room <= want; making room may
+ * hand a finished window's blocks to `write` and send the next window off), the caller reads into *ptr and commits what came
+ * (n <= *room; 0 is allowed). feed(src, n) is reserve + memcpy + commit until n bytes are in. */
+LZFSE_MI_API int lzfse_mi_estream_reserve(lzfse_mi_estream *s, size_t want, uint8_t **ptr, size_t *room, lzfse_mi_write_fn write,
+                                          void *user);
+LZFSE_MI_API int lzfse_mi_estream_commit(lzfse_mi_estream *s, size_t n);
 LZFSE_MI_API int lzfse_mi_estream_finish(lzfse_mi_estream *s, lzfse_mi_write_fn write, void *user, uint64_t *bytes_in,
                                          uint64_t *bytes_out);
 LZFSE_MI_API void lzfse_mi_estream_destroy(lzfse_mi_estream *s);

@@ -26,7 +26,7 @@ _SYMBOLS = [
     "lzfse_mi_decode_chunked_size", "lzfse_mi_decode_chunked", "lzfse_mi_dstream_create", "lzfse_mi_dstream_feed",
     "lzfse_mi_dstream_totals", "lzfse_mi_dstream_destroy", "lzfse_mi_decode_headroom",
     "lzfse_mi_encode_ring", "lzfse_mi_encode_ring_batch", "lzfse_mi_encode_ring_batch_device",
-    "lzfse_mi_get_info", "lzfse_mi_estream_create", "lzfse_mi_estream_feed", "lzfse_mi_estream_finish", "lzfse_mi_estream_destroy",
+    "lzfse_mi_get_info", "lzfse_mi_estream_create", "lzfse_mi_estream_feed", "lzfse_mi_estream_reserve", "lzfse_mi_estream_commit", "lzfse_mi_estream_finish", "lzfse_mi_estream_destroy",
 ]
 
 
@@ -107,6 +107,10 @@ def _load(path):
     L.lzfse_mi_estream_create.argtypes = [vp, sz, C.POINTER(vp)]
     L.lzfse_mi_estream_feed.restype = C.c_int
     L.lzfse_mi_estream_feed.argtypes = [vp, vp, sz, WRITE_FN, vp]
+    L.lzfse_mi_estream_reserve.restype = C.c_int
+    L.lzfse_mi_estream_reserve.argtypes = [vp, sz, C.POINTER(vp), C.POINTER(sz), WRITE_FN, vp]
+    L.lzfse_mi_estream_commit.restype = C.c_int
+    L.lzfse_mi_estream_commit.argtypes = [vp, sz]
     L.lzfse_mi_estream_finish.restype = C.c_int
     L.lzfse_mi_estream_finish.argtypes = [vp, WRITE_FN, vp, u64p, u64p]
     L.lzfse_mi_estream_destroy.restype = None

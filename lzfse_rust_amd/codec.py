@@ -287,11 +287,26 @@ class LzfseRingEncoder:
     def encode(self, reader, writer):
         w = LzfseWriter(self._ctx, writer, self._window)
         n_in = 0
-        while True:
-            piece = reader.read(self._read_size)
-            if not piece:
-                break
-            n_in += w.write(piece)
+        readinto = getattr(reader, "readinto", None)
+        if readinto is not None:
+            # copy(reader) of the reference reads straight into its ring (ring_encoder.rs:55-67): so does this, into the window
+            # buffer the library says (lzfse_mi_estream_reserve / _commit)
+            while True:
+                view = w._reserve(self._read_size)
+                try:
+                    k = readinto(view)
+                finally:
+                    view.release()
+                w._commit(k or 0)
+                if not k:
+                    break
+                n_in += k
+        else:
+            while True:
+                piece = reader.read(self._read_size)
+                if not piece:
+                    break
+                n_in += w.write(piece)
         w.finalize()
         return n_in, w.bytes_out
 
@@ -350,6 +365,18 @@ class LzfseWriter:
             raise self._failure.pop()
         _check(st)
         return a.size
+
+    def _reserve(self, want):
+        """lzfse_mi_estream_reserve: a writable view of where the next input bytes go (release it before _commit)"""
+        p, room = C.c_void_p(), C.c_size_t(0)
+        st = self._lib.lzfse_mi_estream_reserve(self._h, int(want), C.byref(p), C.byref(room), self._cb, None)
+        if self._failure:
+            raise self._failure.pop()
+        _check(st)
+        return memoryview((C.c_uint8 * room.value).from_address(p.value)).cast("B")
+
+    def _commit(self, n):
+        _check(self._lib.lzfse_mi_estream_commit(self._h, int(n)))
 
     def flush(self):
         pass

@@ -454,6 +454,7 @@ struct lzfse_mi_estream {
     size_t pend_n = 0, pend_len = 0;
     int pend_st = 0;
     EncWindow pend_w;
+    size_t reserved = 0;          // bytes lzfse_mi_estream_reserve has promised behind buf.size
     void wait_idle() { if (worker && pending) worker->wait(); }
     ~lzfse_mi_estream() {
         wait_idle();
@@ -605,6 +606,45 @@ int lzfse_mi_estream_create(lzfse_mi_ctx *ctx, size_t window, lzfse_mi_estream *
 
 void lzfse_mi_estream_destroy(lzfse_mi_estream *s) { delete s; }
 
+// Where the next input bytes go, and how many fit there (1 <= *room <= want): LzfseRingEncoder::encode's copy(reader)
+// (encode/ring_encoder.rs:55-67) reads straight into its ring, and so can a binding -- read into *ptr, then commit what came.
+// Making room may take a finished window back (its blocks leave through `write`) and send the next one off.
+int lzfse_mi_estream_reserve(lzfse_mi_estream *s, size_t want, uint8_t **ptr, size_t *room, lzfse_mi_write_fn write, void *user) {
+    if (!s || !ptr || !room || !want || !write || s->finished) return LZFSE_MI_BAD_ARGUMENT;
+    *ptr = nullptr; *room = 0;
+    s->reserved = 0;
+    if (s->status) return s->status;
+    if (!s->ctx) return s->status = LZFSE_MI_BAD_ARGUMENT;   // its context has been destroyed
+    for (;;) {
+        // room: up to where the next window is tried; with a window in flight also no further than `buf` reaches without moving
+        size_t r = s->next_at > s->live() ? s->next_at - s->live() : 0;
+        if (s->pending && r > s->buf.cap - s->buf.size) r = s->buf.cap - s->buf.size;
+        if (r == 0) {
+            if (s->pending) { if (const int st = es_complete(s, write, user)) return s->status = st; continue; }
+            if (const int st = es_launch(s)) return s->status = st;
+            s->next_at = s->live() + s->window;        // (until the window says where it was cut)
+            continue;
+        }
+        if (r > want) r = want;
+        // (room for the whole window at once, as soon as the input shows that it will be needed: growing step by step copies
+        // the window's bytes again and again and pins twice the pages)
+        if (!s->pending && s->buf.cap < s->head + s->next_at && s->buf.size + r > ((size_t)4 << 20) && !s->buf.reserve(s->head + s->next_at + ((size_t)1 << 16))) return s->status = LZFSE_MI_IO;
+        if (s->buf.size + r > s->buf.cap && !s->buf.reserve(std::max<size_t>(std::max(s->buf.size + r, 2 * s->buf.cap), (size_t)256 << 10))) return s->status = LZFSE_MI_IO;
+        *ptr = s->buf.p + s->buf.size; *room = r;
+        s->reserved = r;
+        return LZFSE_MI_OK;
+    }
+}
+
+// n <= the room last reserved bytes have been stored where lzfse_mi_estream_reserve said
+int lzfse_mi_estream_commit(lzfse_mi_estream *s, size_t n) {
+    if (!s || s->finished || n > s->reserved) return LZFSE_MI_BAD_ARGUMENT;
+    if (s->status) return s->status;
+    s->buf.size += n; s->total_in += n;
+    s->reserved = 0;
+    return LZFSE_MI_OK;
+}
+
 // Write::write of LzfseWriter (encode/writer.rs:59-63): takes all of buf; whenever a window's worth of input is on hand the
 // device encodes it -- in the background, while this call and the next ones take more input -- and the blocks that are final
 // leave through `write` as soon as a call finds the window done
@@ -613,21 +653,11 @@ int lzfse_mi_estream_feed(lzfse_mi_estream *s, const uint8_t *src, size_t n, lzf
     if (s->status) return s->status;
     if (!s->ctx) return s->status = LZFSE_MI_BAD_ARGUMENT;   // its context has been destroyed
     while (n) {
-        // room: up to where the next window is tried; with a window in flight also no further than `buf` reaches without moving
-        size_t room = s->next_at > s->live() ? s->next_at - s->live() : 0;
-        if (s->pending && room > s->buf.cap - s->buf.size) room = s->buf.cap - s->buf.size;
-        if (room == 0) {
-            if (s->pending) { if (const int st = es_complete(s, write, user)) return s->status = st; continue; }
-            if (const int st = es_launch(s)) return s->status = st;
-            s->next_at = s->live() + s->window;        // (until the window says where it was cut)
-            continue;
-        }
-        const size_t take = n < room ? n : room;
-        // (room for the whole window at once, as soon as the input shows that it will be needed: growing step by step copies
-        // the window's bytes again and again and pins twice the pages)
-        if (!s->pending && s->buf.cap < s->head + s->next_at && s->buf.size + take > ((size_t)4 << 20) && !s->buf.reserve(s->head + s->next_at + ((size_t)1 << 16))) return s->status = LZFSE_MI_IO;
-        if (!s->buf.append(src, take)) return s->status = LZFSE_MI_IO;
-        src += take; n -= take; s->total_in += take;
+        uint8_t *p; size_t room;
+        if (const int st = lzfse_mi_estream_reserve(s, n, &p, &room, write, user)) return st;
+        std::memcpy(p, src, room);
+        if (const int st = lzfse_mi_estream_commit(s, room)) return st;
+        src += room; n -= room;
     }
     return LZFSE_MI_OK;
 }

@@ -380,3 +380,48 @@ def test_windowed_writer_sink_failure_and_reuse(ctx, oracle):
         w.write(b"more")
     got, _ = _windowed(ctx, data, 1 << 20, 1 << 18)
     assert got == oracle.ring_encode(data)
+
+
+def test_reserve_commit_is_feed_without_the_copy(ctx, oracle, snappy_raw):
+    """lzfse_mi_estream_reserve / _commit (what LzfseRingEncoder::encode's copy(reader) becomes): the same bytes as feed,
+    whatever the reads bring -- short reads, empty reads in the middle, a commit of less than the room -- and a commit of
+    more than the room is refused."""
+    import io
+    import lzfse_rust_amd as m
+    raw = (snappy_raw["lcet10.txt"] + snappy_raw["html"] + snappy_raw["kppkn.gtb"]) * 7          # 5 MB
+    want = oracle.ring_encode(raw)
+
+    class Choppy(io.RawIOBase):
+        def __init__(self, data, sizes):
+            self.d, self.p, self.sizes, self.k = data, 0, sizes, 0
+
+        def readable(self):
+            return True
+
+        def readinto(self, b):
+            n = min(len(b), self.sizes[self.k % len(self.sizes)], len(self.d) - self.p)
+            self.k += 1
+            b[:n] = self.d[self.p:self.p + n]
+            self.p += n
+            return n
+
+    for sizes, window, read_size in (([1 << 20], 1 << 20, 1 << 20), ([70000, 1, 300000, 5], 2 << 20, 123457), ([1 << 22], 1 << 20, 1 << 22)):
+        out = bytearray()
+        u, v = m.LzfseRingEncoder(context=ctx, window=window, read_size=read_size).encode(Choppy(raw, sizes), _Into(out))
+        assert (u, v) == (len(raw), len(want)) and bytes(out) == want, (sizes, window)
+    w = m.LzfseRingEncoder(context=ctx, window=1 << 20).writer_bytes(bytearray())
+    view = w._reserve(1000)
+    n = len(view)
+    view.release()
+    with pytest.raises(m.LzfseError):
+        w._commit(n + 1)
+    w._commit(0)
+    w.finalize()
+
+
+class _Into:
+    def __init__(self, out):
+        self.out = out
+
+    def write(self, b):
+        self.out += b
