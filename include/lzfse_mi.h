@@ -227,6 +227,11 @@ typedef int (*lzfse_mi_write_fn)(void *user, const uint8_t *bytes, size_t n);
 LZFSE_MI_API int lzfse_mi_dstream_create(lzfse_mi_ctx *ctx, size_t window, lzfse_mi_dstream **out);
 LZFSE_MI_API int lzfse_mi_dstream_feed(lzfse_mi_dstream *s, const uint8_t *src, size_t n, int finish, lzfse_mi_write_fn write,
                                        void *user);
+/* feed without the copy, for LzfseRingDecoder::decode(reader, writer) (decode/ring_decoder.rs:57-67 reads straight into its
+ * ring): reserve says where the next `want` input bytes go, the caller reads into *ptr and commits what came (n <= want),
+ * which then does what feed does behind its copy. feed(src, n, ..) is reserve + memcpy + commit. */
+LZFSE_MI_API int lzfse_mi_dstream_reserve(lzfse_mi_dstream *s, size_t want, uint8_t **ptr);
+LZFSE_MI_API int lzfse_mi_dstream_commit(lzfse_mi_dstream *s, size_t n, int finish, lzfse_mi_write_fn write, void *user);
 /* bytes of input consumed / of output written so far: the (u, v) LzfseRingDecoder::decode returns */
 LZFSE_MI_API int lzfse_mi_dstream_totals(const lzfse_mi_dstream *s, uint64_t *bytes_in, uint64_t *bytes_out);
 /* A stream object (decoder or encoder) and its context may be destroyed in either order: lzfse_mi_destroy(ctx) detaches the

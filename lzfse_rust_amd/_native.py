@@ -23,7 +23,7 @@ _SYMBOLS = [
     "lzfse_mi_encode_batch", "lzfse_mi_decode_batch", "lzfse_mi_decode_batch_device",
     "lzfse_mi_encode_batch_device", "lzfse_mi_enable_timing", "lzfse_mi_get_timings", "lzfse_mi_encode_small",
     "lzfse_mi_last_error_detail", "lzfse_mi_set_option", "lzfse_mi_chunked_bound", "lzfse_mi_encode_chunked",
-    "lzfse_mi_decode_chunked_size", "lzfse_mi_decode_chunked", "lzfse_mi_dstream_create", "lzfse_mi_dstream_feed",
+    "lzfse_mi_decode_chunked_size", "lzfse_mi_decode_chunked", "lzfse_mi_dstream_create", "lzfse_mi_dstream_feed", "lzfse_mi_dstream_reserve", "lzfse_mi_dstream_commit",
     "lzfse_mi_dstream_totals", "lzfse_mi_dstream_destroy", "lzfse_mi_decode_headroom",
     "lzfse_mi_encode_ring", "lzfse_mi_encode_ring_batch", "lzfse_mi_encode_ring_batch_device",
     "lzfse_mi_get_info", "lzfse_mi_estream_create", "lzfse_mi_estream_feed", "lzfse_mi_estream_reserve", "lzfse_mi_estream_commit", "lzfse_mi_estream_finish", "lzfse_mi_estream_destroy",
@@ -99,6 +99,10 @@ def _load(path):
     L.lzfse_mi_dstream_create.argtypes = [vp, sz, C.POINTER(vp)]
     L.lzfse_mi_dstream_feed.restype = C.c_int
     L.lzfse_mi_dstream_feed.argtypes = [vp, vp, sz, C.c_int, WRITE_FN, vp]
+    L.lzfse_mi_dstream_reserve.restype = C.c_int
+    L.lzfse_mi_dstream_reserve.argtypes = [vp, sz, C.POINTER(vp)]
+    L.lzfse_mi_dstream_commit.restype = C.c_int
+    L.lzfse_mi_dstream_commit.argtypes = [vp, sz, C.c_int, WRITE_FN, vp]
     L.lzfse_mi_dstream_totals.restype = C.c_int
     L.lzfse_mi_dstream_totals.argtypes = [vp, u64p, u64p]
     L.lzfse_mi_dstream_destroy.restype = None

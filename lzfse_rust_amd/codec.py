@@ -456,16 +456,31 @@ class LzfseRingDecoder:
                 return 1
 
         cb = _native.WRITE_FN(_write)
+        readinto = getattr(reader, "readinto", None)
         try:
             while True:
-                piece = reader.read(self._read_size)
-                a = np.frombuffer(piece, dtype=np.uint8)
-                st = lib.lzfse_mi_dstream_feed(h, a.ctypes.data if a.size else None, a.size, 0 if a.size else 1, cb, None)
+                if readinto is not None:
+                    # (the reference reads straight into its ring, ring_decoder.rs:57-67: so does this, into the library's input buffer)
+                    p = C.c_void_p()
+                    st = lib.lzfse_mi_dstream_reserve(h, self._read_size, C.byref(p))
+                    if st != OK:
+                        raise LzfseError(st, 0)
+                    view = memoryview((C.c_uint8 * self._read_size).from_address(p.value)).cast("B")
+                    try:
+                        k = readinto(view) or 0
+                    finally:
+                        view.release()
+                    st = lib.lzfse_mi_dstream_commit(h, k, 0 if k else 1, cb, None)
+                else:
+                    piece = reader.read(self._read_size)
+                    a = np.frombuffer(piece, dtype=np.uint8)
+                    k = a.size
+                    st = lib.lzfse_mi_dstream_feed(h, a.ctypes.data if a.size else None, a.size, 0 if a.size else 1, cb, None)
                 if failure:
                     raise failure[0]
                 if st != OK:
                     raise LzfseError(st, 0)
-                if not a.size:
+                if not k:
                     break
             u, v = C.c_uint64(0), C.c_uint64(0)
             _check(lib.lzfse_mi_dstream_totals(h, C.byref(u), C.byref(v)))

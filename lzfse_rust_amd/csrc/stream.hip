@@ -48,6 +48,7 @@ struct lzfse_mi_dstream {
     size_t pend_got = 0, pend_nh = 0, pend_len = 0;
     uint64_t pend_cap = 0;
     void *pend_ev = nullptr;       // the window's bytes are still on their way (all but the last 256 KiB): wait for this hipEvent_t first
+    size_t reserved = 0;           // bytes lzfse_mi_dstream_reserve has promised behind in.size
     // (the helper copies the window's blocks out of `in` itself: until it has, `in` must neither move nor lose its front)
     std::atomic<int> copied{1};
     size_t pend_from = 0, pend_span = 0;
@@ -367,18 +368,54 @@ LZFSE_MI_API int lzfse_mi_dstream_totals(const lzfse_mi_dstream *s, uint64_t *by
     return LZFSE_MI_OK;
 }
 
+// Where the next `want` input bytes go (LzfseRingDecoder::decode reads straight into its ring, decode/ring_decoder.rs:57-67):
+// read into *ptr, then commit what came. No decoding happens here.
+LZFSE_MI_API int lzfse_mi_dstream_reserve(lzfse_mi_dstream *s, size_t want, uint8_t **ptr) {
+    if (!s || !ptr || !want) return LZFSE_MI_BAD_ARGUMENT;
+    *ptr = nullptr;
+    s->reserved = 0;
+    if (s->status) return s->status;
+    if (!s->ctx) return s->status = LZFSE_MI_BAD_ARGUMENT;   // its context has been destroyed
+    // (consumed input is dropped now and then; MAX_D_VALUE + 8 bytes of it stay in front of the rest: the next window's
+    // history block is written there, decode_span)
+    constexpr size_t KEEP = (size_t)MAX_D_VALUE + 8;
+    if (s->in_pos > KEEP && s->in_pos - KEEP >= s->in.size / 2) { s->wait_copied(); s->in.erase_front(s->in_pos - KEEP); s->in_pos = KEEP; }
+    if (s->in.size + want > s->in.cap) {
+        s->wait_copied();   // (the buffer is about to move)
+        if (!s->in.reserve(std::max<size_t>(std::max(s->in.size + want, 2 * s->in.cap), (size_t)256 << 10))) return s->status = LZFSE_MI_IO;
+    }
+    *ptr = s->in.p + s->in.size;
+    s->reserved = want;
+    return LZFSE_MI_OK;
+}
+
+static int ds_process(lzfse_mi_dstream *s, int finish, lzfse_mi_write_fn write, void *user);
+
+// n <= want bytes have been stored where lzfse_mi_dstream_reserve said; then as lzfse_mi_dstream_feed does after taking its bytes
+LZFSE_MI_API int lzfse_mi_dstream_commit(lzfse_mi_dstream *s, size_t n, int finish, lzfse_mi_write_fn write, void *user) {
+    if (!s || n > s->reserved) return LZFSE_MI_BAD_ARGUMENT;
+    if (s->status) return s->status;
+    if (!s->ctx) return s->status = LZFSE_MI_BAD_ARGUMENT;
+    s->in.size += n;
+    s->reserved = 0;
+    return ds_process(s, finish, write, user);
+}
+
 LZFSE_MI_API int lzfse_mi_dstream_feed(lzfse_mi_dstream *s, const uint8_t *src, size_t n, int finish, lzfse_mi_write_fn write, void *user) {
     if (!s || (!src && n)) return LZFSE_MI_BAD_ARGUMENT;
     if (s->status) return s->status;
     if (!s->ctx) return s->status = LZFSE_MI_BAD_ARGUMENT;   // its context has been destroyed
     if (n) {
-        // (consumed input is dropped now and then; MAX_D_VALUE + 8 bytes of it stay in front of the rest: the next window's
-        // history block is written there, decode_span)
-        constexpr size_t KEEP = (size_t)MAX_D_VALUE + 8;
-        if (s->in_pos > KEEP && s->in_pos - KEEP >= s->in.size / 2) { s->wait_copied(); s->in.erase_front(s->in_pos - KEEP); s->in_pos = KEEP; }
-        if (s->in.size + n > s->in.cap) s->wait_copied();   // (the buffer is about to move)
-        if (!s->in.append(src, n)) return s->status = LZFSE_MI_IO;
+        uint8_t *p;
+        if (const int st = lzfse_mi_dstream_reserve(s, n, &p)) return st;
+        std::memcpy(p, src, n);
+        s->in.size += n;
+        s->reserved = 0;
     }
+    return ds_process(s, finish, write, user);
+}
+
+static int ds_process(lzfse_mi_dstream *s, int finish, lzfse_mi_write_fn write, void *user) {
     for (;;) {
         if (s->eos_seen) {
             if (s->in.size > s->in_pos) return s->status = LZFSE_MI_PAYLOAD_OVERFLOW;   // bytes behind bvx$ (decoder.rs:93-95)

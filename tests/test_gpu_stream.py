@@ -397,3 +397,42 @@ def test_windows_in_the_background(oracle, snappy_raw):
     assert ei.value.status == oracle.decode_status(bytes(cut), len(raw) + 64)
     assert len(got) >= 4 << 20 and raw.startswith(bytes(got))
     c.close()
+
+
+def test_decode_reads_into_the_library_buffer(ctx, oracle, snappy_raw):
+    """lzfse_mi_dstream_reserve / _commit (decode(reader, writer) with a reader that has readinto): the same bytes and the same
+    statuses as feed, whatever the reads bring; a commit of more than was reserved is refused."""
+    import lzfse_rust_amd as m
+    raw = (snappy_raw["plrabn12.txt"] + snappy_raw["geo.protodata"]) * 6       # 3.6 MB
+    enc = oracle.encode(raw)
+
+    class Choppy(io.RawIOBase):
+        def __init__(self, data, sizes):
+            self.d, self.p, self.sizes, self.k = data, 0, sizes, 0
+
+        def readable(self):
+            return True
+
+        def readinto(self, b):
+            n = min(len(b), self.sizes[self.k % len(self.sizes)], len(self.d) - self.p)
+            self.k += 1
+            b[:n] = self.d[self.p:self.p + n]
+            self.p += n
+            return n
+
+    for sizes, read_size in (([1 << 20], 1 << 20), ([7, 100000, 1, 33333], 65536), ([1 << 24], 1 << 22)):
+        out = io.BytesIO()
+        u, v = m.LzfseRingDecoder(context=ctx, window=1 << 20, read_size=read_size).decode(Choppy(enc, sizes), out)
+        assert (u, v) == (len(enc), len(raw)) and out.getvalue() == raw, sizes
+    cut = enc[:len(enc) // 2]
+    with pytest.raises(m.LzfseError) as ei:
+        m.LzfseRingDecoder(context=ctx, window=1 << 20).decode(io.BytesIO(cut), io.BytesIO())
+    assert ei.value.status == oracle.decode_status(cut, len(raw) + 64)
+    lib = ctx._lib
+    h, p = C.c_void_p(), C.c_void_p()
+    assert lib.lzfse_mi_dstream_create(ctx._h, 0, C.byref(h)) == 0
+    assert lib.lzfse_mi_dstream_reserve(h, 100, C.byref(p)) == 0 and p.value
+    from lzfse_rust_amd import _native
+    cb = _native.WRITE_FN(lambda _u, q, n: 0)
+    assert lib.lzfse_mi_dstream_commit(h, 101, 0, cb, None) == 11      # LZFSE_MI_BAD_ARGUMENT
+    lib.lzfse_mi_dstream_destroy(h)
