@@ -102,7 +102,7 @@ enum {
     LZFSE_MI_OPT_DIAG_LZ_PATH = 100, /* -1: by cost, 0: tile kernel only, 1: pointer jumping for every stream */
     LZFSE_MI_OPT_DIAG_LZ_TILE = 101, /* -1: by stream count, 0: 256-thread / 8 KiB tile, 1: 1024-thread / 32 KiB tile */
     LZFSE_MI_OPT_DIAG_STATS = 102,   /* bit mask: per-stage statistics on stderr */
-    LZFSE_MI_OPT_DIAG_CHAIN = 103,   /* 1: every chain tile through the ballot kernel (the fallback of the LDS-exchange one) */
+    LZFSE_MI_OPT_DIAG_CHAIN = 103,   /* bit 0: every chain tile through the ballot kernel (the fallback of the LDS-exchange one); bits 4-6: chain tiles of 1, 2 or 4 x 65 472 positions (0x10, 0x20, 0x40) instead of the call's own choice */
     LZFSE_MI_OPT_DIAG_WALK = 104,    /* decode header walk: 0 by size, 1: every stream tries the parallel walk first, 2: serial only */
     LZFSE_MI_OPT_DIAG_PIPE_SCATTER = 105  /* 1: the pipelined LZ kernel is told that the workgroups of a stream sit on different XCDs
                                              (it must refuse, and the streams are decoded again by the one-workgroup kernel) */

@@ -4,7 +4,19 @@
 
 namespace lzmi {
 
-constexpr uint32_t TILE_POS = 65472;        // positions per chain tile: multiple of 64 and of CAND_P, offset + 1 fits u16
+constexpr uint32_t TILE_POS = 65472;        // positions per candidate tile (enc_cand_kernel's unit of XCD placement): a multiple of 64 and of 256
+// A CHAIN tile (enc_chain_kernel, enc_link_kernel) is 1, 2 or 4 of them: offset + 1 stays below 2^18, and an entry of the
+// last-seen table is that | 14 check bits. A longer tile has fewer first occurrences to link across tiles (enc_link: 11 % of
+// the Snappy positions at 64 Ki, 3 % at 256 Ki) and fewer summaries and lists to write; a call of few large streams keeps the
+// short tiles, which are what it has to fill the chip with (chain_tile_mult).
+constexpr uint32_t CH_TILE_MAX_MULT = 4;
+// (at least ~1 024 tiles where the call has them: two workgroups of eight waves per CU, two rounds; `count(m)` = chain tiles of the call at m)
+template <class F> __host__ inline uint32_t chain_tile_mult(F count, int forced) {
+    if (forced == 1 || forced == 2 || forced == 4) return (uint32_t)forced;
+    for (uint32_t m = CH_TILE_MAX_MULT; m > 1; m >>= 1)
+        if (count(m) >= 1024) return m;
+    return 1;
+}
 #ifndef LZMI_SEG
 #define LZMI_SEG 2048
 #endif
@@ -72,8 +84,8 @@ __device__ __forceinline__ uint32_t chk_of(uint32_t v) { return (v * 0x85EBCA6Bu
 __device__ __forceinline__ uint32_t link_make(uint32_t dist, uint32_t chk_prev) { return dist | (chk_prev << 18); }
 __device__ __forceinline__ uint32_t link_dist(uint32_t r) { return r & 0x3FFFFu; }
 __device__ __forceinline__ uint32_t link_chk(uint32_t r) { return r >> 18; }
-// Entry of a chain tile's last-seen table and of its summary: (offset in tile + 1) | check bits << 16; 0 = none
-__device__ __forceinline__ uint32_t seen_make(uint32_t off1, uint32_t v) { return off1 | (chk_of(v) << 16); }
+// Entry of a chain tile's last-seen table and of its summary: (offset in tile + 1, 18 bits) | check bits << 18; 0 = none
+__device__ __forceinline__ uint32_t seen_make(uint32_t off1, uint32_t v) { return off1 | (chk_of(v) << 18); }
 
 // ---- geometry of the reference's ring encoder in flat positions (encode/frontend_ring.rs, encode/constants.rs:23-33) ----
 // The ring (512 KiB, filled in 16 KiB blocks) is matched in rounds: round 0 takes positions [0, RING/2 + BLK) with the ring
@@ -240,9 +252,9 @@ __host__ __device__ inline uint32_t stage_need(uint32_t n_lit, uint32_t n_lmd) {
 
 
 // encode_match.hip
-void launch_enc_chain(const uint8_t *src, const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, uint32_t *prev, uint32_t *summary,
+void launch_enc_chain(const uint8_t *src, const EncTile *tiles, uint32_t n_tiles, uint32_t tile_pos, uint32_t *prev, uint32_t *summary,
                       uint32_t *flist, uint32_t *fcount, uint32_t *redo, bool force_redo, hipStream_t st);
-void launch_enc_link(const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, uint32_t *prev, const uint32_t *summary,
+void launch_enc_link(const EncTile *tiles, uint32_t n_tiles, uint32_t tile_pos, uint32_t *prev, const uint32_t *summary,
                      const uint32_t *flist, const uint32_t *fcount, hipStream_t st);
 void launch_enc_cand(const uint8_t *src, const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, const uint32_t *prev, uint32_t *rec,
                      uint64_t *bitmap, hipStream_t st);

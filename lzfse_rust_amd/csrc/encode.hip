@@ -720,7 +720,7 @@ __global__ __launch_bounds__(256) void enc_pack_kernel(const EncStream *__restri
 // ------------------------------------------------------------------------------------ host side
 
 enum { EB_STREAMS, EB_TILES, EB_PREV, EB_SUMMARY, EB_REC, EB_LMDS, EB_BLOCKS, EB_OUTS, EB_STAGE, EB_SLOTS,
-       EB_BITMAP, EB_SEGS, EB_LOGS, EB_HDRS, EB_RANGES, EB_GAPS, EB_MATCHES, EB_PC, EB_PL, EB_RSLOTS, EB_SYNC, EB_RSUM, EB_DBG, EB_SEGFLAG, EB_GSTATE, EB_CUT, EB_N };
+       EB_BITMAP, EB_SEGS, EB_LOGS, EB_HDRS, EB_RANGES, EB_GAPS, EB_MATCHES, EB_PC, EB_PL, EB_RSLOTS, EB_SYNC, EB_RSUM, EB_DBG, EB_SEGFLAG, EB_GSTATE, EB_CUT, EB_CTILES, EB_N };
 static_assert(EB_N <= 32, "EncScratch slots");
 
 static bool eb_ensure(EncScratch &s, int i, size_t n) {
@@ -820,9 +820,17 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         match_total += e.match_cap;
     }
     const uint32_t nt = (uint32_t)ht.size(), nseg = (uint32_t)hsegs.size();
+    // chain tiles: 1, 2 or 4 candidate tiles long (enc_common.h, chain_tile_mult)
+    const uint32_t ch_mult = chain_tile_mult([&](uint32_t m) { uint64_t k = 0; for (const EncStream &e : hs) k += ((uint64_t)e.n - 3 + (uint64_t)TILE_POS * m - 1) / ((uint64_t)TILE_POS * m); return k; },
+                                             ctx_diag_chain(c) >> 4);
+    const uint32_t ch_pos = TILE_POS * ch_mult;
+    std::vector<EncTile> hct;
+    for (uint32_t si = 0; si < ns; si++)
+        for (uint32_t p = 0; p < hs[si].n - 3; p += ch_pos) hct.push_back({si, hs[si].n, p, hs[si].ring, hs[si].src_off, hs[si].pos_base});
+    const uint32_t nct = (uint32_t)hct.size();
 
-    if (!eb_ensure(S, EB_STREAMS, ns * sizeof(EncStream)) || !eb_ensure(S, EB_TILES, nt * sizeof(EncTile)) ||
-        !eb_ensure(S, EB_PREV, pos_total * 4) || !eb_ensure(S, EB_SUMMARY, (size_t)nt * ((2u << HASH_BITS) + 64 + 2) * 4) ||
+    if (!eb_ensure(S, EB_STREAMS, ns * sizeof(EncStream)) || !eb_ensure(S, EB_TILES, nt * sizeof(EncTile)) || !eb_ensure(S, EB_CTILES, nct * sizeof(EncTile)) ||
+        !eb_ensure(S, EB_PREV, pos_total * 4) || !eb_ensure(S, EB_SUMMARY, (size_t)nct * ((2u << HASH_BITS) + 64 + 2) * 4) ||
         !eb_ensure(S, EB_REC, pos_total * 4) || !eb_ensure(S, EB_LMDS, lmd_total * 8) ||
         !eb_ensure(S, EB_BLOCKS, (size_t)blk_total * sizeof(EncBlock)) || !eb_ensure(S, EB_OUTS, ns * sizeof(EncStreamOut)) ||
         !eb_ensure(S, EB_STAGE, stage_total + 256) || !eb_ensure(S, EB_SLOTS, (size_t)blk_total * 4) ||
@@ -839,7 +847,8 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     EncTile *d_tiles = (EncTile *)S.bufs[EB_TILES];
     uint32_t *d_prev = (uint32_t *)S.bufs[EB_PREV];
     uint32_t *d_summary = (uint32_t *)S.bufs[EB_SUMMARY];
-    uint32_t *d_flist = d_summary + (size_t)nt * (1u << HASH_BITS), *d_fcount = d_flist + (size_t)nt * ((1u << HASH_BITS) + 64), *d_redo = d_fcount + nt;
+    uint32_t *d_flist = d_summary + (size_t)nct * (1u << HASH_BITS), *d_fcount = d_flist + (size_t)nct * ((1u << HASH_BITS) + 64), *d_redo = d_fcount + nct;
+    EncTile *d_ctiles = (EncTile *)S.bufs[EB_CTILES];
     uint32_t *d_rec = (uint32_t *)S.bufs[EB_REC];
     uint2 *d_lmds = (uint2 *)S.bufs[EB_LMDS];
     EncBlock *d_blocks = (EncBlock *)S.bufs[EB_BLOCKS];
@@ -849,6 +858,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     uint64_t *d_bitmap = (uint64_t *)S.bufs[EB_BITMAP];
     E_TRY(hipMemcpyAsync(d_streams, hs.data(), ns * sizeof(EncStream), hipMemcpyHostToDevice, stq));
     E_TRY(hipMemcpyAsync(d_tiles, ht.data(), nt * sizeof(EncTile), hipMemcpyHostToDevice, stq));
+    E_TRY(hipMemcpyAsync(d_ctiles, hct.data(), nct * sizeof(EncTile), hipMemcpyHostToDevice, stq));
     E_TRY(hipMemcpyAsync(d_slots, hslots.data(), (size_t)blk_total * 4, hipMemcpyHostToDevice, stq));
     E_TRY(hipMemsetAsync(d_outs, 0, ns * sizeof(EncStreamOut), stq));
     E_TRY(hipMemsetAsync(d_bitmap, 0, pos_total / 8 + 64, stq));
@@ -858,11 +868,11 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     }
     {
         StageTimer t(c, "enc_chain");
-        launch_enc_chain(d_src, d_streams, d_tiles, nt, d_prev, d_summary, d_flist, d_fcount, d_redo, ctx_diag_chain(c) == 1, stq);
+        launch_enc_chain(d_src, d_ctiles, nct, ch_pos, d_prev, d_summary, d_flist, d_fcount, d_redo, (ctx_diag_chain(c) & 1) != 0, stq);
     }
     {
         StageTimer t(c, "enc_link");
-        launch_enc_link(d_streams, d_tiles, nt, d_prev, d_summary, d_flist, d_fcount, stq);
+        launch_enc_link(d_ctiles, nct, ch_pos, d_prev, d_summary, d_flist, d_fcount, stq);
     }
     if (LaneGate *go = ctx_gate_out(c)) go->open(hipEventRecord(go->ev, stq) == hipSuccess ? 1 : 2);
     {
@@ -970,23 +980,27 @@ extern "C" LZFSE_MI_API int lzfse_mi_debug_candidates(lzfse_mi_ctx *c, const uin
     EncScratch &S = ctx_enc(c);
     EncStream e{};
     e.src_off = 0; e.pos_base = 0; e.n = (uint32_t)n;
-    std::vector<EncTile> ht;
+    std::vector<EncTile> ht, hct;
     for (uint32_t p = 0; p < e.n - 3; p += TILE_POS) ht.push_back({0u, e.n, p, 0u, 0ull, 0ull});
     const uint32_t nt = (uint32_t)ht.size();
+    const uint32_t ch_mult = chain_tile_mult([&](uint32_t m) { return ((uint64_t)e.n - 3 + (uint64_t)TILE_POS * m - 1) / ((uint64_t)TILE_POS * m); }, ctx_diag_chain(c) >> 4);
+    const uint32_t ch_pos = TILE_POS * ch_mult;
+    for (uint32_t p = 0; p < e.n - 3; p += ch_pos) hct.push_back({0u, e.n, p, 0u, 0ull, 0ull});
+    const uint32_t nct = (uint32_t)hct.size();
     size_t padn = (n + 255) & ~(size_t)255;
-    if (!eb_ensure(S, EB_STREAMS, sizeof(EncStream)) || !eb_ensure(S, EB_TILES, nt * sizeof(EncTile)) ||
-        !eb_ensure(S, EB_PREV, padn * 4) || !eb_ensure(S, EB_SUMMARY, (size_t)nt * ((2u << HASH_BITS) + 64 + 2) * 4) ||
+    if (!eb_ensure(S, EB_STREAMS, sizeof(EncStream)) || !eb_ensure(S, EB_TILES, nt * sizeof(EncTile)) || !eb_ensure(S, EB_CTILES, nct * sizeof(EncTile)) ||
+        !eb_ensure(S, EB_PREV, padn * 4) || !eb_ensure(S, EB_SUMMARY, (size_t)nct * ((2u << HASH_BITS) + 64 + 2) * 4) ||
         !eb_ensure(S, EB_REC, padn * 4) || !eb_ensure(S, EB_STAGE, padn + 256) || !eb_ensure(S, EB_BITMAP, padn / 8 + 64))
         return LZFSE_MI_IO;
     uint8_t *d_src = (uint8_t *)S.bufs[EB_STAGE];
     E_TRY(hipMemcpyAsync(d_src, h_src, n, hipMemcpyHostToDevice, stq));
     E_TRY(hipMemcpyAsync(S.bufs[EB_STREAMS], &e, sizeof e, hipMemcpyHostToDevice, stq));
     E_TRY(hipMemcpyAsync(S.bufs[EB_TILES], ht.data(), nt * sizeof(EncTile), hipMemcpyHostToDevice, stq));
+    E_TRY(hipMemcpyAsync(S.bufs[EB_CTILES], hct.data(), nct * sizeof(EncTile), hipMemcpyHostToDevice, stq));
     uint32_t *sm = (uint32_t *)S.bufs[EB_SUMMARY];
-    uint32_t *fl = sm + (size_t)nt * (1u << HASH_BITS), *fc = fl + (size_t)nt * ((1u << HASH_BITS) + 64), *redo = fc + nt;
-    launch_enc_chain(d_src, (EncStream *)S.bufs[EB_STREAMS], (EncTile *)S.bufs[EB_TILES], nt, (uint32_t *)S.bufs[EB_PREV], sm, fl, fc, redo,
-                     ctx_diag_chain(c) == 1, stq);
-    launch_enc_link((EncStream *)S.bufs[EB_STREAMS], (EncTile *)S.bufs[EB_TILES], nt, (uint32_t *)S.bufs[EB_PREV], sm, fl, fc, stq);
+    uint32_t *fl = sm + (size_t)nct * (1u << HASH_BITS), *fc = fl + (size_t)nct * ((1u << HASH_BITS) + 64), *redo = fc + nct;
+    launch_enc_chain(d_src, (EncTile *)S.bufs[EB_CTILES], nct, ch_pos, (uint32_t *)S.bufs[EB_PREV], sm, fl, fc, redo, (ctx_diag_chain(c) & 1) != 0, stq);
+    launch_enc_link((EncTile *)S.bufs[EB_CTILES], nct, ch_pos, (uint32_t *)S.bufs[EB_PREV], sm, fl, fc, stq);
     launch_enc_cand(d_src, (EncStream *)S.bufs[EB_STREAMS], (EncTile *)S.bufs[EB_TILES], nt, (uint32_t *)S.bufs[EB_PREV], (uint32_t *)S.bufs[EB_REC],
                     (uint64_t *)S.bufs[EB_BITMAP], stq);
     E_TRY(hipMemcpyAsync(h_prev, S.bufs[EB_PREV], (n - 3) * 4, hipMemcpyDeviceToHost, stq));  // link records

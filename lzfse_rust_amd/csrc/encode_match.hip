@@ -5,9 +5,9 @@
 // position i is a pure function of src[0..i+3] because every position is inserted exactly once,
 // in order (frontend_bytes.rs:187,336-344). That makes the expensive part position-parallel:
 //
-//   enc_chain_kernel   per 64 Ki-position tile: link record of every position = distance to the previous position of
-//                      its bucket (history.rs:221-224 hash, fse/object.rs:38-43) + check bits of that position, exact,
-//                      in order, one LDS exchange per position on a 16 384-entry last-seen table
+//   enc_chain_kernel   per chain tile (64 Ki .. 256 Ki positions): link record of every position = distance to the previous
+//                      position of its bucket (history.rs:221-224 hash, fse/object.rs:38-43) + check bits of that position,
+//                      exact, in order, one LDS exchange per position on a 16 384-entry last-seen table
 //                      (enc_chain_ballot_kernel: the same without the exchange, as a checked fallback)
 //   enc_link_kernel    first occurrences of a tile: link to earlier tiles (window 262 139)
 //   enc_cand_kernel    per position: <= 4 chain entries newest->oldest (<= 3 dependent gathers) with the reference's
@@ -27,21 +27,31 @@ namespace lzmi {
 
 // first-occurrence list of a tile: one slot per bucket + 64 slots where lanes that have nothing to list store
 constexpr uint32_t FL_STRIDE = (1u << HASH_BITS) + 64;
+constexpr int CH_WAVES = 8;                     // waves of a chain workgroup: they take the tile's batches in turn
+constexpr int CH_STEPS = 16;
+constexpr uint32_t CH_POS = 64 * CH_STEPS;     // positions per batch
 
-// One workgroup (two waves) per tile; positions in order, 64 per step. The last-seen table of the tile lives in LDS, one
-// 32-bit entry per bucket, and a step is ONE LDS exchange per lane: the entry a lane gets back is its predecessor in the
-// bucket -- an earlier step's, or a lower lane's of the same step, because gfx950 serialises the lanes of one ds_wrxchg
-// that hit the same address in ascending lane order (measured; scripts/micro/xchg_order.hip). That order is not
-// architectural, so every lane checks what it got (a predecessor must lie before it) and a tile that ever sees anything
-// else is redone by enc_chain_ballot_kernel, which assumes nothing. LDS operations of a wave execute in issue order, so
-// the exchanges of a batch of steps are issued back to back and the wave waits once per batch, not once per step.
-__global__ __launch_bounds__(128) void enc_chain_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
-                                                        const EncTile *__restrict__ tiles, uint32_t n_tiles,
-                                                        uint32_t *__restrict__ prev, uint32_t *__restrict__ summary,
-                                                        uint32_t *__restrict__ flist, uint32_t *__restrict__ fcount,
-                                                        uint32_t *__restrict__ redo, uint32_t force_redo) {
-    __shared__ uint32_t last[1u << HASH_BITS];  // seen_make(): (offset in tile + 1) | check bits << 16, 0 = none
-    __shared__ uint32_t sh_nfirst, sh_wrong;
+// One workgroup per chain tile (up to 4 x TILE_POS positions: the host picks the length, chain_tile_mult); positions in order,
+// 64 per step. The last-seen table of the tile lives in LDS, one 32-bit entry per bucket, and a step is ONE LDS exchange per
+// lane: the entry a lane gets back is its predecessor in the bucket -- an earlier step's, or a lower lane's of the same step,
+// because gfx950 serialises the lanes of one ds_wrxchg that hit the same address in ascending lane order (measured;
+// scripts/micro/xchg_order.hip). That order is not architectural, so every lane checks what it got (a predecessor must lie
+// before it) and a tile that ever sees anything else is redone by enc_chain_ballot_kernel, which assumes nothing.
+//
+// Round 5: EIGHT waves per tile instead of two, and the exchanges are the only thing they do in turn. The LDS unit takes a
+// wave's exchange in ~8 cycles when it is kept busy (scripts/micro/xchg_rate.hip, profiles/r05_xchg_rate.txt) -- rounds 2 to 4
+// read the kernel as bound by "the rate of LDS exchanges, ~64 cycles per wave instruction", but what they measured was a lone
+// wave per SIMD issuing one instruction every ~5 cycles: hashes, address clamps, ballots, 40-odd instructions per step on either
+// side of the exchange. A batch of 32 steps belongs to ONE wave from its loads to its link records; only between "turn == b"
+// and "turn = b + 1" (an LDS word) does the order of the batches matter, and that section is the 32 exchanges and their return.
+// Everything else -- the loads of the batch after next, the hashes, the records, the first-occurrence list (its slots are
+// reserved per batch with one LDS add) -- runs in eight waves side by side.
+__global__ __launch_bounds__(64 * CH_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void enc_chain_kernel(const uint8_t *__restrict__ src, const EncTile *__restrict__ tiles, uint32_t n_tiles,
+                                                                  uint32_t tile_pos, uint32_t *__restrict__ prev, uint32_t *__restrict__ summary,
+                                                                  uint32_t *__restrict__ flist, uint32_t *__restrict__ fcount,
+                                                                  uint32_t *__restrict__ redo, uint32_t force_redo) {
+    __shared__ uint32_t last[1u << HASH_BITS];  // seen_make(): (offset in tile + 1) | check bits << 18, 0 = none
+    __shared__ uint32_t sh_turn, sh_nfirst, sh_wrong;
     const uint32_t t = blockIdx.x;
     if (t >= n_tiles) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -50,114 +60,114 @@ __global__ __launch_bounds__(128) void enc_chain_kernel(const uint8_t *__restric
         return;
     }
     const EncTile tl = tiles[t];
-    for (uint32_t k = tid; k < (1u << HASH_BITS); k += 128) last[k] = 0;
-    if (tid == 0) { sh_nfirst = 0; sh_wrong = 0; }
+    for (uint32_t k = tid; k < (1u << HASH_BITS); k += 64 * CH_WAVES) last[k] = 0;
+    if (tid == 0) { sh_turn = 0; sh_nfirst = 0; sh_wrong = 0; }
     const uint8_t *s = src + tl.src_off;
     uint32_t *pv = prev + tl.pos_base;  // link records (enc_common.h)
     const uint32_t n_pos = tl.n - 3;  // positions 0 .. n-4 are hashed (frontend_bytes.rs:166-170)
-    const uint32_t t_end = tl.start + TILE_POS < n_pos ? tl.start + TILE_POS : n_pos;
+    const uint32_t t_end = tl.start + tile_pos < n_pos ? tl.start + tile_pos : n_pos;
     uint32_t *fl = flist + (uint64_t)t * FL_STRIDE;
-    // Batches of 32 steps (2 048 positions). A batch has two phases: the exchanges, which must follow those of the batch
-    // before (the table is sequential), and the bookkeeping -- links, first-occurrence list -- which only needs the
-    // values the exchanges returned. TWO waves share the table and take the batches in turn: while one does the
-    // bookkeeping of batch b the other runs the exchanges of batch b + 1 (a workgroup barrier between the turns), so
-    // the two halves of the work of a batch overlap; a lone wave is bound by the latency of its own instructions. The
-    // source values of a wave's next batch are loaded while it works. All loads are unconditional (addresses clamped
-    // to the tile's last position) and the stores of a full batch too: straight-line code, counted waits.
-    constexpr int CH_STEPS = 32;
-    constexpr uint32_t CH_POS = 64 * CH_STEPS;
     const uint32_t n_batches = (t_end - tl.start + CH_POS - 1) / CH_POS;
     const uint32_t q_last = t_end - 1;
-    uint32_t nx[CH_STEPS], key[CH_STEPS], old[CH_STEPS];
+    // All loads are unconditional (addresses clamped to the tile's last position) and the stores of a full batch too:
+    // straight-line code, counted waits. The source values of a wave's next batch are loaded while it works on this one.
+    uint32_t nx[CH_STEPS];
 #pragma unroll
     for (int j = 0; j < CH_STEPS; j++) {
         const uint32_t q = tl.start + (uint32_t)w * CH_POS + 64 * j + lane;
         nx[j] = ld_u32(s + (q < q_last ? q : q_last));
-        key[j] = 0; old[j] = 0;
     }
-    uint32_t *pvt = pv + tl.start;   // records of the tile: offsets below 2^16
+    uint32_t *pvt = pv + tl.start;   // records of the tile: offsets below 2^18
     bool wrong = false;
-    auto exchanges = [&](uint32_t pb, auto full_tag) {
-        constexpr bool FULL = decltype(full_tag)::value;
-        uint32_t ent[CH_STEPS];
-        const uint32_t off0 = pb - tl.start + (uint32_t)lane;   // offset in tile of this lane's position in step 0
-#pragma unroll
-        for (int j = 0; j < CH_STEPS; j++) {
-            key[j] = bucket_of(nx[j]);
-            ent[j] = seen_make(off0 + 64 * j + 1, nx[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < CH_STEPS; j++) {   // this wave's next batch
-            const uint32_t q = pb + 2 * CH_POS + 64 * j + lane;
-            nx[j] = ld_u32(s + (q < q_last ? q : q_last));
-        }
-#pragma unroll
-        for (int j = 0; j < CH_STEPS; j++) {
-            old[j] = 0;
-            if (FULL || pb + 64 * j + lane < t_end)
-                old[j] = __hip_atomic_exchange(&last[key[j]], ent[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    };
-    auto bookkeeping = [&](uint32_t pb, auto full_tag, auto later_tag) {
+    auto batch = [&](uint32_t b, auto full_tag, auto later_tag) {
         constexpr bool FULL = decltype(full_tag)::value, LATER = decltype(later_tag)::value;
-        const uint32_t off0 = pb - tl.start + (uint32_t)lane;
-        uint32_t n_first = LATER ? sh_nfirst : 0u;
+        const uint32_t pb = tl.start + b * CH_POS;
+        const uint32_t off0 = pb - tl.start + (uint32_t)lane;   // offset in tile of this lane's position in step 0
+        uint32_t key[CH_STEPS], old[CH_STEPS];
+        {
+            uint32_t ent[CH_STEPS];
+#pragma unroll
+            for (int j = 0; j < CH_STEPS; j++) {
+                key[j] = bucket_of(nx[j]);
+                ent[j] = seen_make(off0 + 64 * j + 1, nx[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < CH_STEPS; j++) {   // this wave's next batch
+                const uint32_t q = pb + CH_WAVES * CH_POS + 64 * j + lane;
+                nx[j] = ld_u32(s + (q < q_last ? q : q_last));
+            }
+            // ---- this batch's turn at the table: every earlier batch's exchanges have returned to their waves ----
+            while (__hip_atomic_load(&sh_turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != b) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < CH_STEPS; j++) {
+                old[j] = 0;
+                if (FULL || pb + 64 * j + lane < t_end)
+                    old[j] = __hip_atomic_exchange(&last[key[j]], ent[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            // (the LDS alone is waited for: the loads of the next batch and the stores of the last one stay in flight)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __hip_atomic_store(&sh_turn, b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("" ::: "memory");
+        }
+        // ---- links and first-occurrence list of the batch, from what the exchanges returned ----
+        uint32_t n_first = 0;
+        if (LATER) {
+            // first occurrence of its bucket in the tile: the link into earlier tiles is made by enc_link_kernel from this list
+            // (offset | bucket << 18; in any order); the first tile of a stream has nothing before it
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int j = 0; j < CH_STEPS; j++) {
+                const bool valid = FULL || pb + 64 * j + lane < t_end;
+                cnt += (uint32_t)__popcll(__ballot(valid && (old[j] & 0x3FFFFu) == 0));
+            }
+            uint32_t base = 0;
+            if (lane == 0 && cnt) base = atomicAdd(&sh_nfirst, cnt);
+            n_first = e_readlane(base, 0);
+        }
 #pragma unroll
         for (int j = 0; j < CH_STEPS; j++) {
             if (!FULL && pb + 64 * j >= t_end) continue;  // (not break: the loop must stay fully unrolled, the arrays live in registers)
             const uint32_t off = off0 + 64 * j;
-            __builtin_assume(off < 65536u);
+            __builtin_assume(off < (1u << 18));
             const bool valid = FULL || pb + 64 * j + lane < t_end;
-            const uint32_t o = old[j] & 0xFFFFu;
+            const uint32_t o = old[j] & 0x3FFFFu;
             wrong = wrong || (valid && o > off);   // a predecessor lies before its position (o is offset + 1)
-            // first occurrence of its bucket in the tile: the link into earlier tiles is made by enc_link_kernel
-            // from this list (offset | bucket << 16); the first tile of a stream has nothing before it
             if (LATER) {
                 const bool first = valid && o == 0;
                 const uint64_t fm = __ballot(first);
                 const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
-                fl[first ? n_first + below : (1u << HASH_BITS) + (uint32_t)lane] = off | (key[j] << 16);
+                fl[first ? n_first + below : (1u << HASH_BITS) + (uint32_t)lane] = off | (key[j] << 18);
                 n_first += (uint32_t)__popcll(fm);
             }
-            const uint32_t rec = o ? link_make(off + 1 - o, old[j] >> 16) : 0u;  // (inside a tile: < 65 536)
+            const uint32_t rec = o ? link_make(off + 1 - o, old[j] >> 18) : 0u;  // (inside a tile: < 2^18 and within the match window)
             if (FULL) pvt[off] = rec;
             else if (valid) pvt[off] = rec;
         }
-        if (LATER && lane == 0) sh_nfirst = n_first;
     };
     __syncthreads();
     const bool later = tl.start != 0;
-    for (uint32_t b = 0; b <= n_batches; b++) {
-        if ((int)(b & 1) == w) {
-            if (b < n_batches) {
-                const uint32_t pb = tl.start + b * CH_POS;
-                if (pb + CH_POS <= t_end) exchanges(pb, std::true_type{}); else exchanges(pb, std::false_type{});
-            }
-        } else if (b >= 1) {
-            const uint32_t pb = tl.start + (b - 1) * CH_POS;
-            const bool full = pb + CH_POS <= t_end;
-            if (later) { if (full) bookkeeping(pb, std::true_type{}, std::true_type{}); else bookkeeping(pb, std::false_type{}, std::true_type{}); }
-            else { if (full) bookkeeping(pb, std::true_type{}, std::false_type{}); else bookkeeping(pb, std::false_type{}, std::false_type{}); }
-        }
-        __syncthreads();
+    for (uint32_t b = (uint32_t)w; b < n_batches; b += CH_WAVES) {
+        const bool full = tl.start + (b + 1) * CH_POS <= t_end;
+        if (later) { if (full) batch(b, std::true_type{}, std::true_type{}); else batch(b, std::false_type{}, std::true_type{}); }
+        else { if (full) batch(b, std::true_type{}, std::false_type{}); else batch(b, std::false_type{}, std::false_type{}); }
     }
     if (__any(wrong) && lane == 0) sh_wrong = 1;
     __syncthreads();
     if (tid == 0) { fcount[t] = sh_nfirst; redo[t] = sh_wrong; }
     if (sh_wrong) return;
     uint32_t *sm = summary + (uint64_t)t * (1u << HASH_BITS);
-    for (uint32_t k = tid; k < (1u << HASH_BITS); k += 128) sm[k] = last[k];
+    for (uint32_t k = tid; k < (1u << HASH_BITS); k += 64 * CH_WAVES) sm[k] = last[k];
 }
 
 // The same links without any assumption about the LDS: the nearest previous position with the same bucket is either a
 // lower lane of the same step (found with 14 ballots) or the last-seen entry written by earlier steps. Runs only for
 // tiles enc_chain_kernel flagged (never, on the hardware measured); the diagnostic build can send every tile here.
-__global__ __launch_bounds__(64) void enc_chain_ballot_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
-                                                              const EncTile *__restrict__ tiles, uint32_t n_tiles,
-                                                              uint32_t *__restrict__ prev, uint32_t *__restrict__ summary,
+__global__ __launch_bounds__(64) void enc_chain_ballot_kernel(const uint8_t *__restrict__ src, const EncTile *__restrict__ tiles, uint32_t n_tiles,
+                                                              uint32_t tile_pos, uint32_t *__restrict__ prev, uint32_t *__restrict__ summary,
                                                               uint32_t *__restrict__ flist, uint32_t *__restrict__ fcount,
                                                               const uint32_t *__restrict__ redo) {
-    __shared__ uint16_t last[1u << HASH_BITS];  // offset in tile + 1, 0 = none
+    __shared__ uint32_t last[1u << HASH_BITS];  // offset in tile + 1, 0 = none
     const uint32_t t = blockIdx.x;
     if (t >= n_tiles || !redo[t]) return;
     const EncTile tl = tiles[t];
@@ -166,7 +176,7 @@ __global__ __launch_bounds__(64) void enc_chain_ballot_kernel(const uint8_t *__r
     const uint8_t *s = src + tl.src_off;
     uint32_t *pv = prev + tl.pos_base;
     const uint32_t n_pos = tl.n - 3;
-    const uint32_t t_end = tl.start + TILE_POS < n_pos ? tl.start + TILE_POS : n_pos;
+    const uint32_t t_end = tl.start + tile_pos < n_pos ? tl.start + tile_pos : n_pos;
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
     uint32_t *fl = flist + (uint64_t)t * FL_STRIDE;
     uint32_t n_first = 0;
@@ -190,11 +200,11 @@ __global__ __launch_bounds__(64) void enc_chain_ballot_kernel(const uint8_t *__r
         if (lower) pr = p0 + (63 - __builtin_clzll(lower));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (valid && (same >> lane) >> 1 == 0) last[key] = (uint16_t)mine;  // newest of its bucket wins
+        if (valid && (same >> lane) >> 1 == 0) last[key] = mine;  // newest of its bucket wins
         const bool first = valid && pr == NONE_TILE;
         if (tl.start != 0) {
             const uint64_t fm = __ballot(first);
-            if (first) fl[n_first + (uint32_t)__popcll(fm & lt_mask)] = (p - tl.start) | (key << 16);
+            if (first) fl[n_first + (uint32_t)__popcll(fm & lt_mask)] = (p - tl.start) | (key << 18);
             n_first += (uint32_t)__popcll(fm);
         }
         if (valid) pv[p] = pr == NONE_TILE ? 0u : link_make(p - pr, chk_of(ld_u32(s + pr)));
@@ -210,9 +220,9 @@ __global__ __launch_bounds__(64) void enc_chain_ballot_kernel(const uint8_t *__r
 }
 
 // Cross-tile links: a bucket's first occurrence in a tile (listed by the chain kernel) points at the newest
-// occurrence in an earlier tile of the same stream, whose summary entry also holds its check bits. Anything further
-// back than 5 tiles is outside the 262 139-byte window (fse/constants.rs:42) and would end the candidate scan anyway.
-__global__ void enc_link_kernel(const EncStream *__restrict__ streams, const EncTile *__restrict__ tiles, uint32_t n_tiles,
+// occurrence in an earlier tile of the same stream, whose summary entry also holds its check bits. A tile further back than
+// (MAX_D_VALUE - 1) / tile_pos + 1 lies outside the 262 139-byte window (fse/constants.rs:42) and would end the candidate scan anyway.
+__global__ void enc_link_kernel(const EncTile *__restrict__ tiles, uint32_t n_tiles, uint32_t tile_pos,
                                 uint32_t *__restrict__ prev, const uint32_t *__restrict__ summary,
                                 const uint32_t *__restrict__ flist, const uint32_t *__restrict__ fcount) {
     constexpr uint32_t BPT = (1u << HASH_BITS) / 256;  // workgroups per tile
@@ -224,13 +234,14 @@ __global__ void enc_link_kernel(const EncStream *__restrict__ streams, const Enc
     if (t >= n_tiles || e >= fcount[t]) return;
     const EncTile tl = tiles[t];
     const uint32_t ent = flist[(uint64_t)t * FL_STRIDE + e];
-    const uint32_t p = tl.start + (ent & 0xFFFF), key = ent >> 16;
-    const uint32_t t_idx = tl.start / TILE_POS;  // tile index inside the stream (its tiles are consecutive)
-    for (uint32_t back = 1; back <= 5 && back <= t_idx; back++) {
+    const uint32_t p = tl.start + (ent & 0x3FFFFu), key = ent >> 18;
+    const uint32_t t_idx = tl.start / tile_pos;  // tile index inside the stream (its tiles are consecutive)
+    const uint32_t max_back = (MAX_D_VALUE - 1) / tile_pos + 1;
+    for (uint32_t back = 1; back <= max_back && back <= t_idx; back++) {
         const uint32_t sv = summary[(uint64_t)(t - back) * (1u << HASH_BITS) + key];
         if (sv != 0) {
-            const uint32_t r = tl.start - back * TILE_POS + (sv & 0xFFFFu) - 1;
-            if (p - r <= MAX_D_VALUE) prev[tl.pos_base + p] = link_make(p - r, sv >> 16);   // (the chain kernel left 0 here)
+            const uint32_t r = tl.start - back * tile_pos + (sv & 0x3FFFFu) - 1;
+            if (p - r <= MAX_D_VALUE) prev[tl.pos_base + p] = link_make(p - r, sv >> 18);   // (the chain kernel left 0 here)
             break;
         }
     }
@@ -731,18 +742,18 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const uint8_t *__restrict
 
 // ------------------------------------------------------------------------------------ launchers
 
-void launch_enc_chain(const uint8_t *src, const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, uint32_t *prev, uint32_t *summary,
+void launch_enc_chain(const uint8_t *src, const EncTile *tiles, uint32_t n_tiles, uint32_t tile_pos, uint32_t *prev, uint32_t *summary,
                       uint32_t *flist, uint32_t *fcount, uint32_t *redo, bool force_redo, hipStream_t st) {
     if (!n_tiles) return;
-    hipLaunchKernelGGL(enc_chain_kernel, dim3(n_tiles), dim3(128), 0, st, src, streams, tiles, n_tiles, prev, summary, flist, fcount, redo,
+    hipLaunchKernelGGL(enc_chain_kernel, dim3(n_tiles), dim3(64 * CH_WAVES), 0, st, src, tiles, n_tiles, tile_pos, prev, summary, flist, fcount, redo,
                        force_redo ? 1u : 0u);
-    hipLaunchKernelGGL(enc_chain_ballot_kernel, dim3(n_tiles), dim3(64), 0, st, src, streams, tiles, n_tiles, prev, summary, flist, fcount, redo);
+    hipLaunchKernelGGL(enc_chain_ballot_kernel, dim3(n_tiles), dim3(64), 0, st, src, tiles, n_tiles, tile_pos, prev, summary, flist, fcount, redo);
 }
 
-void launch_enc_link(const EncStream *streams, const EncTile *tiles, uint32_t n_tiles, uint32_t *prev, const uint32_t *summary,
+void launch_enc_link(const EncTile *tiles, uint32_t n_tiles, uint32_t tile_pos, uint32_t *prev, const uint32_t *summary,
                      const uint32_t *flist, const uint32_t *fcount, hipStream_t st) {
     if (!n_tiles) return;
-    hipLaunchKernelGGL(enc_link_kernel, dim3(((n_tiles + 63) / 64) * 64 * ((1u << HASH_BITS) / 256)), dim3(256), 0, st, streams, tiles, n_tiles, prev, summary, flist,
+    hipLaunchKernelGGL(enc_link_kernel, dim3(((n_tiles + 63) / 64) * 64 * ((1u << HASH_BITS) / 256)), dim3(256), 0, st, tiles, n_tiles, tile_pos, prev, summary, flist,
                        fcount);
 }
 

@@ -69,7 +69,7 @@ def test_candidate_stage_matches_oracle(diag_ctx, oracle, snappy_raw):
         prev, rec = gpu_candidates(diag_ctx, raw)
         want = oracle.table_rows(raw)
         n = len(raw) - 3
-        # prev[i] = newest entry of the row, as long as it lies within the 5-tile link horizon (beyond the match window)
+        # prev[i] = newest entry of the row, as long as it lies within the match window (links across chain tiles stop there)
         near = (want[:, 0] != 0xFFFFFFFF) & (np.arange(n, dtype=np.int64) - want[:, 0].astype(np.int64) <= 262139)
         assert (prev[near] == want[near, 0]).all(), name
         assert (prev[~near] == -1).all(), name   # nothing, or nothing within the window
