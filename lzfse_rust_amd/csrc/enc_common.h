@@ -12,6 +12,9 @@ constexpr uint32_t TILE_POS = 65472;        // positions per candidate tile (enc
 constexpr uint32_t CH_TILE_MAX_MULT = 4;
 // (at least ~1 024 tiles where the call has them: two workgroups of eight waves per CU, two rounds; `count(m)` = chain tiles of the call at m)
 template <class F> __host__ inline uint32_t chain_tile_mult(F count, int forced) {
+#ifdef LZMI_CH_MULT
+    forced = LZMI_CH_MULT;   // (experiment switch, experiments/README.md)
+#endif
     if (forced == 1 || forced == 2 || forced == 4) return (uint32_t)forced;
     for (uint32_t m = CH_TILE_MAX_MULT; m > 1; m >>= 1)
         if (count(m) >= 1024) return m;

@@ -27,8 +27,17 @@ namespace lzmi {
 
 // first-occurrence list of a tile: one slot per bucket + 64 slots where lanes that have nothing to list store
 constexpr uint32_t FL_STRIDE = (1u << HASH_BITS) + 64;
-constexpr int CH_WAVES = 8;                     // waves of a chain workgroup: they take the tile's batches in turn
-constexpr int CH_STEPS = 16;
+#ifndef LZMI_CH_WAVES
+#define LZMI_CH_WAVES 8
+#endif
+#ifndef LZMI_CH_STEPS
+#define LZMI_CH_STEPS 16
+#endif
+#ifndef LZMI_CH_OCC
+#define LZMI_CH_OCC 4
+#endif
+constexpr int CH_WAVES = LZMI_CH_WAVES;         // waves of a chain workgroup: they take the tile's batches in turn
+constexpr int CH_STEPS = LZMI_CH_STEPS;         // steps of 64 positions per batch (16: the batch's values fit 128 registers, four waves per SIMD)
 constexpr uint32_t CH_POS = 64 * CH_STEPS;     // positions per batch
 
 // One workgroup per chain tile (up to 4 x TILE_POS positions: the host picks the length, chain_tile_mult); positions in order,
@@ -46,7 +55,7 @@ constexpr uint32_t CH_POS = 64 * CH_STEPS;     // positions per batch
 // and "turn = b + 1" (an LDS word) does the order of the batches matter, and that section is the 32 exchanges and their return.
 // Everything else -- the loads of the batch after next, the hashes, the records, the first-occurrence list (its slots are
 // reserved per batch with one LDS add) -- runs in eight waves side by side.
-__global__ __launch_bounds__(64 * CH_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void enc_chain_kernel(const uint8_t *__restrict__ src, const EncTile *__restrict__ tiles, uint32_t n_tiles,
+__global__ __launch_bounds__(64 * CH_WAVES) __attribute__((amdgpu_waves_per_eu(LZMI_CH_OCC, LZMI_CH_OCC))) void enc_chain_kernel(const uint8_t *__restrict__ src, const EncTile *__restrict__ tiles, uint32_t n_tiles,
                                                                   uint32_t tile_pos, uint32_t *__restrict__ prev, uint32_t *__restrict__ summary,
                                                                   uint32_t *__restrict__ flist, uint32_t *__restrict__ fcount,
                                                                   uint32_t *__restrict__ redo, uint32_t force_redo) {

@@ -1,5 +1,5 @@
 """One-off randomised parity campaign on a GPU box (not part of the test-suite: the suite's cases are fixed):
-    python scripts/fuzz_gpu.py [ROUNDS] [SEED] [walk|pipe|pipeck|big|ring|stream]  (stream: 3 to 6 inputs of 1.2 .. 12 MiB per round through LzfseWriter with
+    python scripts/fuzz_gpu.py [ROUNDS] [SEED] [walk|pipe|pipeck|big|ring|stream|chain]  (stream: 3 to 6 inputs of 1.2 .. 12 MiB per round through LzfseWriter with
                                                               windows of 1 .. 3 MiB and pieces of any size: the bytes are those of the restated ring
                                                               encoder on the whole input, and the windows did leave early;
                                                               ring: the streams are ALSO encoded with the ring / stream encoder's parse and
@@ -26,7 +26,7 @@ O = oracle_py.Oracle()
 if len(sys.argv) > 3 and sys.argv[3] == "walk":
     ctx = lz.Context(0, diag=True)
     ctx.set_option("diag_walk", 1)
-elif len(sys.argv) > 3 and sys.argv[3] == "pipeck":
+elif len(sys.argv) > 3 and sys.argv[3] in ("pipeck", "chain"):
     ctx = lz.Context(0, diag=True)
 else:
     ctx = lz.Context(0)
@@ -34,6 +34,7 @@ PIPE = len(sys.argv) > 3 and sys.argv[3] in ("pipe", "pipeck")
 BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
 RING = len(sys.argv) > 3 and sys.argv[3] == "ring"
 STREAM = len(sys.argv) > 3 and sys.argv[3] == "stream"
+CHAIN = len(sys.argv) > 3 and sys.argv[3] == "chain"   # the diagnostic build, chain tiles of 1, 2 or 4 x 65 472 positions forced per round (a small call picks 1)
 rng = np.random.default_rng(seed)
 words = [bytes(rng.integers(97, 123, size=int(rng.integers(1, 12)), dtype=np.uint8)) for _ in range(800)]
 TILE = 65472
@@ -70,7 +71,7 @@ def gen(kind, n):
 def length():
     r = rng.random()
     if r < 0.15:
-        return int(TILE * rng.integers(1, 6) + 3 + rng.integers(-3, 70))
+        return int(TILE * rng.integers(1, 14 if CHAIN else 6) + 3 + rng.integers(-3, 70))
     if r < 0.3:
         return int(rng.integers(4097, 20000))
     if RING and r < 0.5:   # around the ring size and the round ends (multiples of 16 KiB beyond 512 KiB)
@@ -117,6 +118,8 @@ for rd in range(rounds):
         stream_round(rd)
         print(f"round {rd}: ok, {time.time() - t0:.0f} s", flush=True)
         continue
+    if CHAIN:
+        ctx.set_option("diag_chain", int(rng.choice([0x10, 0x20, 0x40, 0x40, 0x41])))
     if PIPE:
         ctx.set_option("decode_pipe", int(rng.integers(2, 12)) | (int(rng.integers(0, 2)) << 8))
     if BIG:

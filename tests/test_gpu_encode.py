@@ -58,7 +58,7 @@ def synth_cases():
 def test_candidate_stage_matches_oracle(diag_ctx, oracle, snappy_raw):
     """enc_chain / enc_link / enc_cand vs the oracle: the bucket chain of every position equals the newest entry of the
     history row it sees (history.rs push), and the as-if-visited find_match at every position. The 3 MiB case spans
-    48 chain tiles (links across tiles)."""
+    48 candidate tiles (links across chain tiles of every length)."""
     from oracle_py import seq_masked
     cases = dict(synth_cases())
     for k in ("html", "alice29.txt", "kppkn.gtb", "urls.10K"):
@@ -67,6 +67,15 @@ def test_candidate_stage_matches_oracle(diag_ctx, oracle, snappy_raw):
     for name, raw in cases.items():
         mi, fl = oracle.candidates(raw)
         prev, rec = gpu_candidates(diag_ctx, raw)
+        if name in ("tiles", "text", "noise_mask"):
+            # the same links whatever the length of a chain tile (1, 2 or 4 candidate tiles; the call picks one)
+            for force in (0x10, 0x20, 0x40):
+                diag_ctx.set_option("diag_chain", force)
+                try:
+                    prev_f, rec_f = gpu_candidates(diag_ctx, raw)
+                finally:
+                    diag_ctx.set_option("diag_chain", 0)
+                assert (prev_f == prev).all() and (rec_f == rec).all(), (name, force)
         want = oracle.table_rows(raw)
         n = len(raw) - 3
         # prev[i] = newest entry of the row, as long as it lies within the match window (links across chain tiles stop there)
@@ -251,20 +260,23 @@ def test_encode_few_streams_many_waves_per_stream(ctx, oracle, snappy_raw):
 
 
 def test_encode_tile_and_batch_edges_bit_exact(ctx, diag_ctx, oracle, snappy_raw):
-    """Stream lengths around the edges of the match-finding kernels: the 65 472-position chain tile (last tile of 1, 2,
-    63 positions; exactly full), the 2 048-position batch of the chain kernel (tail batch of 1 / 2 047 positions), the
-    256-position candidate workgroup and the 64-position wave; text, a highly repetitive input and low-entropy noise,
-    through the LDS-exchange chain kernel and through its ballot fallback."""
+    """Stream lengths around the edges of the match-finding kernels: the 65 472-position candidate tile and the chain tiles of
+    1, 2 and 4 of them (last tile of 1, 2, 63 positions; exactly full), the 1 024-position batch of the chain kernel (tail batch
+    of 1 / 1 023 positions; a tile of fewer batches than the workgroup has waves), the 256-position candidate workgroup and the
+    64-position wave; text, a highly repetitive input and low-entropy noise, through the LDS-exchange chain kernel and through
+    its ballot fallback, with the call's own choice of chain tile and with each length forced (LZFSE_MI_OPT_DIAG_CHAIN)."""
     from oracle_py import seq_masked
     tile = 65472
     text = (snappy_raw["alice29.txt"] + snappy_raw["lcet10.txt"]) * 2
-    rep = (snappy_raw["html"][:7000] * 40)
-    noise = seq_masked(5, 0x07070707, 300000)
+    rep = (snappy_raw["html"][:7000] * 170)
+    noise = seq_masked(5, 0x07070707, 1190000)
     lens = [tile + 3, tile + 4, tile + 5, tile + 3 + 63, tile + 3 + 64, tile + 3 + 65, 2 * tile + 2, 2 * tile + 3, 2 * tile + 4,
-            tile + 3 + 2047, tile + 3 + 2048, tile + 3 + 2049, tile + 3 + 255, tile + 3 + 256, tile + 3 + 257, 3 * tile + 3 + 1]
-    raws = [src[:n] for src in (text, rep, noise) for n in lens]
+            tile + 3 + 2047, tile + 3 + 2048, tile + 3 + 2049, tile + 3 + 255, tile + 3 + 256, tile + 3 + 257, 3 * tile + 3 + 1,
+            tile + 3 + 1023, tile + 3 + 1024, tile + 3 + 1025, 4 * tile + 2, 4 * tile + 3, 4 * tile + 4, 4 * tile + 3 + 64,
+            8 * tile + 3, 8 * tile + 4, 12 * tile + 3 + 7 * 1024 + 5, 4100, 4097 + 1024, 8 * 1024 + 3, 8 * 1024 + 4]
+    raws = [src[:n] for src in (text, rep, noise) for n in lens if n <= len(src)]
     want = [oracle.encode(r) for r in raws]
-    for c, force in ((ctx, None), (diag_ctx, 1)):
+    for c, force in ((ctx, None), (diag_ctx, 1), (diag_ctx, 0x10), (diag_ctx, 0x20), (diag_ctx, 0x40), (diag_ctx, 0x41), (diag_ctx, 0x21)):
         if force is not None:
             c.set_option("diag_chain", force)
         try:
