@@ -235,7 +235,7 @@ class LzfseEncoder:
     def encode_bytes(self, src, dst):
         """Appends the LZFSE stream of `src` to bytearray `dst`; returns bytes appended."""
         if type(dst) is bytearray:
-            st, n = _into_tail(self._ctx, self._ctx._lib.lzfse_mi_encode, src, dst, self._ctx._lib.lzfse_mi_encode_bound(len(src)))
+            st, n = _into_tail(self._ctx, self._ctx._lib.lzfse_mi_encode, src, dst, self._ctx._lib.lzfse_mi_encode_bound(int(_as_u8(src).size)))
             _check(st)
             return n
         outs, st = self._ctx.encode_batch([src])
@@ -279,13 +279,16 @@ class LzfseRingEncoder:
     encoder's (ring_encoder.rs:71-73); writer(inner) / writer_bytes(vec) give the Write front ends. The streams are the
     ring front end's (encode/frontend_ring.rs), not the slice encoder's bytes."""
 
-    def __init__(self, device=0, context=None, read_size=1 << 20, window=0):
+    def __init__(self, device=0, context=None, read_size=1 << 20, window=0, zero_copy=True):
         self._ctx = context or Context(device)
         self._read_size = read_size
         self._window = window    # input bytes per device call (0 = 64 MiB)
+        # True: the sink gets a view of the library's buffer that is released after the call (a sink that keeps one fails loudly
+        # later); False: bytes it may keep, e.g. `pieces.append` (one copy more)
+        self._zero_copy = zero_copy
 
     def encode(self, reader, writer):
-        w = LzfseWriter(self._ctx, writer, self._window)
+        w = LzfseWriter(self._ctx, writer, self._window, self._zero_copy)
         n_in = 0
         readinto = getattr(reader, "readinto", None)
         if readinto is not None:
@@ -315,7 +318,7 @@ class LzfseRingEncoder:
 
     def writer(self, inner):
         """LzfseRingEncoder::writer (ring_encoder.rs:79-84)"""
-        return LzfseWriter(self._ctx, inner, self._window)
+        return LzfseWriter(self._ctx, inner, self._window, self._zero_copy)
 
     def writer_bytes(self, vec):
         """LzfseRingEncoder::writer_bytes (ring_encoder.rs:91-96): `vec` (a bytearray) is appended to"""
@@ -328,11 +331,12 @@ class LzfseWriter:
     no later input can change leave during write(), the rest at finalize(). Dropping a writer without finalize() loses
     the end of the stream, as in the reference (writer.rs:36-38)."""
 
-    def __init__(self, context, inner, window=0):
+    def __init__(self, context, inner, window=0, zero_copy=True):
         self._ctx, self._inner = context, inner
         self._lib = context._lib
         self._h = C.c_void_p()
         self._failure = []
+        self._zero_copy = zero_copy
 
         def _write(_user, p, n):
             try:
@@ -340,6 +344,8 @@ class LzfseWriter:
                 # fails loudly later instead of reading a reused buffer; file objects, hashers, `bytearray +=` copy what they need)
                 if not n:
                     self._sink(b"")
+                elif not self._zero_copy:
+                    self._sink(C.string_at(p, n))   # bytes the sink may keep (one copy more; LzfseRingDecoder's zero_copy=False does the same)
                 else:
                     view = memoryview((C.c_uint8 * n).from_address(C.addressof(p.contents)))
                     try:
@@ -578,11 +584,14 @@ def _ctx_array(contexts):
     return arr
 
 
-def encode_chunked(contexts, src, chunk=0):
-    """One large input -> "LZMC" frame of independent LZFSE streams, chunk c on contexts[c mod len(contexts)]."""
+def encode_chunked(contexts, src, chunk=0, cap=None):
+    """One large input -> "LZMC" frame of independent LZFSE streams, chunk c on contexts[c mod len(contexts)]. `cap`: the
+    destination's size (default lzfse_mi_chunked_bound, with which every chunk is encoded straight into the frame; a smaller
+    one that still holds the frame works through private buffers)."""
     lib = contexts[0]._lib
     a = np.frombuffer(src, dtype=np.uint8) if not isinstance(src, np.ndarray) else src
-    cap = lib.lzfse_mi_chunked_bound(a.size, chunk)
+    if cap is None:
+        cap = lib.lzfse_mi_chunked_bound(a.size, chunk)
     out = np.empty(cap, dtype=np.uint8)
     n = C.c_size_t(0)
     _check(lib.lzfse_mi_encode_chunked(_ctx_array(contexts), len(contexts), a.ctypes.data if a.size else None, a.size, chunk,

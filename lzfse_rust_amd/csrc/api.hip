@@ -1112,6 +1112,12 @@ static uint64_t staged_at(const std::vector<CopyJob> &jobs, const std::vector<ui
 #ifndef HOST_DIRECT_OUT
 #define HOST_DIRECT_OUT ((uint64_t)512 << 20)   // (beyond that a second copy of the output in pinned memory is the larger evil)
 #endif
+// ... and all staged outputs of a call together stay below this (round 5): the pinned staging is kept until the context goes, and a batch of
+// 64 streams of 256 MiB would otherwise pin 20 GiB of host memory for good. Outputs beyond the budget travel straight into the caller's
+// buffers, as all of them do when the staging cannot be had at all.
+#ifndef HOST_STAGE_BUDGET
+#define HOST_STAGE_BUDGET ((uint64_t)512 << 20)
+#endif
 
 static int host_batch_one(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, size_t count, const uint8_t *const *srcs,
                           const size_t *lens, uint8_t *const *dsts, const size_t *caps, size_t *out_lens,
@@ -1128,9 +1134,20 @@ static int host_batch_one(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, s
             if ((lens[i] >= HOST_DIRECT_IN) == (big != 0)) { so[i] = in_total; sl[i] = lens[i]; in_total += (lens[i] + 255) & ~(uint64_t)255; }
         if (!big) in_staged = in_total;
     }
+    // which outputs travel by a transfer of their own: by capacity, and whatever would take the staged ones beyond the budget
+    // (encoded streams are packed first: there the budget is applied to what they really hold, below)
+    std::vector<uint8_t> big_out(count);
+    {
+        uint64_t acc = 0;
+        for (size_t i = 0; i < count; i++) {
+            const uint64_t padded = (caps[i] + 255) & ~(uint64_t)255;
+            big_out[i] = caps[i] >= direct_out || (!pack_outputs && acc + padded > HOST_STAGE_BUDGET);
+            if (!big_out[i]) acc += padded;
+        }
+    }
     for (int big = 0; big < 2; big++) {
         for (size_t i = 0; i < count; i++)
-            if ((caps[i] >= direct_out) == (big != 0)) { dof[i] = out_total; dc[i] = caps[i]; out_total += (caps[i] + 255) & ~(uint64_t)255; }
+            if ((big_out[i] != 0) == (big != 0)) { dof[i] = out_total; dc[i] = caps[i]; out_total += (caps[i] + 255) & ~(uint64_t)255; }
         if (!big) out_staged = out_total;
     }
     // (a deferred transfer, see below: this call's device output buffer is the one of the call before last, whose transfer is over)
@@ -1191,8 +1208,7 @@ static int host_batch_one(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, s
     if (!produced) return LZFSE_MI_OK;
     const uint8_t *d_from = (const uint8_t *)dout.p;
     uint64_t staged_span = out_staged;      // the staged outputs lie in [0, staged_span) of the buffer that travels
-    std::vector<uint8_t> big_out(count);    // which outputs travel by a transfer of their own: by capacity (the layout) ...
-    for (size_t i = 0; i < count; i++) big_out[i] = caps[i] >= direct_out;
+    const std::vector<uint8_t> big_layout = big_out;   // (by capacity: the layout)
     if (pack_outputs && fits32 && produced + (produced >> 2) < hi_off) {
         uint64_t pk = 0;
         std::vector<SmallDesc> desc;
@@ -1200,7 +1216,14 @@ static int host_batch_one(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, s
         desc.reserve(count);
         uint64_t pk_staged = 0;
         // ... or, when the outputs are packed anyway (encoded streams: a third of their capacity), by what they really hold
-        for (size_t i = 0; i < count; i++) big_out[i] = out_lens[i] >= direct_out;
+        {
+            uint64_t acc = 0;
+            for (size_t i = 0; i < count; i++) {
+                const uint64_t padded = (out_lens[i] + 15) & ~(uint64_t)15;
+                big_out[i] = out_lens[i] >= direct_out || acc + padded > HOST_STAGE_BUDGET;
+                if (!big_out[i]) acc += padded;
+            }
+        }
         for (int big = 0; big < 2; big++) {   // (staged streams first)
             for (size_t i = 0; i < count; i++) {
                 if ((big_out[i] != 0) != (big != 0)) continue;
@@ -1223,10 +1246,23 @@ static int host_batch_one(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, s
             at = packed;
             staged_span = pk_staged;
         } else {
-            for (size_t i = 0; i < count; i++) big_out[i] = caps[i] >= direct_out;
+            big_out = big_layout;
         }
+    } else if (pack_outputs) {
+        // (encoded streams that are not packed: the staging would hold their capacities' span)
+        uint64_t acc = 0;
+        for (size_t i = 0; i < count; i++)
+            if (!big_out[i]) {
+                const uint64_t padded = (caps[i] + 255) & ~(uint64_t)255;
+                if (acc + padded > HOST_STAGE_BUDGET) { staged_span = std::min(staged_span, dof[i]); for (size_t k = i; k < count; k++) if (!big_out[k]) big_out[k] = 1; break; }
+                acc += padded;
+            }
     }
-    if (!c->h_out.ensure(staged_span + 256)) return LZFSE_MI_IO;
+    if (!c->h_out.ensure(staged_span + 256)) {
+        // no pinned staging to be had: every output travels straight into the caller's buffer
+        for (size_t i = 0; i < count; i++) big_out[i] = 1;
+        staged_span = 0;
+    }
     // ---- granules again: every DMA is queued, and a granule is copied to its destinations as soon as it has arrived ----
     jobs.clear(); pre.clear(); stage.clear();
     uint64_t n_out = 0;
@@ -1260,13 +1296,23 @@ static int host_batch_one(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, s
         if (c->xfer_stream && c->defer_ev[ob]) {
             const size_t tail = out_lens[0] < ((size_t)1 << 18) ? out_lens[0] : (size_t)1 << 18, body = out_lens[0] - tail;
             HIP_TRY(hipMemcpyAsync(dsts[0] + body, d_from + at[0] + body, tail, hipMemcpyDeviceToHost, c->stream));
+            bool ok = true;
             if (body) {
                 HIP_TRY(hipMemcpyAsync(dsts[0], d_from + at[0], body, hipMemcpyDeviceToHost, c->xfer_stream));
-                HIP_TRY(hipEventRecord(c->defer_ev[ob], c->xfer_stream));
-                c->defer_pending[ob] = true;
-                c->defer_last = c->defer_ev[ob];
+                // (from here on a transfer into the caller's buffer is in flight: whatever fails, it is waited for before this
+                // call returns an error -- the caller frees or reuses that buffer on one)
+                if (hipEventRecord(c->defer_ev[ob], c->xfer_stream) == hipSuccess) {
+                    c->defer_pending[ob] = true;
+                    c->defer_last = c->defer_ev[ob];
+                } else ok = false;
             }
-            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (hipStreamSynchronize(c->stream) != hipSuccess) ok = false;
+            if (!ok) {
+                (void)hipStreamSynchronize(c->xfer_stream);
+                c->defer_pending[ob] = false;
+                c->defer_last = nullptr;
+                return LZFSE_MI_IO;
+            }
             return LZFSE_MI_OK;
         }
     }

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -62,6 +63,19 @@ int parse(const uint8_t *src, size_t n, Frame &f) {
     return LZFSE_MI_OK;
 }
 
+// Runs work(1) .. work(n - 1) on threads of their own and work(0) here; a thread that cannot be had has its share done here too.
+// Nothing is thrown across the C ABI: the callers catch what is left (allocation failures of their vectors).
+template <class F> void fan_out(int n, F &work) {
+    std::vector<std::thread> th;
+    std::vector<int> here;
+    for (int k = 1; k < n; k++) {
+        try { th.emplace_back([&work, k] { work(k); }); } catch (...) { here.push_back(k); }
+    }
+    work(0);
+    for (int k : here) work(k);
+    for (auto &t : th) t.join();
+}
+
 }  // namespace
 
 extern "C" {
@@ -83,60 +97,69 @@ int lzfse_mi_encode_chunked(lzfse_mi_ctx *const *ctxs, int n_ctx, const uint8_t 
     if (n_chunks > 0xFFFFFFFFu) return LZFSE_MI_UNSUPPORTED;
     const size_t head = kFixed + n_chunks * 8;
     if (cap < head) return LZFSE_MI_BUFFER_OVERFLOW;
-    // every context encodes its chunks (c mod n_ctx) into private buffers; the frame is assembled afterwards
-    std::vector<std::vector<uint8_t>> enc(n_chunks);
-    std::vector<size_t> enc_len(n_chunks, 0);
-    std::vector<int> rc((size_t)n_ctx, LZFSE_MI_OK);
-    auto work = [&](int k) {
-        std::vector<const uint8_t *> srcs;
-        std::vector<size_t> lens, caps, outs;
-        std::vector<uint8_t *> dsts;
-        std::vector<size_t> ids;
-        for (size_t c = (size_t)k; c < n_chunks; c += (size_t)n_ctx) {
-            const size_t off = c * chunk, len = std::min(chunk, n - off);
-            enc[c].resize(lzfse_mi_encode_bound(len));
-            srcs.push_back(src + off); lens.push_back(len);
-            dsts.push_back(enc[c].data()); caps.push_back(enc[c].size());
-            ids.push_back(c);
+    try {
+        // Every context encodes its chunks (c mod n_ctx). Round 5: when the destination has the room lzfse_mi_chunked_bound asks
+        // for, a chunk is encoded INTO the frame, at the place it would have if every stream before it filled its bound, and the
+        // streams are then moved down to lie back to back (one pass over the compressed bytes, in place). Round 4 encoded every
+        // chunk into a zero-filled vector of its own (1.75 x the input touched before a byte was encoded) and copied it over.
+        // A smaller destination gets private buffers, uninitialised, as a caller that sized `dst` by guesswork would need.
+        const size_t slot = lzfse_mi_encode_bound(std::min(chunk, n));
+        const bool in_frame = n_chunks == 0 || (cap - head) / (n_chunks ? n_chunks : 1) >= slot;
+        std::vector<std::unique_ptr<uint8_t[]>> priv(in_frame ? 0 : n_chunks);
+        std::vector<size_t> enc_len(n_chunks, 0);
+        std::vector<int> rc((size_t)n_ctx, LZFSE_MI_OK);
+        auto work = [&](int k) {
+            try {
+                std::vector<const uint8_t *> srcs;
+                std::vector<size_t> lens, caps, outs;
+                std::vector<uint8_t *> dsts;
+                std::vector<size_t> ids;
+                for (size_t c = (size_t)k; c < n_chunks; c += (size_t)n_ctx) {
+                    const size_t off = c * chunk, len = std::min(chunk, n - off);
+                    const size_t bound = lzfse_mi_encode_bound(len);
+                    uint8_t *to = in_frame ? dst + head + c * slot : (priv[c].reset(new uint8_t[bound]), priv[c].get());
+                    srcs.push_back(src + off); lens.push_back(len);
+                    dsts.push_back(to); caps.push_back(bound);
+                    ids.push_back(c);
+                }
+                if (ids.empty()) return;
+                outs.assign(ids.size(), 0);
+                std::vector<int> st(ids.size(), 0);
+                int r = lzfse_mi_encode_batch(ctxs[k], ids.size(), srcs.data(), lens.data(), dsts.data(), caps.data(), outs.data(), st.data());
+                for (size_t j = 0; j < ids.size() && !r; j++) {
+                    if (st[j]) r = st[j];
+                    enc_len[ids[j]] = outs[j];
+                }
+                rc[(size_t)k] = r;
+            } catch (...) { rc[(size_t)k] = LZFSE_MI_IO; }
+        };
+        fan_out(n_ctx, work);
+        for (int r : rc)
+            if (r) return r;
+        size_t total = head;
+        for (size_t c = 0; c < n_chunks; c++) {
+            if (enc_len[c] > 0xFFFFFFFFu) return LZFSE_MI_UNSUPPORTED;
+            total += enc_len[c];
         }
-        if (ids.empty()) return;
-        outs.assign(ids.size(), 0);
-        std::vector<int> st(ids.size(), 0);
-        int r = lzfse_mi_encode_batch(ctxs[k], ids.size(), srcs.data(), lens.data(), dsts.data(), caps.data(), outs.data(), st.data());
-        for (size_t j = 0; j < ids.size() && !r; j++) {
-            if (st[j]) r = st[j];
-            enc_len[ids[j]] = outs[j];
+        if (total > cap) return LZFSE_MI_BUFFER_OVERFLOW;
+        put32(dst, kMagic);
+        const uint16_t version = 1, flags = 0;
+        std::memcpy(dst + 4, &version, 2);
+        std::memcpy(dst + 6, &flags, 2);
+        put32(dst + 8, (uint32_t)chunk);
+        put32(dst + 12, (uint32_t)n_chunks);
+        put64(dst + 16, (uint64_t)n);
+        uint8_t *p = dst + head;
+        for (size_t c = 0; c < n_chunks; c++) {
+            put32(dst + kFixed + 8 * c, (uint32_t)std::min(chunk, n - c * chunk));
+            put32(dst + kFixed + 8 * c + 4, (uint32_t)enc_len[c]);
+            const uint8_t *from = in_frame ? dst + head + c * slot : priv[c].get();
+            if (from != p) std::memmove(p, from, enc_len[c]);   // (in the frame: downwards, stream by stream, never over one not yet moved)
+            p += enc_len[c];
         }
-        rc[(size_t)k] = r;
-    };
-    std::vector<std::thread> th;
-    for (int k = 1; k < n_ctx; k++) th.emplace_back(work, k);
-    work(0);
-    for (auto &t : th) t.join();
-    for (int r : rc)
-        if (r) return r;
-    size_t total = head;
-    for (size_t c = 0; c < n_chunks; c++) {
-        if (enc_len[c] > 0xFFFFFFFFu) return LZFSE_MI_UNSUPPORTED;
-        total += enc_len[c];
-    }
-    if (total > cap) return LZFSE_MI_BUFFER_OVERFLOW;
-    put32(dst, kMagic);
-    const uint16_t version = 1, flags = 0;
-    std::memcpy(dst + 4, &version, 2);
-    std::memcpy(dst + 6, &flags, 2);
-    put32(dst + 8, (uint32_t)chunk);
-    put32(dst + 12, (uint32_t)n_chunks);
-    put64(dst + 16, (uint64_t)n);
-    uint8_t *p = dst + head;
-    for (size_t c = 0; c < n_chunks; c++) {
-        put32(dst + kFixed + 8 * c, (uint32_t)std::min(chunk, n - c * chunk));
-        put32(dst + kFixed + 8 * c + 4, (uint32_t)enc_len[c]);
-        std::memcpy(p, enc[c].data(), enc_len[c]);
-        p += enc_len[c];
-    }
-    *out_len = total;
-    return LZFSE_MI_OK;
+        *out_len = total;
+        return LZFSE_MI_OK;
+    } catch (...) { return LZFSE_MI_IO; }
 }
 
 int lzfse_mi_decode_chunked_size(const uint8_t *src, size_t n, uint64_t *raw_len) {
@@ -157,6 +180,7 @@ int lzfse_mi_decode_chunked(lzfse_mi_ctx *const *ctxs, int n_ctx, const uint8_t 
     int r = parse(src, n, f);
     if (r) return r;
     if (f.raw_total > cap) return LZFSE_MI_BUFFER_OVERFLOW;
+    try {
     std::vector<size_t> enc_off(f.n_chunks), raw_off(f.n_chunks);
     size_t eo = 0, ro = 0;
     for (uint32_t c = 0; c < f.n_chunks; c++) {
@@ -166,6 +190,7 @@ int lzfse_mi_decode_chunked(lzfse_mi_ctx *const *ctxs, int n_ctx, const uint8_t 
     }
     std::vector<int> rc((size_t)n_ctx, LZFSE_MI_OK);
     auto work = [&](int k) {
+        try {
         std::vector<const uint8_t *> srcs;
         std::vector<size_t> lens, caps, outs;
         std::vector<uint8_t *> dsts;
@@ -182,15 +207,14 @@ int lzfse_mi_decode_chunked(lzfse_mi_ctx *const *ctxs, int n_ctx, const uint8_t 
             else if (outs[j] != caps[j]) e = LZFSE_MI_BAD_ARGUMENT;   // the chunk table promised another size
         }
         rc[(size_t)k] = e;
+        } catch (...) { rc[(size_t)k] = LZFSE_MI_IO; }
     };
-    std::vector<std::thread> th;
-    for (int k = 1; k < n_ctx; k++) th.emplace_back(work, k);
-    work(0);
-    for (auto &t : th) t.join();
+    fan_out(n_ctx, work);
     for (int e : rc)
         if (e) return e;
     *out_len = (size_t)f.raw_total;
     return LZFSE_MI_OK;
+    } catch (...) { return LZFSE_MI_IO; }
 }
 
 }  // extern "C"

@@ -765,7 +765,9 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         statuses[i] = LZFSE_MI_OK;
         uint64_t n = src_len[i];
         if (n <= VN_CUTOFF) { statuses[i] = LZFSE_MI_UNSUPPORTED; continue; }  // host-side size classes (frontend_bytes.rs:63-77)
-        if (n > 0x7FFFFFFFull) { statuses[i] = LZFSE_MI_UNSUPPORTED; continue; }  // reposition path (:348-375) not built
+        // (a slice of up to BLOCK_GUIDE + 3 = 0x8000_0002 bytes is ONE block of the reference's front end, frontend_bytes.rs:169-178;
+        // beyond that it repositions, :348-375, which is not built)
+        if (n > 0x80000002ull) { statuses[i] = LZFSE_MI_UNSUPPORTED; continue; }
         EncStream e{};
         e.src_off = src_off[i]; e.dst_off = dst_off[i]; e.dst_cap = dst_cap[i];
         e.n = (uint32_t)n; e.user_index = i; e.ring = ring;

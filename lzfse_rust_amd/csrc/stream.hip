@@ -217,8 +217,12 @@ int ds_complete(lzfse_mi_dstream *s, const uint8_t **ptr, size_t *len, void **ev
     s->pending = false;
     *ev = s->pend_ev;     // (the next window's helper writes the field again)
     s->pend_ev = nullptr;
-    if (s->pend_st) return s->pend_st;
-    if (s->pend_got < s->pend_nh) return LZFSE_MI_IO;
+    if (s->pend_st || s->pend_got < s->pend_nh) {
+        // (the caller of a failed window never looks at its bytes, and may free or reuse their buffer: nothing may still be travelling into it)
+        if (*ev) (void)hipEventSynchronize((hipEvent_t)*ev);
+        *ev = nullptr;
+        return s->pend_st ? s->pend_st : LZFSE_MI_IO;
+    }
     const uint8_t *base = s->adst[s->pend_buf].p;
     const size_t got = s->pend_got;
     *ptr = base + s->pend_nh; *len = got - s->pend_nh;
@@ -247,6 +251,13 @@ int ds_launch(lzfse_mi_dstream *s, size_t span, uint64_t raw) {
     const size_t nh = s->hist.size(), head = nh ? nh + 8 : 0, src_len = head + span + 4;
     const uint64_t cap64 = nh + raw;
     if (cap64 > ((uint64_t)1 << 30) || !s->box) return -1;
+    {
+        // (the background path runs on a context of the library's own: when that cannot be had -- no memory for a second set of
+        // scratch -- the window is decoded in the call, on the caller's context, as before round 4)
+        StreamBox *b = s->box.get();
+        std::lock_guard<std::mutex> g(b->m);
+        if (!b->dead && !box_peer(*b)) return -1;
+    }
     if (!s->worker) {
         try { s->worker = new (std::nothrow) LaneWorker(); } catch (...) { s->worker = nullptr; }
         if (!s->worker) return -1;
@@ -576,7 +587,15 @@ int es_launch(lzfse_mi_estream *s) {
     for (int k = 0; k < 5; k++) w.st[k] = s->st[k];
     w.skip = s->skip;
     s->pend_n = n; s->pend_len = 0; s->pend_st = 0;
-    auto job = [s, n, cap] {
+    // (no second context to be had -- the peer is a full set of device scratch -- and the box alive: the window runs in this call on
+    // the caller's own context, as before round 4, instead of failing the stream)
+    bool own = false;
+    if (StreamBox *b = s->box.get()) {
+        std::lock_guard<std::mutex> g(b->m);
+        own = !b->dead && !box_peer(*b) && s->ctx;
+    }
+    auto job = [s, n, cap, own] {
+        if (own) { s->pend_st = es_call(s->ctx, s, n, &s->pend_w, cap, &s->pend_len); return; }
         StreamBox *b = s->box.get();
         if (!b) { s->pend_st = LZFSE_MI_IO; return; }
         std::lock_guard<std::mutex> g(b->m);
@@ -584,8 +603,8 @@ int es_launch(lzfse_mi_estream *s) {
         s->pend_st = c ? es_call(c, s, n, &s->pend_w, cap, &s->pend_len) : (b->dead ? LZFSE_MI_BAD_ARGUMENT : LZFSE_MI_IO);
     };
     s->pending = true;
-    if (s->worker) s->worker->submit(job);
-    else job();   // (no thread to be had: the window runs here)
+    if (s->worker && !own) s->worker->submit(job);
+    else job();   // (no thread to be had, or the caller's own context: the window runs here)
     return 0;
 }
 

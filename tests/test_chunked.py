@@ -55,6 +55,13 @@ def test_chunked_round_trip_and_chunk_streams_are_plain_lzfse(oracle, snappy_raw
     assert pos == len(frame)
     assert m.decode_chunked(ctxs, frame).tobytes() == data
     assert m.decode_chunked(ctxs[:1], frame).tobytes() == data
+    # a destination below lzfse_mi_chunked_bound that still holds the frame (chunks encoded into private buffers instead of
+    # into the frame): the same frame; one that does not hold it: BUFFER_OVERFLOW (6)
+    assert m.encode_chunked(ctxs, data, chunk, cap=len(frame) + 100).tobytes() == frame
+    assert m.encode_chunked(ctxs, data, chunk, cap=len(frame)).tobytes() == frame
+    with pytest.raises(m.LzfseError) as ei:
+        m.encode_chunked(ctxs, data, chunk, cap=len(frame) - 1)
+    assert ei.value.status == 6
     # default chunk size, empty input, damaged chunk
     assert m.decode_chunked(ctxs, m.encode_chunked(ctxs, data)).tobytes() == data
     assert m.decode_chunked(ctxs, m.encode_chunked(ctxs, b"")).tobytes() == b""

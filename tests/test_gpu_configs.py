@@ -86,10 +86,11 @@ def test_config5_chunks_4mib_each_equals_oracle(ctx, oracle, text64):
 
 
 def test_encode_rejects_streams_beyond_i32(ctx):
-    """E20: inputs > 0x7FFF_FFFF bytes need the reference's reposition path (frontend_bytes.rs:348-375), which is not
-    built: the stream is refused with LZFSE_MI_UNSUPPORTED before anything is read (lengths are host arrays)."""
+    """E20: inputs > 0x8000_0002 bytes (BLOCK_GUIDE + 3: more than one block of the reference's slice front end) need its
+    reposition path (frontend_bytes.rs:348-375), which is not built: the stream is refused with LZFSE_MI_UNSUPPORTED before
+    anything is read (lengths are host arrays). Up to that size a slice is one block: tests/test_gpu_big.py."""
     off = np.zeros(2, dtype=np.uint64)
-    ln = np.array([0x8000_0000, 0xFFFF_FFFF_0], dtype=np.uint64)
+    ln = np.array([0x8000_0003, 0xFFFF_FFFF_0], dtype=np.uint64)
     cap = np.array([4096, 4096], dtype=np.uint64)
     out_len, st = ctx.encode_batch_device(0, off, ln, 0, off, cap)   # no byte of a refused stream is touched
     assert list(st) == [9, 9] and list(out_len) == [0, 0]

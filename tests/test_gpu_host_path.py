@@ -108,3 +108,31 @@ def test_two_contexts_in_two_threads(oracle, snappy_raw):
     for t in ts:
         t.join()
     assert not errors, errors
+
+
+def test_host_batch_beyond_the_staging_budget(ctx, snappy_raw):
+    """Outputs below 512 MiB go through the library's pinned staging, which is kept until the context goes: a call stages at most
+    512 MiB of them (HOST_STAGE_BUDGET, api.hip) and the rest travel straight into the caller's buffers. 1.4 GiB of 4 .. 64 MiB
+    streams either way: the bytes are the same as those of small calls (the encoder's own bytes are checked against the oracle elsewhere)."""
+    import os
+    if os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") < (24 << 30):
+        pytest.skip("needs ~6 GiB of host memory")
+    text = (snappy_raw["lcet10.txt"] + snappy_raw["urls.10K"] + snappy_raw["kppkn.gtb"]) * 60     # 79 MB
+    rng = np.random.default_rng(11)
+    sizes = [64 << 20] * 10 + [int(x) for x in rng.integers(4 << 20, 33 << 20, size=40)]
+    rng.shuffle(sizes)
+    raws = [text[(k * 999983) % 1000000:][:n] for k, n in enumerate(sizes)]
+    assert sum(map(len, raws)) > (1400 << 20)
+    encs, st = ctx.encode_batch(raws)
+    assert all(e == 0 for e in st)
+    ref = {}
+    for k in (0, 7, 23, 49):       # the same streams from calls of their own
+        one, st1 = ctx.encode_batch([raws[k]])
+        assert st1[0] == 0 and one[0].tobytes() == encs[k].tobytes(), k
+        ref[k] = one[0].tobytes()
+    streams = [e.tobytes() for e in encs]
+    del encs
+    outs, st = ctx.decode_batch(streams)
+    assert all(e == 0 for e in st)
+    for k, (o, r) in enumerate(zip(outs, raws)):
+        assert len(o) == len(r) and o.tobytes() == r, k

@@ -347,6 +347,40 @@ def test_writer_pieces_are_views_released_after_the_call(ctx, oracle, snappy_raw
     assert out.getvalue() == raw
 
 
+def test_encoder_pieces_and_typed_sources(ctx, oracle, snappy_raw):
+    """LzfseWriter hands its sink views that die with the call (as the decoder does); zero_copy=False hands out bytes a sink may
+    keep (`pieces.append`). encode_bytes sizes its destination by the BYTES of a typed source, not by its element count."""
+    import lzfse_rust_amd as m
+    raw = snappy_raw["alice29.txt"] * 9
+    want = oracle.ring_encode(raw)
+    class Keep:
+        def __init__(self):
+            self.pieces = []
+
+        def write(self, b):
+            self.pieces.append(b)
+
+    k = Keep()
+    pieces = k.pieces
+    w = m.LzfseRingEncoder(context=ctx, window=1 << 20, zero_copy=False).writer(k)
+    for o in range(0, len(raw), 300000):
+        w.write(raw[o:o + 300000])
+    w.finalize()
+    assert all(isinstance(p, bytes) for p in pieces) and b"".join(pieces) == want
+    k = Keep()
+    kept = k.pieces
+    w = m.LzfseRingEncoder(context=ctx, window=1 << 20).writer(k)
+    w.write(raw)
+    w.finalize()
+    assert kept and all(isinstance(p, memoryview) for p in kept)
+    with pytest.raises(ValueError):
+        bytes(kept[0])
+    typed = np.frombuffer(snappy_raw["html"][:102400], dtype=np.uint32)          # 25 600 elements, 102 400 bytes
+    out = bytearray(b"head")
+    n = m.LzfseEncoder(context=ctx).encode_bytes(typed, out)
+    assert bytes(out[4:]) == oracle.encode(snappy_raw["html"][:102400]) and n == len(out) - 4
+
+
 def test_windows_in_the_background(oracle, snappy_raw):
     """Round 4: a stream object hands a full window to a helper thread and returns (stream.hip). Two stream objects of one context
     with windows in flight at the same time (a decoder whose sink is an encoder: transcoding, window sizes that do not line
