@@ -585,6 +585,10 @@ def file_rates(ctx, torch, dev, lz, raw, R, samples=5):
     enc_len, est = ctx.encode_batch_device(B.d_raw.data_ptr(), B.raw_off, B.raw_len, B.d_enc.data_ptr(), B.enc_off, B.enc_cap)
     assert (est == 0).all()
     te, td = [], []
+    import gc
+    gc_was = gc.isenabled() and not os.environ.get("BENCH_KEEP_GC")
+    if gc_was:
+        gc.disable()       # (as timeit does: a cyclic collection inside a 1 ms sample is the interpreter's time, not the call's)
     for _ in range(samples + 2):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -597,6 +601,8 @@ def file_rates(ctx, torch, dev, lz, raw, R, samples=5):
         assert (dst_ == 0).all()
         te.append(t1 - t0)
         td.append(t2 - t1)
+    if gc_was:
+        gc.enable()
     assert torch.equal(B.d_dec[:B.raw_padded], B.d_raw[:B.raw_padded])
     return B, enc_len, np.array(te[2:]), np.array(td[2:])
 
@@ -685,7 +691,7 @@ def per_file_table(ctx, torch, dev, names, fixture_streams, R):
     rows = []
     for name, r in zip(names, raws_np):
         raw = r.tobytes()
-        B, enc_len, te, td = file_rates(ctx, torch, dev, lz, raw, R)
+        B, enc_len, te, td = file_rates(ctx, torch, dev, lz, raw, R, samples=20)
         want = o.encode(raw)
         got = B.d_enc[int(B.enc_off[0]):int(B.enc_off[0]) + int(enc_len[0])].cpu().numpy().tobytes()
         assert got == want, name   # bit-exact vs the CPU port
@@ -708,13 +714,16 @@ def per_file_table(ctx, torch, dev, names, fixture_streams, R):
             "file": name, "raw_bytes": len(raw), "compressed_bytes": len(want), "copies": R,
             "gpu_encode_MiBps": round(len(raw) * R / te.mean() / mib, 1), "gpu_encode_sd_pct": round(100 * te.std() / te.mean(), 1),
             "gpu_decode_MiBps": round(len(raw) * R / td.mean() / mib, 1), "gpu_decode_sd_pct": round(100 * td.std() / td.mean(), 1),
-            "gpu_encode_GBps": round(len(raw) * R / te.mean() / 1e9, 2), "gpu_decode_GBps": round(len(raw) * R / td.mean() / 1e9, 2),
+            "gpu_encode_GBps": round(len(raw) * R / float(np.median(te)) / 1e9, 2), "gpu_decode_GBps": round(len(raw) * R / float(np.median(td)) / 1e9, 2),
+            "gpu_encode_ms_median_max": [round(float(np.median(te)) * 1e3, 3), round(float(te.max()) * 1e3, 3)],
+            "gpu_decode_ms_median_max": [round(float(np.median(td)) * 1e3, 3), round(float(td.max()) * 1e3, 3)],
             "cpu_port_encode_MiBps": round(len(raw) * k / ce / mib, 1), "cpu_port_decode_MiBps": round(len(raw) * j / cd / mib, 1),
             "readme_i5_2500k_decode_MiBps": pub[0] if pub else None, "readme_i5_2500k_encode_MiBps": pub[1] if pub else None,
         })
     print(json.dumps({"table": "snappy per file (BASELINE config 4)", "copies_per_batch": R, "protocol":
-                      "each file alone as R independent streams resident in HBM, 2 warm-up + 5 samples, mean and sd; wall time of "
-                      "the batch call incl. host orchestration; outputs bit-exact vs the CPU port; CPU port = oracle/, 1 thread",
+                      "each file alone as R independent streams resident in HBM, 2 warm-up + 20 samples (Criterion's count); wall time of "
+                      "the batch call incl. host orchestration; *_MiBps and *_sd_pct from the mean, *_GBps from the MEDIAN, "
+                      "*_ms_median_max = [median, slowest sample]; outputs bit-exact vs the CPU port; CPU port = oracle/, 1 thread",
                       "rows": rows}), flush=True)
 
 

@@ -122,6 +122,8 @@ struct lzfse_mi_ctx {
     int diag_lz_jump = -1, diag_lz_variant = -1, diag_stats = 0, diag_chain = 0, diag_walk = 0, diag_pipe_scatter = 0;  // diagnostic build only
     uint64_t diag_last_lmds = 0;   // LMD records the entropy stage of the last decode pass on this context left in d_lmds (stage hook)
 
+    lzmi::PinVec h_ctl[8];   // control arrays of a decode call (DH_*): pinned, so that their transfers are asynchronous and cheap
+
     hipEvent_t get_event() {
         if (ev_used == ev_pool.size()) {
             hipEvent_t e;
@@ -323,6 +325,7 @@ void lzfse_mi_destroy(lzfse_mi_ctx *c) {
                       &c->d_lmds, &c->d_lits, &c->d_origin, &c->d_jerr, &c->d_wcache, &c->d_fwalk, &c->d_ck, &c->d_lzp, &c->d_in, &c->d_out, &c->d_small})
         b->release();
     enc_scratch_release(c->enc);
+    for (lzmi::PinVec &h : c->h_ctl) h.release();
     delete c->host_worker;
     c->host_worker = nullptr;
     if (c->host_peer) lzfse_mi_destroy(c->host_peer);
@@ -450,7 +453,17 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
     timing_begin(c);
     hipStream_t st = c->stream;
     const uint32_t ns = (uint32_t)count;
-    std::vector<StreamIn> h_streams(ns);
+#ifdef LZFSE_MI_DIAG
+    // (LZFSE_MI_OPT_DIAG_STATS & 4: where the host's time goes in this call -- scripts/stall_probe.py)
+    const bool trace_host = (c->diag_stats & 4) != 0;
+    std::chrono::steady_clock::time_point tp[6];
+    auto mark = [&](int k) { if (trace_host) tp[k] = std::chrono::steady_clock::now(); };
+#else
+    auto mark = [](int) {};
+#endif
+    mark(0);
+    enum { DH_STREAMS, DH_WALK, DH_PLAN, DH_SRES, DH_STATE, DH_MLIST };
+    lzmi::CtlArray<StreamIn> h_streams(c->h_ctl[DH_STREAMS], ns);
     uint64_t src_total = 0;
     // walk cache: the count pass leaves its descriptors there (one per ~2 KiB of input plus a few per stream; a real
     // bvx2 block is far larger), so that placing them afterwards is a parallel copy instead of a second serial walk
@@ -492,10 +505,12 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
         launch_dec_walk(false, (const uint8_t *)d_src, (const StreamIn *)c->d_streams.p, ns,
                         (StreamWalk *)c->d_walk.p, nullptr, (BlockDesc *)c->d_wcache.p, d_settled, st);
     }
-    std::vector<StreamWalk> h_walk(ns);
+    mark(1);
+    lzmi::CtlArray<StreamWalk> h_walk(c->h_ctl[DH_WALK], ns);
     HIP_TRY(hipMemcpyAsync(h_walk.data(), c->d_walk.p, ns * sizeof(StreamWalk), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    std::vector<StreamPlan> h_plan(ns);
+    mark(2);
+    lzmi::CtlArray<StreamPlan> h_plan(c->h_ctl[DH_PLAN], ns);
     uint64_t nb = 0, nl = 0, nu = 0, nj = 0;
     int jump_mode = c->diag_lz_jump;  // -1: by cost; the diagnostic build can force 0 (never) or 1 (always)
     // Streams >= 2 MiB may take the pointer-jumping LZ path. One workgroup per stream copies ~0.63 GB/s whatever else
@@ -656,11 +671,21 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
                         (const BlockResult *)c->d_bres.p, (const LmdRec *)c->d_lmds.p, (const uint8_t *)c->d_lits.p, (uint8_t *)d_dst,
                         (uint32_t *)c->d_origin.p, nj, d_jerr, d_jflags, (StreamResult *)c->d_sres.p, c, jump_fused, st);
     }
-    std::vector<StreamResult> h_sres(ns);
-    std::vector<uint32_t> h_state(mlist.empty() ? 0 : (size_t)LZP_STATE_WORDS * ns);
+    mark(3);
+    lzmi::CtlArray<StreamResult> h_sres(c->h_ctl[DH_SRES], ns);
+    lzmi::CtlArray<uint32_t> h_state(c->h_ctl[DH_STATE], mlist.empty() ? 0 : (size_t)LZP_STATE_WORDS * ns);
     HIP_TRY(hipMemcpyAsync(h_sres.data(), c->d_sres.p, ns * sizeof(StreamResult), hipMemcpyDeviceToHost, st));
+    mark(4);
     if (!mlist.empty()) HIP_TRY(hipMemcpyAsync(h_state.data(), d_lzp_state, h_state.size() * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    mark(5);
+#ifdef LZFSE_MI_DIAG
+    if (trace_host) {
+        auto ms = [&](int a, int b) { return std::chrono::duration<double, std::milli>(tp[b] - tp[a]).count(); };
+        fprintf(stderr, "dec_host ctx=%p streams=%u total=%.3f upload+walk_launch=%.3f walk_wait=%.3f plan+launches=%.3f results_copy_call=%.3f wait=%.3f\n", (void *)c, ns, ms(0, 5),
+                ms(0, 1), ms(1, 2), ms(2, 3), ms(3, 4), ms(4, 5));
+    }
+#endif
     if (hipGetLastError() != hipSuccess) return LZFSE_MI_IO;
     {
         // The pipelined LZ kernel hands data from workgroup to workgroup through one XCD's L2 and checks that it may
@@ -919,12 +944,16 @@ int lzfse_mi_encode_batch_device(lzfse_mi_ctx *c, size_t count, const void *d_sr
                                  const uint64_t *src_len, void *d_dst, const uint64_t *dst_off,
                                  const uint64_t *dst_cap, uint64_t *out_lens, int *statuses) {
     if (!c) return LZFSE_MI_BAD_ARGUMENT;
-    // two lanes, three from 512 MiB on (measured: +5 % at 752 MB, -4 % at 188 MB, where the lanes' tails dominate)
+    // One pass below 448 MiB, two lanes up to 700 MiB, three beyond (round 5, profiles/r05_lanes_sweep.txt: Snappy x 16 / 64 / 128 /
+    // 192 / 256 / 512 encode 17.6 / 27.3 / 30.5 / 32.2 / 30.0 / 30.6 GB/s as one pass, 9.6 / 26.8 / 29.8 / 32.9 / 34.3 / 35.5 with two
+    // lanes, - / - / - / 31.6 / 34.9 / 36.5 with three; 256 MiB in 64 streams 31.8 against 30.4). Rounds 2 to 4 cut every call of
+    // 8 streams and 4 MiB in two: the candidate stage fills every wave slot by itself, and what a second lane hides of the
+    // latency-bound stages only pays once those are a large batch's worth.
     int lanes = c->opt_lanes_enc;
     if (!lanes) {
         uint64_t total = 0;
         for (size_t i = 0; src_len && i < count; i++) total += src_len[i];
-        lanes = total >= (512ull << 20) ? 3 : 2;
+        lanes = total >= (700ull << 20) ? 3 : total >= (448ull << 20) ? 2 : 1;
     }
     return split_batch(c, encode_batch_device_one, lanes, c->opt_stagger != 0, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap,
                        out_lens, statuses);

@@ -740,7 +740,10 @@ void enc_scratch_release(EncScratch &s) {
         s.bufs[i] = nullptr;
         s.caps[i] = 0;
     }
+    for (PinVec &h : s.host) h.release();
 }
+enum { EH_STREAMS, EH_TILES, EH_CTILES, EH_SLOTS, EH_SEGS, EH_RSLOTS, EH_OUTS, EH_N };
+static_assert(EH_N <= 8, "EncScratch::host");
 
 #define E_TRY(x) do { if ((x) != hipSuccess) return LZFSE_MI_IO; } while (0)
 
@@ -749,6 +752,15 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
                      uint64_t *out_lens, int *statuses) {
     hipStream_t stq = ctx_stream(c);
     EncScratch &S = ctx_enc(c);
+#ifdef LZFSE_MI_DIAG
+    // (LZFSE_MI_OPT_DIAG_STATS & 4: where the host's time goes in this call -- scripts/stall_probe.py)
+    const bool trace_host = (ctx_diag_stats(c) & 4) != 0;
+    std::chrono::steady_clock::time_point tp[6];
+    auto mark = [&](int k) { if (trace_host) tp[k] = std::chrono::steady_clock::now(); };
+#else
+    auto mark = [](int) {};
+#endif
+    mark(0);
     // whatever path leaves this function, the next lane of a split call must not be left waiting
     struct GateRelease {
         LaneGate *g;
@@ -782,10 +794,8 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     // longest streams first: per-stream serial stages of the longest stream bound the batch
     std::stable_sort(hs.begin(), hs.end(), [](const EncStream &a, const EncStream &b) { return a.n > b.n; });
     std::vector<EncTile> ht;
-    std::vector<uint32_t> hslots, hrslots;
-    std::vector<uint2> hsegs;
     uint64_t pos_total = 0, lmd_total = 0, stage_total = 0, match_total = 0;
-    uint32_t blk_total = 0, range_total = 0;
+    uint32_t blk_total = 0, range_total = 0, seg_total = 0;
     // segment length of the speculative parse: one value for the batch (seg_for, enc_common.h)
     uint64_t batch_pos = 0;
     for (uint32_t si = 0; si < ns; si++) batch_pos += hs[si].n;
@@ -804,16 +814,14 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         e.stage_base = stage_total;
         e.stage_cap = (uint64_t)e.n + e.n / 2 + e.n / 4 + (uint64_t)e.blk_cap * 1024 + 4096;
         e.stage_cap = (e.stage_cap + 255) & ~255ull;
-        e.seg_base = (uint32_t)hsegs.size();
+        e.seg_base = seg_total;
         e.n_seg = (n_pos + seg - 1) / seg;
-        for (uint32_t k = 0; k < e.n_seg; k++) hsegs.push_back(make_uint2(si, k));
+        seg_total += e.n_seg;
         e.range_base = range_total;
         // (ring parse: up to one more event and range per 16 KiB block, the literals a round pushes when they pass the head)
         e.range_cap = 2 * e.n_seg + 4 + (ring ? e.n / RING_BLK + 4 : 0);
         e.match_base = match_total;
         e.match_cap = e.n / 4 + 8 + (ring ? e.n / RING_BLK + 4 : 0);
-        for (uint32_t b = 0; b < e.blk_cap; b++) hslots.push_back(si);
-        for (uint32_t b = 0; b < e.range_cap; b++) hrslots.push_back(si);
         blk_total += e.blk_cap;
         range_total += e.range_cap;
         pos_total += ((uint64_t)e.n + 255) & ~255ull;
@@ -821,7 +829,8 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         stage_total += e.stage_cap;
         match_total += e.match_cap;
     }
-    const uint32_t nt = (uint32_t)ht.size(), nseg = (uint32_t)hsegs.size();
+    const uint32_t nt = (uint32_t)ht.size(), nseg = seg_total;
+    mark(1);
     // chain tiles: 1, 2 or 4 candidate tiles long (enc_common.h, chain_tile_mult)
     const uint32_t ch_mult = chain_tile_mult([&](uint32_t m) { uint64_t k = 0; for (const EncStream &e : hs) k += ((uint64_t)e.n - 3 + (uint64_t)TILE_POS * m - 1) / ((uint64_t)TILE_POS * m); return k; },
                                              ctx_diag_chain(c) >> 4);
@@ -845,6 +854,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         !eb_ensure(S, EB_RSLOTS, (size_t)range_total * 4) || !eb_ensure(S, EB_SYNC, (size_t)nseg * sizeof(uint4)) ||
         !eb_ensure(S, EB_RSUM, (size_t)range_total * sizeof(uint2)))
         return LZFSE_MI_IO;
+    mark(2);
     EncStream *d_streams = (EncStream *)S.bufs[EB_STREAMS];
     EncTile *d_tiles = (EncTile *)S.bufs[EB_TILES];
     uint32_t *d_prev = (uint32_t *)S.bufs[EB_PREV];
@@ -858,12 +868,19 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     uint8_t *d_stage = (uint8_t *)S.bufs[EB_STAGE];
     uint32_t *d_slots = (uint32_t *)S.bufs[EB_SLOTS];
     uint64_t *d_bitmap = (uint64_t *)S.bufs[EB_BITMAP];
-    E_TRY(hipMemcpyAsync(d_streams, hs.data(), ns * sizeof(EncStream), hipMemcpyHostToDevice, stq));
-    E_TRY(hipMemcpyAsync(d_tiles, ht.data(), nt * sizeof(EncTile), hipMemcpyHostToDevice, stq));
-    E_TRY(hipMemcpyAsync(d_ctiles, hct.data(), nct * sizeof(EncTile), hipMemcpyHostToDevice, stq));
-    E_TRY(hipMemcpyAsync(d_slots, hslots.data(), (size_t)blk_total * 4, hipMemcpyHostToDevice, stq));
+    // (descriptors travel from pinned arrays of the context, PinVec: the uploads are asynchronous, the candidate stage is queued
+    // before the host has made the lists the later stages want)
+    CtlArray<EncStream> ps(S.host[EH_STREAMS], ns);
+    CtlArray<EncTile> pt(S.host[EH_TILES], nt), pct(S.host[EH_CTILES], nct);
+    std::memcpy(ps.data(), hs.data(), ns * sizeof(EncStream));
+    std::memcpy(pt.data(), ht.data(), nt * sizeof(EncTile));
+    std::memcpy(pct.data(), hct.data(), nct * sizeof(EncTile));
+    E_TRY(hipMemcpyAsync(d_streams, ps.data(), ns * sizeof(EncStream), hipMemcpyHostToDevice, stq));
+    E_TRY(hipMemcpyAsync(d_tiles, pt.data(), nt * sizeof(EncTile), hipMemcpyHostToDevice, stq));
+    E_TRY(hipMemcpyAsync(d_ctiles, pct.data(), nct * sizeof(EncTile), hipMemcpyHostToDevice, stq));
     E_TRY(hipMemsetAsync(d_outs, 0, ns * sizeof(EncStreamOut), stq));
     E_TRY(hipMemsetAsync(d_bitmap, 0, pos_total / 8 + 64, stq));
+    mark(3);
     if (LaneGate *gi = ctx_gate_in(c)) {
         // lane of a split call: start when the previous lane has queued its candidate kernel (LaneGate, internal.h)
         if (gi->wait() == 1) (void)hipStreamWaitEvent(stq, gi->ev, 0);
@@ -888,8 +905,20 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         RangeRec *d_ranges = (RangeRec *)S.bufs[EB_RANGES];
         MatchRec *d_gaps = (MatchRec *)S.bufs[EB_GAPS], *d_matches = (MatchRec *)S.bufs[EB_MATCHES];
         uint32_t *d_pc = (uint32_t *)S.bufs[EB_PC], *d_pl = (uint32_t *)S.bufs[EB_PL], *d_rslots = (uint32_t *)S.bufs[EB_RSLOTS];
-        E_TRY(hipMemcpyAsync(d_segs, hsegs.data(), (size_t)nseg * sizeof(uint2), hipMemcpyHostToDevice, stq));
-        E_TRY(hipMemcpyAsync(d_rslots, hrslots.data(), (size_t)range_total * 4, hipMemcpyHostToDevice, stq));
+        // the lists of segments, block slots and range slots (a million entries for a 750 MB batch: 0.6 ms of this thread) are made
+        // while the device is busy with the candidate stage
+        CtlArray<uint2> psegs(S.host[EH_SEGS], nseg);
+        CtlArray<uint32_t> pslots(S.host[EH_SLOTS], blk_total), prslots(S.host[EH_RSLOTS], range_total);
+        for (uint32_t si = 0; si < ns; si++) {
+            const EncStream &e = hs[si];
+            uint2 *sg = psegs.data() + e.seg_base;
+            for (uint32_t k = 0; k < e.n_seg; k++) sg[k] = make_uint2(si, k);
+            std::fill_n(pslots.data() + e.blk_base, e.blk_cap, si);
+            std::fill_n(prslots.data() + e.range_base, e.range_cap, si);
+        }
+        E_TRY(hipMemcpyAsync(d_slots, pslots.data(), (size_t)blk_total * 4, hipMemcpyHostToDevice, stq));
+        E_TRY(hipMemcpyAsync(d_segs, psegs.data(), (size_t)nseg * sizeof(uint2), hipMemcpyHostToDevice, stq));
+        E_TRY(hipMemcpyAsync(d_rslots, prslots.data(), (size_t)range_total * 4, hipMemcpyHostToDevice, stq));
         {
             StageTimer t(c, "enc_spec");
             launch_enc_spec(d_src, d_streams, d_segs, nseg, seg, d_prev, d_rec, d_bitmap, d_logs, d_hdrs, stq);
@@ -936,16 +965,25 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         StageTimer t(c, "enc_pack");
         hipLaunchKernelGGL(enc_pack_kernel, dim3(blk_total), dim3(256), 0, stq, d_streams, d_slots, d_blocks, d_stage, d_dst, d_outs);
     }
-    std::vector<EncStreamOut> ho(ns);
+    CtlArray<EncStreamOut> ho(S.host[EH_OUTS], ns + 1);   // (+ the window's cut record, behind the streams')
     EncCut hcut{};
     if (win && !win->final) {
         // where this window of a longer stream is cut: the blocks in front of that point are final, the parse goes on from there
         launch_enc_cut(d_streams, ns, d_outs, d_blocks, (const RangeRec *)S.bufs[EB_RANGES], (const SpecEvent *)S.bufs[EB_LOGS],
                        (const MatchRec *)S.bufs[EB_GAPS], (const uint4 *)S.bufs[EB_GSTATE], (EncCut *)S.bufs[EB_CUT], stq);
-        E_TRY(hipMemcpyAsync(&hcut, S.bufs[EB_CUT], sizeof hcut, hipMemcpyDeviceToHost, stq));
+        E_TRY(hipMemcpyAsync(&hcut, S.bufs[EB_CUT], sizeof hcut, hipMemcpyDeviceToHost, stq));   // (a window of a stream: one small record, pageable)
     }
+    mark(4);
     E_TRY(hipMemcpyAsync(ho.data(), d_outs, ns * sizeof(EncStreamOut), hipMemcpyDeviceToHost, stq));
     E_TRY(hipStreamSynchronize(stq));
+    mark(5);
+#ifdef LZFSE_MI_DIAG
+    if (trace_host) {
+        auto ms = [&](int a, int b) { return std::chrono::duration<double, std::milli>(tp[b] - tp[a]).count(); };
+        fprintf(stderr, "enc_host ctx=%p streams=%u total=%.3f prep=%.3f alloc=%.3f upload=%.3f launches=%.3f wait=%.3f\n", (void *)c, ns, ms(0, 5), ms(0, 1),
+                ms(1, 2), ms(2, 3), ms(3, 4), ms(4, 5));
+    }
+#endif
     if (hipGetLastError() != hipSuccess) return LZFSE_MI_IO;
     for (uint32_t i = 0; i < ns; i++) {
         uint32_t u = hs[i].user_index;

@@ -207,10 +207,44 @@ void launch_dec_jump(const uint8_t *src, const StreamIn *streams, const StreamPl
                      uint8_t *dst, uint32_t *origin, uint64_t total, uint32_t *jerr, uint32_t *flags, StreamResult *sres,
                      lzfse_mi_ctx *c, bool init_done, hipStream_t st);
 
+// A host array that travels to or from the device in every call (stream descriptors, plans, per-stream results): pinned and kept
+// with the context. Round 5: these were std::vectors, i.e. pageable memory, and a transfer of pageable memory is neither
+// asynchronous -- the call returns when every kernel queued before it is through -- nor cheap beyond a size the runtime
+// keeps to itself: the 221 KB of walk results of a 4 608-stream decode call took 14.5 ms to arrive where the 196 KB of a
+// 4 080-stream call took 0.06 (profiles/r05_host_phases.txt).
+struct PinVec {
+    void *p = nullptr;
+    size_t cap = 0;
+    void *get(size_t bytes) {   // nullptr: no pinned memory to be had (the caller falls back to a vector)
+        if (bytes <= cap) return p;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        const size_t nc = bytes + bytes / 2 + 4096;
+        if (hipHostMalloc(&p, nc, hipHostMallocDefault) != hipSuccess) { p = nullptr; return nullptr; }
+        cap = nc;
+        return p;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+template <class T> struct CtlArray {
+    T *p = nullptr;
+    size_t n = 0;
+    std::vector<T> fallback;
+    CtlArray(PinVec &pv, size_t count) : n(count) {
+        p = (T *)pv.get((count ? count : 1) * sizeof(T));
+        if (!p) { fallback.resize(count ? count : 1); p = fallback.data(); }
+    }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    T *data() { return p; }
+    size_t size() const { return n; }
+};
+
 // ---- encode.hip ----
 struct EncScratch {
     void *bufs[32] = {};
     size_t caps[32] = {};
+    PinVec host[8];   // control arrays of a call (EH_*)
 };
 EncScratch &ctx_enc(lzfse_mi_ctx *c);
 void enc_scratch_release(EncScratch &s);

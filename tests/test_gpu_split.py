@@ -29,10 +29,15 @@ def _mixed(snappy_raw):
 def test_split_encode_matches_oracle(ctx, oracle, snappy_raw):
     raws = _mixed(snappy_raw)
     assert len(raws) >= 8 and sum(map(len, raws)) >= 4 << 20  # large enough to be split
+    # (round 5: a call below 448 MiB runs as one pass unless told otherwise -- the lanes are asked for here)
+    ctx.set_option("encode_lanes", 2)
     ctx.enable_timing(True)
-    outs, st = ctx.encode_batch(raws)
-    t = ctx.timings()
-    ctx.enable_timing(False)
+    try:
+        outs, st = ctx.encode_batch(raws)
+        t = ctx.timings()
+    finally:
+        ctx.enable_timing(False)
+        ctx.set_option("encode_lanes", 0)
     assert t["enc_cand"][1] >= 2, t  # sub-batches ran side by side
     for r, o, e in zip(raws, outs, st):
         assert e == 0
