@@ -19,6 +19,7 @@
 
 #include "common.h"
 #include "internal.h"
+#include <atomic>
 
 using namespace lzmi;
 
@@ -123,6 +124,8 @@ struct lzfse_mi_ctx {
     uint64_t diag_last_lmds = 0;   // LMD records the entropy stage of the last decode pass on this context left in d_lmds (stage hook)
 
     lzmi::PinVec h_ctl[8];   // control arrays of a decode call (DH_*): pinned, so that their transfers are asynchronous and cheap
+    lzmi::OutMirror mirror;  // set by the host-pointer decode call for the device call it makes: the LZ stage also writes the pinned image
+    lzmi::PinVec h_done;     // ... and its word per stream
 
     hipEvent_t get_event() {
         if (ev_used == ev_pool.size()) {
@@ -326,6 +329,7 @@ void lzfse_mi_destroy(lzfse_mi_ctx *c) {
         b->release();
     enc_scratch_release(c->enc);
     for (lzmi::PinVec &h : c->h_ctl) h.release();
+    c->h_done.release();
     delete c->host_worker;
     c->host_worker = nullptr;
     if (c->host_peer) lzfse_mi_destroy(c->host_peer);
@@ -530,7 +534,8 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
     for (uint32_t i = 0; i < ns; i++) {
         StreamPlan &p = h_plan[i];
         p.blk_base = nb; p.lmd_base = nl; p.lit_base = nu; p.n_blocks = h_walk[i].n_blocks; p.skip = 0;
-        p.jbase = 0; p.jump = 0; p.turn = i; p.pipe = 0; p.pad = 0;
+        p.jbase = 0; p.jump = 0; p.turn = i; p.pipe = 0;
+        p.pad = h_walk[i].status != 0;   // (a stream that fails in the end leaves nothing in the caller's buffer: no host image of its first blocks)
         statuses[i] = LZFSE_MI_OK;
         out_lens[i] = 0;
         // A stream whose walk failed at block k still has its first k blocks decoded: the reference decodes in order, so
@@ -653,7 +658,7 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
         launch_dec_lz(variant, (const uint8_t *)d_src, (const StreamIn *)c->d_streams.p,
                       (const StreamPlan *)c->d_plan.p, ns, (const BlockDesc *)c->d_blocks.p,
                       (const BlockResult *)c->d_bres.p, (const LmdRec *)c->d_lmds.p, (const uint8_t *)c->d_lits.p,
-                      (uint8_t *)d_dst, (StreamResult *)c->d_sres.p, st);
+                      (uint8_t *)d_dst, (StreamResult *)c->d_sres.p, c->lane_share <= 1 ? c->mirror : lzmi::OutMirror(), st);
         if (!mlist.empty()) {
             // (tickets of two LMDs per thread when the streams are long enough to keep their workgroups in tickets: dec_lzp_kernel)
             uint64_t pipe_raw = 0;
@@ -702,7 +707,7 @@ static int decode_batch_device_one(lzfse_mi_ctx *c, size_t count, const void *d_
                 StageTimer t(c, "dec_lz_again");
                 launch_dec_lz(1, (const uint8_t *)d_src, (const StreamIn *)c->d_streams.p, (const StreamPlan *)c->d_plan.p, ns,
                               (const BlockDesc *)c->d_blocks.p, (const BlockResult *)c->d_bres.p, (const LmdRec *)c->d_lmds.p,
-                              (const uint8_t *)c->d_lits.p, (uint8_t *)d_dst, (StreamResult *)c->d_sres.p, st);
+                              (const uint8_t *)c->d_lits.p, (uint8_t *)d_dst, (StreamResult *)c->d_sres.p, c->lane_share <= 1 ? c->mirror : lzmi::OutMirror(), st);
             }
             HIP_TRY(hipMemcpyAsync(h_sres.data(), c->d_sres.p, ns * sizeof(StreamResult), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
@@ -1117,6 +1122,64 @@ static void par_copy(lzfse_mi_ctx *c, const std::vector<CopyJob> &jobs, const st
     for (unsigned t = 1; t < T; t++) c->copy_workers[t - 1]->wait();
 }
 
+// The host's side of OutMirror (internal.h): helper threads that watch the streams' words and copy a stream out of the pinned image
+// as soon as the device says it is whole.
+struct MirrorOut {
+    lzfse_mi_ctx *c = nullptr;
+    unsigned busy = 0;
+    std::atomic<bool> stop{false};
+    volatile unsigned long long *done = nullptr;
+    std::vector<uint8_t> ok;    // [stream]: copied out of the image (and how long it was)
+    std::vector<uint64_t> len;
+    void start(lzfse_mi_ctx *ctx, size_t count, const std::vector<uint8_t> &big_out, const std::vector<uint64_t> &dof, uint8_t *const *dsts,
+               uint64_t span) {
+        if (!ctx->h_out.ensure(span + 256)) return;
+        void *dv = nullptr, *dd = nullptr;
+        unsigned long long *flags = (unsigned long long *)ctx->h_done.get(count * sizeof(unsigned long long));
+        if (!flags || hipHostGetDevicePointer(&dv, ctx->h_out.p, 0) != hipSuccess || hipHostGetDevicePointer(&dd, flags, 0) != hipSuccess) return;
+        std::memset(flags, 0, count * sizeof(unsigned long long));
+        const unsigned hc = std::thread::hardware_concurrency();
+        unsigned T = std::min<unsigned>(8u, std::max<unsigned>(1u, hc / 2));
+        T = (unsigned)std::min<size_t>(T, std::max<size_t>(1, count / 4));
+        T = copy_helpers(ctx, T);
+        if (!T) return;
+        c = ctx; done = flags; busy = T;
+        ok.assign(count, 0); len.assign(count, 0);
+        stop.store(false);
+        ctx->mirror.base = (uint8_t *)dv; ctx->mirror.span = span; ctx->mirror.done = (unsigned long long *)dd;
+        const uint8_t *img = (const uint8_t *)ctx->h_out.p;
+        for (unsigned t = 0; t < T; t++) {
+            c->copy_workers[t]->submit([this, t, T, count, &big_out, &dof, dsts, img] {
+                std::vector<size_t> mine;
+                for (size_t i = t; i < count; i += T) if (!big_out[i]) mine.push_back(i);
+                for (;;) {
+                    const bool last = stop.load(std::memory_order_acquire);   // (read BEFORE the sweep: after it, every word is final)
+                    size_t keep = 0;
+                    for (size_t k = 0; k < mine.size(); k++) {
+                        const size_t i = mine[k];
+                        const unsigned long long w = __atomic_load_n(&done[i], __ATOMIC_ACQUIRE);
+                        if (w == 0) { mine[keep++] = i; continue; }
+                        if (w != ~0ull) { std::memcpy(dsts[i], img + dof[i], (size_t)(w - 1)); len[i] = w - 1; ok[i] = 1; }
+                    }
+                    mine.resize(keep);
+                    if (mine.empty() || last) return;
+                    if (keep) std::this_thread::yield();
+                }
+            });
+        }
+    }
+    void finish() {
+        if (!busy) return;
+        stop.store(true, std::memory_order_release);
+        for (unsigned t = 0; t < busy; t++) c->copy_workers[t]->wait();
+        busy = 0;
+        c->mirror = lzmi::OutMirror();
+    }
+    // the stream's bytes are in the caller's buffer already (all `n` of them)
+    bool copied(size_t i, uint64_t n) const { return i < ok.size() && ok[i] && len[i] == n; }
+    ~MirrorOut() { finish(); }
+};
+
 static constexpr uint64_t HOST_GROUP = (uint64_t)16 << 20;   // staging granule: copied by the threads while the DMA moves the granule before / after
 
 // The staged image of byte `pos` of the concatenation: jobs are in staging order, stage[k] = staging offset of job k.
@@ -1144,6 +1207,9 @@ static uint64_t staged_at(const std::vector<CopyJob> &jobs, const std::vector<ui
 // ... and all staged outputs of a call together stay below this (round 5): the pinned staging is kept until the context goes, and a batch of
 // 64 streams of 256 MiB would otherwise pin 20 GiB of host memory for good. Outputs beyond the budget travel straight into the caller's
 // buffers, as all of them do when the staging cannot be had at all.
+#ifndef HOST_MIRROR_MAX
+#define HOST_MIRROR_MAX ((uint64_t)80 << 20)
+#endif
 #ifndef HOST_STAGE_BUDGET
 #define HOST_STAGE_BUDGET ((uint64_t)512 << 20)
 #endif
@@ -1221,7 +1287,20 @@ static int host_batch_one(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, s
         pop.add(dsts[i], want);
     }
     pop.start(c);
+    // Decode (round 5): the LZ stage writes every finished tile of a staged stream into the device buffer AND into the pinned
+    // staging image (OutMirror), and a word per stream when it is through; helper threads copy finished streams from the image into
+    // the caller's buffers while the rest is still decoded. What the transfer after the kernels cost (94 MB: 1.7 ms at the link's
+    // rate, then the copies) now runs under the stage. Streams that go another way on the device (pointer jumping, several
+    // workgroups per stream) and failed ones leave no word: they travel as before.
+    // (Up to 80 MiB of staged output per call, i.e. per half of a large call: beyond that the halves' pipeline does better with a
+    // stage that is over quickly and a copy engine that moves its output under the other half's kernels, than with a stage that
+    // holds its wave slots for as long as the link takes -- A/B on one box, 47 / 71 / 94 / 141 / 188 MB: 17.3 / 19 / 21.5 / 21 / 19.7
+    // GB/s with the image against 14.2 / 12.5 / 14 / 20.6 / 23 without, scripts/pcie_sample.py.)
+    MirrorOut mo;
+    if (!pack_outputs && !defer && !c->pinned_out && out_staged && out_staged <= HOST_MIRROR_MAX && c->opt_lanes_dec <= 1 && !pop.busy)
+        mo.start(c, count, big_out, dof, dsts, out_staged);
     int r = fn(c, count, c->d_in.p, so.data(), sl.data(), dout.p, dof.data(), dc.data(), ol.data(), statuses);
+    mo.finish();
     pop.finish();
     if (r) return r;
     // ---- out: where each stream's bytes are on the device (packed first when they fill little of their capacity) ----
@@ -1296,7 +1375,7 @@ static int host_batch_one(lzfse_mi_ctx *c, batch_dev_fn fn, bool pack_outputs, s
     jobs.clear(); pre.clear(); stage.clear();
     uint64_t n_out = 0;
     for (size_t i = 0; i < count; i++)
-        if (out_lens[i] && !big_out[i]) { jobs.push_back({dsts[i], (const uint8_t *)c->h_out.p + at[i], out_lens[i]}); pre.push_back(n_out); stage.push_back(at[i]); n_out += out_lens[i]; }
+        if (out_lens[i] && !big_out[i] && !mo.copied(i, out_lens[i])) { jobs.push_back({dsts[i], (const uint8_t *)c->h_out.p + at[i], out_lens[i]}); pre.push_back(n_out); stage.push_back(at[i]); n_out += out_lens[i]; }
     const size_t n_gran = (size_t)((n_out + HOST_GROUP - 1) / HOST_GROUP);
     while (c->host_ev.size() < n_gran) {
         hipEvent_t e;

@@ -54,7 +54,7 @@ struct StreamPlan {
     int32_t jump;    // != 0: LZ stage by pointer jumping (large streams), else by the tile kernel
     uint32_t turn;   // plan[b].turn = the stream workgroup b of the tile kernel decodes: longest streams first
     uint32_t pipe;   // != 0: LZ stage by the pipelined tile kernel (several workgroups per stream), else one workgroup
-    uint32_t pad;
+    uint32_t pad;    // != 0: no second copy of this stream's output in the host image (OutMirror, internal.h)
 };
 
 struct BlockDesc {

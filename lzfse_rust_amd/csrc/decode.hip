@@ -1128,7 +1128,7 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
     const uint8_t *__restrict__ src, const StreamIn *__restrict__ streams, const StreamPlan *__restrict__ plan,
     const BlockDesc *__restrict__ blocks, const BlockResult *__restrict__ bres,
     const LmdRec *__restrict__ lmds, const uint8_t *__restrict__ lits, uint8_t *dst_all,
-    StreamResult *__restrict__ sres) {
+    StreamResult *__restrict__ sres, const OutMirror mirror) {
     constexpr int NW = NT / 64;
     constexpr int NS = NT * LPT;     // LMDs (slots) per group
     __shared__ __attribute__((aligned(16))) uint8_t tile[TILE + 32];
@@ -1151,6 +1151,11 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
     if (pl.skip || pl.jump || pl.pipe) return;
     const StreamIn in = streams[s];
     uint8_t *dst = dst_all + in.dst_off;
+    // Round 5, the host-pointer calls: every finished piece of the output is stored TWICE -- into the device buffer, which later
+    // matches read, and into the pinned host image of that buffer (same offsets), so that the bytes cross the link while the
+    // stage runs instead of in a transfer after it (stores into mapped host memory run at the link's rate from any number of
+    // waves: scripts/micro/host_store.hip, profiles/r05_host_store.txt). A word per stream tells the host when its bytes are there.
+    uint8_t *mir = (mirror.base && !pl.pad && in.dst_off + in.dst_cap <= mirror.span) ? mirror.base + in.dst_off : nullptr;   // (pl.pad: not this stream, says the host)
     uint64_t out_pos = 0;  // bytes produced so far in this stream
     int status = 0;
     uint64_t cy0 = 0, cy1 = 0, cy2 = 0, cy3 = 0, cy4 = 0;
@@ -1166,6 +1171,7 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
             if (out_pos + d.n_raw > in.dst_cap) { status = LZFSE_MI_BUFFER_OVERFLOW; break; }
             const uint8_t *p = src + d.src_pos + 8;
             for (uint32_t i = tid; i < d.n_raw; i += NT) dst[out_pos + i] = p[i];
+            if (mir) for (uint32_t i = tid; i < d.n_raw; i += NT) mir[out_pos + i] = p[i];
             out_pos += d.n_raw;
             __syncthreads();
             continue;
@@ -1180,6 +1186,7 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
             }
             __syncthreads();
             status = s_status;
+            if (mir && !status) for (uint32_t i = tid; i < s_cnt[0]; i += NT) mir[out_pos + i] = dst[out_pos + i];   // (what thread 0 has just written)
             out_pos += s_cnt[0];
             __syncthreads();
             continue;
@@ -1418,6 +1425,13 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
                 for (uint32_t k = tid; k < body / 16; k += NT) gd[k] = ts[k];
                 uint32_t tail0 = head + body;
                 if (tail0 + tid < tile_len && tid < 16) g[tail0 + tid] = t[tail0 + tid];
+                if (mir) {   // (the image lies like the buffer: offsets are multiples of 256 in both)
+                    uint8_t *mg = mir + tile_base;
+                    if (tid < (int)head) mg[tid] = t[tid];
+                    uint4 *md = (uint4 *)(mg + head);
+                    for (uint32_t k = tid; k < body / 16; k += NT) md[k] = ts[k];
+                    if (tail0 + tid < tile_len && tid < 16) mg[tail0 + tid] = t[tail0 + tid];
+                }
             }
             out_pos += tile_len;
             // lit_run advances by the literals of the participants only
@@ -1435,6 +1449,13 @@ __global__ __launch_bounds__(NT) void dec_lz_kernel(
         r.cyc[0] = cy0; r.cyc[1] = cy1; r.cyc[2] = cy2; r.cyc[3] = cy3; r.cyc[4] = cy4;
         r.cyc[5] = __builtin_amdgcn_s_memtime() - t_start;
         sres[s] = r;
+    }
+    if (mir && mirror.done) {
+        // every thread's stores into the image have left the chip before the word that says so is written (system scope: the reader
+        // is a host thread): 1 + the stream's length when it came out whole, all ones otherwise
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(mirror.done + s, status ? ~0ull : out_pos + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -2400,14 +2421,14 @@ void launch_dec_fse(const uint8_t *src, uint64_t src_total, const BlockDesc *blo
 
 void launch_dec_lz(int variant, const uint8_t *src, const StreamIn *streams, const StreamPlan *plan,
                    uint32_t n_streams, const BlockDesc *blocks, const BlockResult *bres, const LmdRec *lmds,
-                   const uint8_t *lits, uint8_t *dst, StreamResult *sres, hipStream_t st) {
+                   const uint8_t *lits, uint8_t *dst, StreamResult *sres, const OutMirror &mirror, hipStream_t st) {
     if (!n_streams) return;
     if (variant == 0)
         hipLaunchKernelGGL((dec_lz_kernel<256, 8192, LZ_LPT>), dim3(n_streams), dim3(256), 0, st, src, streams, plan,
-                           blocks, bres, lmds, lits, dst, sres);
+                           blocks, bres, lmds, lits, dst, sres, mirror);
     else
         hipLaunchKernelGGL((dec_lz_kernel<1024, 32768, LZ_LPT>), dim3(n_streams), dim3(1024), 0, st, src, streams, plan,
-                           blocks, bres, lmds, lits, dst, sres);
+                           blocks, bres, lmds, lits, dst, sres, mirror);
 }
 
 void launch_dec_lzp(int variant, uint32_t K, int lpt, const uint8_t *src, const StreamIn *streams, const StreamPlan *plan,

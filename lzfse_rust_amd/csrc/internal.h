@@ -186,9 +186,16 @@ struct JumpFuse {
 void launch_dec_fse(const uint8_t *src, uint64_t src_total, const BlockDesc *blocks, uint32_t n_blocks,
                     uint8_t *lit_out, LmdRec *lmd_out, BlockResult *results, uint32_t *order_hist, uint32_t *order,
                     const JumpFuse *jf, hipStream_t st);
+// Where dec_lz_kernel stores a second copy of what it writes (the host-pointer decode calls): the pinned image of the output buffer
+// (streams whose capacity ends below `span` have one, at their offset), and a word per stream for "its bytes are there".
+struct OutMirror {
+    uint8_t *base = nullptr;
+    uint64_t span = 0;
+    unsigned long long *done = nullptr;   // [stream]: 0 until the stream is through; then 1 + its length, or all ones (failed)
+};
 void launch_dec_lz(int variant, const uint8_t *src, const StreamIn *streams, const StreamPlan *plan,
                    uint32_t n_streams, const BlockDesc *blocks, const BlockResult *bres, const LmdRec *lmds,
-                   const uint8_t *lits, uint8_t *dst, StreamResult *sres, hipStream_t st);
+                   const uint8_t *lits, uint8_t *dst, StreamResult *sres, const OutMirror &mirror, hipStream_t st);
 
 // dec_lzp_kernel's words per stream, one 128-byte line per KIND of access: [LZP_NEXT] next ticket and [LZP_HOME] home XCC + 1
 // (device-scope atomics), [LZP_DONE] the published ticket (plain stores and L2-scope loads inside one XCD: that line is dirty
