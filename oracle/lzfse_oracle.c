@@ -804,31 +804,84 @@ static void push_match(frontend *f, match_t m) {
     backend_push_match(f, lit, n_lit, m.match_len, dist);
 }
 
-/* frontend_bytes.rs:121-131,160-211,271-344 for src.len() <= 0x7FFF_FFFF + 3 */
-static void frontend_finalize(frontend *f) {
-    const uint8_t *src = f->src;
-    uint32_t end = (uint32_t)f->n - 3;
-    uint32_t index = 0;
+/* frontend_bytes.rs:121-211,271-375: match_blocks (match_any per block, reposition between blocks), flush_pending,
+ * flush_literals. guide / slack: BLOCK_GUIDE = 0x7FFF_FFFF and SLACK = 0x1000_0000 (:19-23) -- parameters here so that the
+ * tests can make the front end reposition on inputs of a few MiB (lzo_encode_guide); a slice of up to guide + 3 bytes is one
+ * block and never repositions. Positions are relative to f->src, which moves up by `delta` at every reposition, as
+ * self.src does (:372). */
+#define BLOCK_GUIDE 0x7FFFFFFFu
+#define BLOCK_SLACK 0x10000000u
+static void frontend_finalize_guide(frontend *f, uint32_t guide, uint32_t slack) {
+    size_t total = f->n;          /* bytes from f->src to the end of the input */
+    uint32_t index = 0;           /* self.index between blocks: 0, then MAX_MATCH_DISTANCE (is_any :384-388) */
     for (;;) {
-        uint32_t val = ld32(src + index);
-        history_t queue = table_push(f->table, f->vn, val, index);
-        match_t incoming = find_match(f, &queue, val, index);
-        match_t sel;
-        if (match_select(&f->pending, incoming, &sel)) {
-            push_match(f, sel);
-            if (f->err) return;
-            if (f->literal_index >= end) break;
-            index += 1;
-            while (index < f->literal_index) { /* sync_history :336-344 */
-                table_push(f->table, f->vn, ld32(src + index), index);
-                index++;
+        const uint8_t *src = f->src;
+        /* match_any :160-211 */
+        int is_short = total <= (size_t)guide + 3;
+        size_t block_len = is_short ? total : (size_t)guide;
+        uint32_t end = is_short ? (uint32_t)block_len - 3 : (uint32_t)block_len - slack - 3;
+        f->n = block_len;         /* matches end with the block (:253: max = self.block.len() - index) */
+        for (;;) {
+            uint32_t val = ld32(src + index);
+            history_t queue = table_push(f->table, f->vn, val, index);
+            match_t incoming = find_match(f, &queue, val, index);
+            match_t sel;
+            if (match_select(&f->pending, incoming, &sel)) {
+                push_match(f, sel);
+                if (f->err) return;
+                if (f->literal_index >= end) break;
+                index += 1;
+                while (index < f->literal_index) { /* sync_history :336-344 */
+                    table_push(f->table, f->vn, ld32(src + index), index);
+                    index++;
+                }
+                if (index >= end) break;
+            } else {
+                index += 1;
+                if (index == end) break;
             }
-            if (index >= end) break;
-        } else {
-            index += 1;
-            if (index == end) break;
         }
+        if (is_short) break;
+        /* reposition :348-375. self.index is the block's limit here, whatever the loop's own `index` got to (match_any keeps a
+         * local copy, :168,180): positions between the one the last match was found at and the limit are never pushed when
+         * that match ran past the limit. */
+        index = end;
+        while (index < f->literal_index) { /* sync_history over self.src */
+            table_push(f->table, f->vn, ld32(src + index), index);
+            index++;
+        }
+        uint32_t delta = index - f->max_dist;
+        if (f->literal_index < delta) {
+            /* literals that have passed the buffer head go as they are, the pending match is dropped */
+            f->pending.match_len = 0;
+            uint32_t len = delta - f->literal_index;
+            if (f->trace && f->trace->match)
+                f->trace->match(f->trace->ctx, f->literal_index, f->literal_index + len, 0, 1);
+            const uint8_t *lit = src + f->literal_index;
+            f->literal_index += len;
+            if (f->vn) {
+                if (!vn_push_literals(&f->vnb, f->dst, lit, len)) f->err = LZO_IO;
+            } else {
+                backend_push_match(f, lit, len, 0, 1);
+            }
+            if (f->err) return;
+        }
+        /* history.rs:62-66,121-130 clamp_rebias: idx values are wrapping u32 */
+        for (size_t b = 0; b < ((size_t)1 << HASH_BITS); b++)
+            for (int k = 0; k < HASH_WIDTH; k++) {
+                item_t *it = &f->table[b].q[k];
+                if ((uint32_t)(index - it->idx) > 0x40000000u) it->idx = index - 0x40000000u - delta;
+                else it->idx -= delta;
+            }
+        /* match_object.rs:35-38 */
+        f->pending.match_idx -= delta;
+        f->pending.idx -= delta;
+        f->src += delta;
+        total -= delta;
+        f->literal_index -= delta;
+        index -= delta;
     }
+    const uint8_t *src = f->src;
     /* flush_pending :271-285 */
     if (f->pending.match_len != 0) {
         push_match(f, f->pending);
@@ -848,6 +901,7 @@ static void frontend_finalize(frontend *f) {
         }
     }
 }
+static void frontend_finalize(frontend *f) { frontend_finalize_guide(f, BLOCK_GUIDE, BLOCK_SLACK); }
 
 /* history.rs:72-84: every entry (val 0, idx Q0 - Q1 = 0xC000_0000) */
 static void table_reset(history_t *t) {
@@ -868,10 +922,21 @@ static int raw_compress(vec_t *dst, const uint8_t *src, size_t n) {
 size_t lzo_encode_bound(size_t n) { return n + n / 2 + n / 4 + 4096; }
 
 /* encoder.rs:49-53 -> frontend_bytes.rs:41-111 */
+static int encode_guide(const uint8_t *src, size_t n, uint8_t *out, size_t cap, size_t *out_len, const lzo_trace *trace,
+                        uint32_t guide, uint32_t slack);
 int lzo_encode(const uint8_t *src, size_t n, uint8_t *out, size_t cap, size_t *out_len,
                const lzo_trace *trace) {
+    return encode_guide(src, n, out, cap, out_len, trace, BLOCK_GUIDE, BLOCK_SLACK);
+}
+/* The same front end with another block guide and slack (test hook: repositions on small inputs). The reference's own
+ * assertions (:166-168,359): 256 <= slack, 2 * slack <= guide, and the limit guide - slack - 3 >= MAX_MATCH_DISTANCE. */
+int lzo_encode_guide(const uint8_t *src, size_t n, uint8_t *out, size_t cap, size_t *out_len, uint32_t guide, uint32_t slack) {
+    if (slack < 256 || (uint64_t)slack * 2 > guide || guide > BLOCK_GUIDE || guide - slack - 3 < MAX_D_VALUE) return LZO_UNSUPPORTED;
+    return encode_guide(src, n, out, cap, out_len, NULL, guide, slack);
+}
+static int encode_guide(const uint8_t *src, size_t n, uint8_t *out, size_t cap, size_t *out_len, const lzo_trace *trace,
+                        uint32_t guide, uint32_t slack) {
     init_tables();
-    if (n > (size_t)0x7FFFFFFFu + 3) return LZO_UNSUPPORTED; /* reposition :348-375 not restated */
     vec_t dst = {0, 0, 0};
     int status = LZO_OK;
     history_t *table = NULL;
@@ -900,7 +965,7 @@ int lzo_encode(const uint8_t *src, size_t n, uint8_t *out, size_t cap, size_t *o
         f.fse = fb;
         f.dst = &dst;
         f.trace = trace;
-        frontend_finalize(&f);
+        frontend_finalize_guide(&f, guide, slack);
         if (!f.err) f.err = emit_block_v2(fb, &dst); /* fse/backend.rs:92-95 */
         status = f.err;
     } else if (n > RAW_CUTOFF) {

@@ -81,6 +81,9 @@ size_t lzo_encode_bound(size_t n);
 /* encode_bytes: appends the stream for src[0..n) at dst, *out_len = bytes written. */
 int lzo_encode(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *out_len,
                const lzo_trace *trace);
+/* the same with another BLOCK_GUIDE / SLACK (frontend_bytes.rs:19-23): lets the tests see the front end reposition
+ * (:348-375) on inputs of a few MiB. lzo_encode == lzo_encode_guide(0x7FFF_FFFF, 0x1000_0000), inputs of any length. */
+int lzo_encode_guide(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *out_len, uint32_t guide, uint32_t slack);
 
 /* decode_bytes: decodes the whole stream src[0..n) (must end exactly at bvx$ + 4). */
 int lzo_decode(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *out_len,

@@ -44,6 +44,8 @@ class Oracle:
         lib.lzo_decode_size.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
         lib.lzo_candidates.restype = C.c_int
         lib.lzo_candidates.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        lib.lzo_encode_guide.restype = C.c_int
+        lib.lzo_encode_guide.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_uint32, C.c_uint32]
         lib.lzo_table_rows.restype = C.c_int
         lib.lzo_table_rows.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         lib.lzo_normalize_m1.restype = None
@@ -136,6 +138,17 @@ class Oracle:
         return enc, matches, blocks, packs
 
     # ---- ring / stream encoder (LzfseRingEncoder::encode, LzfseWriter) ----
+
+    def encode_guide(self, data, guide, slack):
+        """lzo_encode with another BLOCK_GUIDE / SLACK (frontend_bytes.rs:19-23): the front end repositions (:348-375) on small inputs."""
+        a, p = self._buf(data)
+        cap = self.encode_bound(a.size)
+        out = np.empty(cap, dtype=np.uint8)
+        n = C.c_size_t(0)
+        st = self.lib.lzo_encode_guide(p, a.size, out.ctypes.data, cap, C.byref(n), guide, slack)
+        if st != 0:
+            raise OracleError(st)
+        return out[: n.value].tobytes()
 
     def ring_encode(self, data, piece=0, trace=None):
         """The stream LzfseRingEncoder::encode / LzfseWriter produce for `data` (fed `piece` bytes at a time)."""
