@@ -104,8 +104,11 @@ enum {
     LZFSE_MI_OPT_DIAG_STATS = 102,   /* bit mask: per-stage statistics on stderr */
     LZFSE_MI_OPT_DIAG_CHAIN = 103,   /* bit 0: every chain tile through the ballot kernel (the fallback of the LDS-exchange one); bits 4-6: chain tiles of 1, 2 or 4 x 65 472 positions (0x10, 0x20, 0x40) instead of the call's own choice */
     LZFSE_MI_OPT_DIAG_WALK = 104,    /* decode header walk: 0 by size, 1: every stream tries the parallel walk first, 2: serial only */
-    LZFSE_MI_OPT_DIAG_PIPE_SCATTER = 105  /* 1: the pipelined LZ kernel is told that the workgroups of a stream sit on different XCDs
+    LZFSE_MI_OPT_DIAG_PIPE_SCATTER = 105, /* 1: the pipelined LZ kernel is told that the workgroups of a stream sit on different XCDs
                                              (it must refuse, and the streams are decoded again by the one-workgroup kernel) */
+    LZFSE_MI_OPT_DIAG_GUIDE = 106    /* guide | slack << 32: BLOCK_GUIDE and SLACK of the slice front end (frontend_bytes.rs:19-23) for
+                                        lzfse_mi_encode, so that tests see it reposition (:348-375) on inputs of a few MiB; 0: the
+                                        reference's 0x7FFF_FFFF and 0x1000_0000 */
 };
 LZFSE_MI_API int lzfse_mi_set_option(lzfse_mi_ctx *ctx, int option, int64_t value);
 

@@ -45,7 +45,7 @@ def device_count():
 class Context:
     """One HIP device + stream + scratch (lzfse_mi_ctx)."""
 
-    OPTIONS = {"encode_lanes": 1, "decode_lanes": 2, "stagger": 3, "decode_pipe": 4, "stream_spare": 5, "diag_lz_path": 100, "diag_lz_tile": 101, "diag_stats": 102, "diag_chain": 103, "diag_walk": 104, "diag_pipe_scatter": 105}
+    OPTIONS = {"encode_lanes": 1, "decode_lanes": 2, "stagger": 3, "decode_pipe": 4, "stream_spare": 5, "diag_lz_path": 100, "diag_lz_tile": 101, "diag_stats": 102, "diag_chain": 103, "diag_walk": 104, "diag_pipe_scatter": 105, "diag_guide": 106}
 
     def __init__(self, device=0, diag=False):
         self._lib = _native.lib(diag=diag)

@@ -124,6 +124,8 @@ struct lzfse_mi_ctx {
     uint64_t diag_last_lmds = 0;   // LMD records the entropy stage of the last decode pass on this context left in d_lmds (stage hook)
 
     lzmi::PinVec h_ctl[8];   // control arrays of a decode call (DH_*): pinned, so that their transfers are asynchronous and cheap
+    lzmi::RepoWindow *repo = nullptr;   // set by encode_slice_blocks for the device call over one block of a long slice
+    uint64_t diag_guide = 0;            // diagnostic build: guide | slack << 32 of the slice front end (LZFSE_MI_OPT_DIAG_GUIDE)
     lzmi::OutMirror mirror;  // set by the host-pointer decode call for the device call it makes: the LZ stage also writes the pinned image
     lzmi::PinVec h_done;     // ... and its word per stream
 
@@ -139,7 +141,7 @@ struct lzfse_mi_ctx {
 
 namespace lzmi {
 // RAII helper: brackets a kernel (or group) with events when timing is enabled
-StageTimer::StageTimer(lzfse_mi_ctx *c, const char *name) : ctx(c) {
+StageTimer::StageTimer(lzfse_mi_ctx *c, const char *name) : ctx(c), stage(name) {
     if (!ctx->timing) return;
     hipEvent_t a = ctx->get_event(), b = ctx->get_event();
     if (!a || !b) return;
@@ -149,6 +151,12 @@ StageTimer::StageTimer(lzfse_mi_ctx *c, const char *name) : ctx(c) {
 }
 StageTimer::~StageTimer() {
     if (idx >= 0) (void)hipEventRecord(ctx->spans[idx].b, ctx->stream);
+#ifdef LZFSE_MI_DIAG
+    if (ctx->diag_stats & 8) {   // (LZFSE_MI_OPT_DIAG_STATS & 8: every stage waited for and named -- which one faults)
+        const hipError_t e = hipStreamSynchronize(ctx->stream);
+        fprintf(stderr, "stage %s: %s\n", stage, e == hipSuccess ? "ok" : hipGetErrorString(e));
+    }
+#endif
 }
 hipStream_t ctx_stream(lzfse_mi_ctx *c) { return c->stream; }
 EncScratch &ctx_enc(lzfse_mi_ctx *c) { return c->enc; }
@@ -157,6 +165,11 @@ LaneGate *ctx_gate_out(lzfse_mi_ctx *c) { return c->gate_out; }
 int ctx_diag_stats(lzfse_mi_ctx *c) { return c->diag_stats; }
 bool ctx_parse_ring(lzfse_mi_ctx *c) { return c->parse_ring; }
 EncWindow *ctx_window(lzfse_mi_ctx *c) { return c->window; }
+RepoWindow *ctx_repo(lzfse_mi_ctx *c) { return c->repo; }
+void ctx_diag_guide(lzfse_mi_ctx *c, uint32_t &guide, uint32_t &slack) {
+    guide = 0x7FFFFFFFu; slack = 0x10000000u;   // BLOCK_GUIDE, SLACK (frontend_bytes.rs:19-23)
+    if (c->diag_guide) { guide = (uint32_t)c->diag_guide; slack = (uint32_t)(c->diag_guide >> 32); }
+}
 StreamSpare &ctx_spare(lzfse_mi_ctx *c) { return c->spare; }
 void ctx_attach(lzfse_mi_ctx *c, lzfse_mi_ctx **ref) {
     std::lock_guard<std::mutex> g(c->stream_refs_m);
@@ -1010,13 +1023,21 @@ int lzfse_mi_set_option(lzfse_mi_ctx *c, int option, int64_t value) {
     case LZFSE_MI_OPT_DIAG_CHAIN: c->diag_chain = (int)value; return LZFSE_MI_OK;
     case LZFSE_MI_OPT_DIAG_WALK: c->diag_walk = (int)value; return LZFSE_MI_OK;
     case LZFSE_MI_OPT_DIAG_PIPE_SCATTER: c->diag_pipe_scatter = (int)value; c->pipe_broken = false; return LZFSE_MI_OK;
+    case LZFSE_MI_OPT_DIAG_GUIDE: {
+        // (the reference's own conditions on the two, frontend_bytes.rs:166-168,359: the limit of a block lies MAX_MATCH_DISTANCE or more into it)
+        const uint64_t g = (uint64_t)value & 0xFFFFFFFFull, sl = (uint64_t)value >> 32;
+        if (value && (sl < 256 || 2 * sl > g || g > 0x7FFFFFFFull || g - sl - 3 < MAX_D_VALUE)) return LZFSE_MI_BAD_ARGUMENT;
+        c->diag_guide = (uint64_t)value;
+        return LZFSE_MI_OK;
+    }
 #else
     case LZFSE_MI_OPT_DIAG_LZ_PATH:
     case LZFSE_MI_OPT_DIAG_LZ_TILE:
     case LZFSE_MI_OPT_DIAG_STATS:
     case LZFSE_MI_OPT_DIAG_CHAIN:
     case LZFSE_MI_OPT_DIAG_WALK:
-    case LZFSE_MI_OPT_DIAG_PIPE_SCATTER: return LZFSE_MI_UNSUPPORTED;
+    case LZFSE_MI_OPT_DIAG_PIPE_SCATTER:
+    case LZFSE_MI_OPT_DIAG_GUIDE: return LZFSE_MI_UNSUPPORTED;
 #endif
     default: return LZFSE_MI_BAD_ARGUMENT;
     }
@@ -1521,8 +1542,86 @@ int lzfse_mi_decode(lzfse_mi_ctx *c, const uint8_t *src, size_t n, uint8_t *dst,
     return r ? r : st;
 }
 
+// A slice of more than BLOCK_GUIDE + 3 bytes (E20; frontend_bytes.rs:160-211 match_any, :348-375 reposition; test/src/big_mem.rs encodes
+// 0x8000_0003 .. 0x2_0000_0000 bytes this way). The reference matches it in blocks of BLOCK_GUIDE bytes: positions below a block's limit
+// (BLOCK_GUIDE - SLACK - 3) are visited, matches may run to the block's end, then the source slice is moved up to
+// MAX_MATCH_DISTANCE below where the walk stands and the next block begins. The device takes ONE BLOCK PER CALL; between the calls
+// this function does what reposition does to the walk's state, and carries what the FSE back end had not written yet:
+//   * the walk's literal index and pending match go into the next call as its start state (EncStream::start);
+//   * the positions the reference never pushed into its history -- those between the position the block's last match was found at
+//     and the limit, when that match ran past the limit -- are kept out of the next call's chains (EncTile::skip_lo);
+//   * the bvx2 block the back end was filling when the walk ended is not emitted: its events lead the next call's match list, and
+//     that call's stream begins at that block's first raw byte (at most a block's worth, 27 MB, below the reference's own slice), so
+//     that its literals are where the entropy stage looks for them. The complete blocks are final: their bytes stay in `dst`.
+static int encode_slice_blocks(lzfse_mi_ctx *c, const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *out_len, uint32_t guide, uint32_t slack) {
+    uint64_t base = 0, out = 0, lit = 0, p_idx = 0, p_midx = 0, raw0 = 0, sk_lo = 0, sk_hi = 0;
+    uint32_t p_len = 0, carry_skip = 0;
+    std::vector<lzmi::RepoEvent> carry;
+    std::vector<uint64_t> carry_pos;
+    bool first = true;
+    try {
+        for (;;) {
+            const uint64_t remaining = n - base;
+            const bool is_short = remaining <= (uint64_t)guide + 3;
+            const uint64_t block_len = is_short ? remaining : guide;
+            const uint64_t w0 = first ? 0 : std::min(base, raw0);
+            if (base - w0 > ((uint64_t)64 << 20) || lit < w0) return LZFSE_MI_IO;   // (a bvx2 block spans 27 MB at most)
+            lzmi::RepoWindow w;
+            w.first = first; w.final = is_short;
+            w.rel0 = (uint32_t)(base - w0);
+            w.stop = is_short ? 0u : (uint32_t)(base - w0 + block_len - slack - 3);
+            w.st_lit = (uint32_t)(lit - w0);
+            w.st_plen = p_len; w.st_pidx = p_len ? (uint32_t)(p_idx - w0) : 0u; w.st_pmidx = p_len ? (uint32_t)(p_midx - w0) : 0u;
+            w.st_skip = carry_skip; w.st_raw = (uint32_t)(raw0 - w0);
+            if (sk_hi > sk_lo && sk_hi > w0) { w.skip_lo = (uint32_t)(std::max(sk_lo, w0) - w0); w.skip_hi = (uint32_t)(sk_hi - w0); }
+            for (size_t k = 0; k < carry.size(); k++) {
+                if (carry_pos[k] < w0) return LZFSE_MI_IO;
+                carry[k].lit_pos = (uint32_t)(carry_pos[k] - w0);
+            }
+            w.carry = carry.data(); w.n_carry = (uint32_t)carry.size();
+            const uint8_t *ws = src + w0;
+            uint8_t *wd = dst + out;
+            size_t n_win = (size_t)(base + block_len - w0), wcap = cap - (size_t)out, got = 0;
+            int st = 0;
+            c->repo = &w;
+            const int r = lzfse_mi_encode_batch(c, 1, &ws, &n_win, &wd, &wcap, &got, &st);
+            c->repo = nullptr;
+            if (r || st) return r ? r : st;
+            out += got;
+            if (is_short) break;
+            // ---- reposition (:348-375) ----
+            lit = w0 + w.e_lit;
+            p_len = w.e_plen; p_idx = w0 + w.e_pidx; p_midx = w0 + w.e_pmidx;
+            const uint64_t limit = base + block_len - slack - 3;
+            const uint64_t idx_end = std::max(limit, lit);   // self.index after sync_history (:357)
+            sk_lo = sk_hi = 0;
+            if (w.e_cross && w0 + w.e_cross < limit) { sk_lo = w0 + w.e_cross; sk_hi = limit; }
+            carry = w.left;
+            if (!carry.empty() && w.left_skip) {
+                // (the front of the unclosed block's first event lies in blocks that are written: the event is carried without it)
+                lzmi::RepoEvent &f = carry[0];
+                const uint32_t sk = w.left_skip, sl = sk < f.l ? sk : f.l;
+                f.lit_pos += sk; f.l -= sl; f.m -= sk - sl;
+            }
+            carry_pos.resize(carry.size());
+            for (size_t k = 0; k < carry.size(); k++) carry_pos[k] = w0 + carry[k].lit_pos;
+            carry_skip = 0;
+            raw0 = w0 + w.left_raw;
+            base = idx_end - MAX_D_VALUE;   // delta = self.index - MAX_MATCH_DISTANCE (:359); the literals that have passed it left with this call
+            first = false;
+        }
+    } catch (...) { c->repo = nullptr; return LZFSE_MI_IO; }
+    *out_len = (size_t)out;
+    return LZFSE_MI_OK;
+}
+
 int lzfse_mi_encode(lzfse_mi_ctx *c, const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *out_len) {
     if (!out_len) return LZFSE_MI_BAD_ARGUMENT;
+    if (c && src && dst && !c->parse_ring) {
+        uint32_t guide, slack;
+        lzmi::ctx_diag_guide(c, guide, slack);
+        if (n > (size_t)guide + 3) return encode_slice_blocks(c, src, n, dst, cap, out_len, guide, slack);
+    }
     int st = 0;
     int r = lzfse_mi_encode_batch(c, 1, &src, &n, &dst, &cap, out_len, &st);
     return r ? r : st;

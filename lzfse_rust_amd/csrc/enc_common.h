@@ -127,8 +127,10 @@ __host__ __device__ __forceinline__ RingGeo ring_geo(uint32_t ring, uint32_t n, 
     return g;
 }
 // lowest position a backward extension of a match found at p may reach (find_match :482: match_idx - head); 0 for the slice parse
-__host__ __device__ __forceinline__ uint32_t parse_head(uint32_t ring, uint32_t n, uint32_t p) {
-    if (!ring) return 0u;
+// (midx: the candidate. rel0: a block of a slice beyond the first -- the reference's self.src begins there; a speculative walker that
+// stands in the part of the stream in front of it, where nothing it finds is ever used, must still stay inside the stream)
+__host__ __device__ __forceinline__ uint32_t parse_head(uint32_t ring, uint32_t n, uint32_t p, uint32_t rel0 = 0, uint32_t midx = 0xFFFFFFFFu) {
+    if (!ring) return rel0 <= midx ? rel0 : 0u;
     if (!(ring & RING_CONT) && (n < RING_SIZE || p < RING_FIRST_END)) return 0u;
     const uint32_t tl = ring_t_last(n);
     return ring_head_at((p < tl ? p : tl) & ~(RING_BLK - 1));
@@ -160,7 +162,18 @@ struct EncStream {       // one input stream (n > VN_CUTOFF) of the batch
     // a window that continues a stream: the parse starts from this state instead of (0, 0, nothing pending)
     uint32_t start, st_index, st_lit, st_pidx, st_pmidx, st_plen;
     uint32_t st_skip;   // bytes of the window's first event (its literals, then its match) that the window before has emitted already
+    // ---- one block of the reference's slice front end beyond the first (frontend_bytes.rs:160-211 match_any, :348-375 reposition): a
+    // slice of more than BLOCK_GUIDE + 3 bytes is matched in blocks of BLOCK_GUIDE bytes whose positions up to the block's limit are
+    // visited; the device takes a block per call (a "repo window", encode.hip enc_slice_blocks). The stream of such a call begins
+    // `rel0` bytes BEFORE the block (the raw bytes of the bvx2 block the front end had not closed yet: its events are carried) ----
+    uint32_t stop;      // the walk ends here (the block's limit) instead of at n - 3; 0: n - 3
+    uint32_t no_flush;  // != 0: no flush_pending / flush_literals behind the walk (the input goes on: the end state leaves in EncStreamOut)
+    uint32_t n_carry;   // events of the block the front end had not closed when the block before ended: the first n_carry gap events of the stream, put there by the host
+    uint32_t rel0;      // position of the block's first byte in this stream (self.src of the reference): no backward extension goes below it
+    uint32_t st_raw;    // first raw byte of the first bvx2 block this call makes (start != 0)
+    uint32_t pad2;
 };
+__device__ __forceinline__ uint32_t walk_end(const EncStream &es) { return es.stop ? es.stop : es.n - 3; }
 
 // One emitted match of a segment walker + the walker state after it, in 16 bytes (round 4; eight plain words before: the
 // events were 2.4 of the 43 bytes of HBM traffic per input byte written by the walkers and read again by the sync search and the
@@ -212,6 +225,9 @@ struct EncTile {         // one chain tile; carries what its kernels need of the
     uint32_t ring;       // EncStream::ring
     uint64_t src_off;    // offset of the stream in d_src
     uint64_t pos_base;   // offset of the stream in the per-position arrays (prev, rec)
+    uint32_t skip_lo, skip_hi;   // positions [skip_lo, skip_hi) are NOT entered into the history (chain tiles only): the reference never pushed
+                                 // them -- those between the position a block's last match was found at and the block's limit, when that match
+                                 // ran past the limit (frontend_bytes.rs:180,191-193,357)
 };
 
 struct EncBlock {        // one bvx2 block (written by the walk kernel)
@@ -241,6 +257,9 @@ struct EncStreamOut {
     int32_t status;
     uint64_t out_len;
     uint32_t n_matches, n_ranges;
+    // the walk's state where it ended (no_flush streams): literal index, pending match, and 1 + the position the last match was
+    // found at when that match carried the literal index past the walk's end (0 otherwise)
+    uint32_t e_lit, e_pidx, e_pmidx, e_plen, e_cross, e_pad;
     // walk statistics (diagnostics only)
     uint32_t iters, emits, capped, refills;
     uint64_t cycles;

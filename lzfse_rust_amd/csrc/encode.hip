@@ -772,6 +772,10 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     EncWindow *win = ctx_window(c);
     if (win && (count != 1 || !ring || src_len[0] < RING_SIZE || src_len[0] > 0x7FFFFFFFull)) return LZFSE_MI_BAD_ARGUMENT;
     if (win && win->beyond) ring |= RING_CONT;
+    // one block of a slice that the reference's front end matches in several (encode_slice_blocks, api.hip)
+    RepoWindow *repo = ctx_repo(c);
+    static_assert(sizeof(RepoEvent) == sizeof(MatchRec), "RepoEvent is MatchRec");
+    if (repo && (count != 1 || ring || win || src_len[0] <= VN_CUTOFF || src_len[0] > 0xF0000000ull)) return LZFSE_MI_BAD_ARGUMENT;
     for (uint32_t i = 0; i < count; i++) {
         out_lens[i] = 0;
         statuses[i] = LZFSE_MI_OK;
@@ -779,13 +783,23 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         if (n <= VN_CUTOFF) { statuses[i] = LZFSE_MI_UNSUPPORTED; continue; }  // host-side size classes (frontend_bytes.rs:63-77)
         // (a slice of up to BLOCK_GUIDE + 3 = 0x8000_0002 bytes is ONE block of the reference's front end, frontend_bytes.rs:169-178;
         // beyond that it repositions, :348-375, which is not built)
-        if (n > 0x80000002ull) { statuses[i] = LZFSE_MI_UNSUPPORTED; continue; }
+        if (n > 0x80000002ull && !repo) { statuses[i] = LZFSE_MI_UNSUPPORTED; continue; }
         EncStream e{};
         e.src_off = src_off[i]; e.dst_off = dst_off[i]; e.dst_cap = dst_cap[i];
         e.n = (uint32_t)n; e.user_index = i; e.ring = ring;
         if (win && win->start) {
             e.start = 1; e.st_index = win->st[0]; e.st_lit = win->st[1]; e.st_pidx = win->st[2]; e.st_pmidx = win->st[3]; e.st_plen = win->st[4]; e.st_skip = win->skip;
             if (e.st_lit > e.st_index || e.st_index >= e.n - 3) return LZFSE_MI_BAD_ARGUMENT;
+            e.st_raw = e.st_lit + e.st_skip;
+        }
+        if (repo) {
+            e.rel0 = repo->rel0; e.stop = repo->final ? 0u : repo->stop; e.no_flush = repo->final ? 0u : 1u; e.n_carry = repo->n_carry;
+            if (!repo->first) {
+                e.start = 1; e.st_index = repo->rel0 + MAX_D_VALUE; e.st_lit = repo->st_lit; e.st_pidx = repo->st_pidx; e.st_pmidx = repo->st_pmidx;
+                e.st_plen = repo->st_plen; e.st_skip = repo->st_skip; e.st_raw = repo->st_raw;
+                if (e.st_lit > e.st_index || e.st_index >= e.n - 3) return LZFSE_MI_BAD_ARGUMENT;
+            }
+            if (e.stop && (e.stop > e.n - 3 || e.stop <= e.st_index)) return LZFSE_MI_BAD_ARGUMENT;
         }
         hs.push_back(e);
     }
@@ -805,7 +819,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         e.pos_base = pos_total;
         e.tile_base = (uint32_t)ht.size();
         const uint32_t n_pos = e.n - 3;
-        for (uint32_t p = 0; p < n_pos; p += TILE_POS) ht.push_back({si, e.n, p, e.ring, e.src_off, e.pos_base});
+        for (uint32_t p = 0; p < n_pos; p += TILE_POS) ht.push_back({si, e.n, p, e.ring, e.src_off, e.pos_base, 0u, 0u});
         e.blk_base = blk_total;
         e.blk_cap = e.n / 39000 + 2 + ring;
         e.lmd_base = lmd_total;
@@ -821,7 +835,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         // (ring parse: up to one more event and range per 16 KiB block, the literals a round pushes when they pass the head)
         e.range_cap = 2 * e.n_seg + 4 + (ring ? e.n / RING_BLK + 4 : 0);
         e.match_base = match_total;
-        e.match_cap = e.n / 4 + 8 + (ring ? e.n / RING_BLK + 4 : 0);
+        e.match_cap = e.n / 4 + 8 + (ring ? e.n / RING_BLK + 4 : 0) + e.n_carry + 2;
         blk_total += e.blk_cap;
         range_total += e.range_cap;
         pos_total += ((uint64_t)e.n + 255) & ~255ull;
@@ -837,7 +851,8 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
     const uint32_t ch_pos = TILE_POS * ch_mult;
     std::vector<EncTile> hct;
     for (uint32_t si = 0; si < ns; si++)
-        for (uint32_t p = 0; p < hs[si].n - 3; p += ch_pos) hct.push_back({si, hs[si].n, p, hs[si].ring, hs[si].src_off, hs[si].pos_base});
+        for (uint32_t p = 0; p < hs[si].n - 3; p += ch_pos)
+            hct.push_back({si, hs[si].n, p, hs[si].ring, hs[si].src_off, hs[si].pos_base, repo ? repo->skip_lo : 0u, repo ? repo->skip_hi : 0u});
     const uint32_t nct = (uint32_t)hct.size();
 
     if (!eb_ensure(S, EB_STREAMS, ns * sizeof(EncStream)) || !eb_ensure(S, EB_TILES, nt * sizeof(EncTile)) || !eb_ensure(S, EB_CTILES, nct * sizeof(EncTile)) ||
@@ -928,6 +943,8 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
             if (!eb_ensure(S, EB_GSTATE, match_total * sizeof(uint4)) || !eb_ensure(S, EB_CUT, ns * sizeof(EncCut))) return LZFSE_MI_IO;
             d_gstate = (uint4 *)S.bufs[EB_GSTATE];
         }
+        if (repo && repo->n_carry)   // (the events of the bvx2 block the front end had not closed: in front of the stream's gap events)
+            E_TRY(hipMemcpyAsync(d_gaps + hs[0].match_base, repo->carry, (size_t)repo->n_carry * sizeof(MatchRec), hipMemcpyHostToDevice, stq));
         {
             StageTimer t(c, "enc_stitch");
             launch_enc_stitch(d_src, d_streams, ns, d_segs, nseg, seg, d_prev, d_rec, d_bitmap, d_logs, d_hdrs, (uint4 *)S.bufs[EB_SYNC], d_ranges, d_gaps,
@@ -989,6 +1006,26 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         uint32_t u = hs[i].user_index;
         statuses[u] = ho[i].status;
         out_lens[u] = ho[i].status ? 0 : ho[i].out_len;
+    }
+    if (repo && !repo->final && !ho[0].status) {
+        // a block that is not the slice's last: the bvx2 blocks that are complete are final; the last one (unclosed when the walk
+        // ended) is carried into the next call as its events, and the walk's state goes with it
+        const EncStreamOut &o = ho[0];
+        repo->e_lit = o.e_lit; repo->e_pidx = o.e_pidx; repo->e_pmidx = o.e_pmidx; repo->e_plen = o.e_plen; repo->e_cross = o.e_cross;
+        std::vector<EncBlock> hb(o.n_blocks);
+        if (o.n_blocks) E_TRY(hipMemcpy(hb.data(), d_blocks + hs[0].blk_base, (size_t)o.n_blocks * sizeof(EncBlock), hipMemcpyDeviceToHost));
+        uint64_t bytes = 0;
+        for (uint32_t b = 0; b + 1 < o.n_blocks; b++) bytes += (uint64_t)hb[b].hdr_len + hb[b].lit_len + hb[b].lmd_len;
+        repo->final_bytes = bytes;
+        uint32_t first_ev = 0, skip = hs[0].st_skip;
+        if (o.n_blocks >= 2) { first_ev = hb[o.n_blocks - 2].cut_ev; skip = (first_ev == 0 ? hs[0].st_skip : 0u) + hb[o.n_blocks - 2].cut_skip; }
+        if (first_ev == NONE || first_ev > o.n_matches) return LZFSE_MI_IO;
+        repo->left.resize(o.n_matches - first_ev);
+        if (!repo->left.empty())
+            E_TRY(hipMemcpy(repo->left.data(), (const MatchRec *)S.bufs[EB_MATCHES] + hs[0].match_base + first_ev, repo->left.size() * sizeof(MatchRec), hipMemcpyDeviceToHost));
+        repo->left_skip = repo->left.empty() ? 0u : skip;
+        repo->left_raw = o.n_blocks ? hb[o.n_blocks - 1].src_start : o.e_lit;
+        out_lens[hs[0].user_index] = bytes;
     }
     if (win && !win->final && !ho[0].status) {
         win->found = hcut.found;

@@ -88,6 +88,7 @@ __global__ __launch_bounds__(64 * CH_WAVES) __attribute__((amdgpu_waves_per_eu(L
     }
     uint32_t *pvt = pv + tl.start;   // records of the tile: offsets below 2^18
     bool wrong = false;
+    const bool has_skip = tl.skip_hi > tl.skip_lo;
     auto batch = [&](uint32_t b, auto full_tag, auto later_tag) {
         constexpr bool FULL = decltype(full_tag)::value, LATER = decltype(later_tag)::value;
         const uint32_t pb = tl.start + b * CH_POS;
@@ -108,11 +109,22 @@ __global__ __launch_bounds__(64 * CH_WAVES) __attribute__((amdgpu_waves_per_eu(L
             // ---- this batch's turn at the table: every earlier batch's exchanges have returned to their waves ----
             while (__hip_atomic_load(&sh_turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != b) __builtin_amdgcn_s_sleep(1);
             asm volatile("" ::: "memory");
+            if (has_skip && pb < tl.skip_hi && pb + CH_POS > tl.skip_lo) {
+                // (a batch that holds positions the reference never pushed: those make no exchange, and their link records are nobody's business)
+#pragma unroll
+                for (int j = 0; j < CH_STEPS; j++) {
+                    old[j] = 0;
+                    const uint32_t q = pb + 64 * j + lane;
+                    if ((FULL || q < t_end) && !(q >= tl.skip_lo && q < tl.skip_hi))
+                        old[j] = __hip_atomic_exchange(&last[key[j]], ent[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < CH_STEPS; j++) {
                 old[j] = 0;
                 if (FULL || pb + 64 * j + lane < t_end)
                     old[j] = __hip_atomic_exchange(&last[key[j]], ent[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             }
             // (the LDS alone is waited for: the loads of the next batch and the stores of the last one stay in flight)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -127,7 +139,9 @@ __global__ __launch_bounds__(64 * CH_WAVES) __attribute__((amdgpu_waves_per_eu(L
             uint32_t cnt = 0;
 #pragma unroll
             for (int j = 0; j < CH_STEPS; j++) {
-                const bool valid = FULL || pb + 64 * j + lane < t_end;
+                const uint32_t q = pb + 64 * j + lane;
+                // (a position the reference never pushed made no exchange: it is not the first of anything)
+                const bool valid = (FULL || q < t_end) && !(has_skip && q >= tl.skip_lo && q < tl.skip_hi);
                 cnt += (uint32_t)__popcll(__ballot(valid && (old[j] & 0x3FFFFu) == 0));
             }
             uint32_t base = 0;
@@ -139,7 +153,9 @@ __global__ __launch_bounds__(64 * CH_WAVES) __attribute__((amdgpu_waves_per_eu(L
             if (!FULL && pb + 64 * j >= t_end) continue;  // (not break: the loop must stay fully unrolled, the arrays live in registers)
             const uint32_t off = off0 + 64 * j;
             __builtin_assume(off < (1u << 18));
-            const bool valid = FULL || pb + 64 * j + lane < t_end;
+            const uint32_t qq = pb + 64 * j + lane;
+            const bool in_tile = FULL || qq < t_end;
+            const bool valid = in_tile && !(has_skip && qq >= tl.skip_lo && qq < tl.skip_hi);
             const uint32_t o = old[j] & 0x3FFFFu;
             wrong = wrong || (valid && o > off);   // a predecessor lies before its position (o is offset + 1)
             if (LATER) {
@@ -151,7 +167,7 @@ __global__ __launch_bounds__(64 * CH_WAVES) __attribute__((amdgpu_waves_per_eu(L
             }
             const uint32_t rec = o ? link_make(off + 1 - o, old[j] >> 18) : 0u;  // (inside a tile: < 2^18 and within the match window)
             if (FULL) pvt[off] = rec;
-            else if (valid) pvt[off] = rec;
+            else if (in_tile) pvt[off] = rec;
         }
     };
     __syncthreads();
@@ -193,7 +209,7 @@ __global__ __launch_bounds__(64) void enc_chain_ballot_kernel(const uint8_t *__r
     __builtin_amdgcn_wave_barrier();
     for (uint32_t p0 = tl.start; p0 < t_end; p0 += 64) {
         const uint32_t p = p0 + lane;
-        const bool valid = p < t_end;
+        const bool valid = p < t_end && !(p >= tl.skip_lo && p < tl.skip_hi);   // (positions the reference never pushed: EncTile::skip_lo)
         const uint32_t v = valid ? ld_u32(s + p) : 0u;
         const uint32_t key = bucket_of(v);
         const uint32_t old = last[key];
@@ -216,7 +232,7 @@ __global__ __launch_bounds__(64) void enc_chain_ballot_kernel(const uint8_t *__r
             if (first) fl[n_first + (uint32_t)__popcll(fm & lt_mask)] = (p - tl.start) | (key << 18);
             n_first += (uint32_t)__popcll(fm);
         }
-        if (valid) pv[p] = pr == NONE_TILE ? 0u : link_make(p - pr, chk_of(ld_u32(s + pr)));
+        if (p < t_end) pv[p] = (!valid || pr == NONE_TILE) ? 0u : link_make(p - pr, chk_of(ld_u32(s + pr)));   // (a position the reference never pushed: no link)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }

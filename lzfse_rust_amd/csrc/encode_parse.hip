@@ -191,7 +191,7 @@ __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict_
     const bool exists = g < n_segs;
     const uint2 sg = exists ? segs[g] : make_uint2(0, 0);
     const EncStream &es = streams[sg.x];
-    const uint32_t end = es.n - 3;
+    const uint32_t end = walk_end(es);
     const uint32_t ring = exists ? es.ring : 0u, n_own = es.n;
     const uint32_t S = sg.y * seg, ev_cap = seg_ev_cap(seg);
     const uint32_t stop = exists ? ((S + seg + OVER < end) ? S + seg + OVER : end) : 0;
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict_
                 }
                 d = link_dist(pv[c]);
             }
-            const uint32_t q_hr = best_idx - parse_head(qs.ring, qs.n, q_p);
+            const uint32_t q_hr = best_idx - parse_head(qs.ring, qs.n, q_p, qs.rel0, best_idx);
             const uint32_t bl = st_wave_lcs_bwd(s, q_p, best_idx, q_hr < BCAP ? q_hr : BCAP);
             if (lane == L) {
                 if (over) { status = 1; running = false; have = false; }  // longer than XCAP: left to the stitcher
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict_
         // ---- exact backward length when the capped one may be too short (frontend_bytes.rs:259-268) ----
         // backward room: the literals before p, and the bytes between the candidate and the start of the input -- or, for
         // the ring parse, the ring's head (frontend_ring.rs:482)
-        const uint32_t hroom = midx - parse_head(ring, n_own, p);
+        const uint32_t hroom = midx - parse_head(ring, n_own, p, es.rel0, midx);
         const uint32_t room = (p - st.lit) < hroom ? p - st.lit : hroom;
         uint32_t b = bw < room ? bw : room;
         uint64_t reqb = __ballot(have && bw == BCAP && room > BCAP);
@@ -307,7 +307,15 @@ __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict_
             {
                 uint32_t e_idx = 0, e_midx = 0, e_len = 0;
                 const uint32_t lit_before = st.lit;
+                WState st_was = st;
                 if (select40(st, p - b, midx - b, fwd + b, e_idx, e_midx, e_len)) {
+                    if (es.stop && e_idx + e_len >= end) {
+                        // a block of a slice that is not the last (EncStream::stop): the match that carries the literal index past the
+                        // block's limit is the stitcher's to make -- the position it is found at decides which positions the
+                        // reference never pushed (EncTile::skip_lo), and an event does not say it
+                        st = st_was; st.index = p;
+                        status = 1; running = false;
+                    } else {
                     st.lit = e_idx + e_len;
                     st.index = (p + 1 > st.lit) ? p + 1 : st.lit;
                     if (nev < ev_cap) {
@@ -316,6 +324,7 @@ __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict_
                         else ev[nev] = h;
                         nev++;
                     } else nev = ev_cap + 1;   // (log overflow: cannot happen, reported below)
+                    }
                 } else {
                     st.index = p + 1;
                 }
@@ -484,7 +493,7 @@ __global__ __launch_bounds__(64 * W) void enc_stitch_kernel(const uint8_t *__res
     const uint32_t *pv = prev + es.pos_base;
     const uint32_t *r = rec + es.pos_base;
     const uint64_t *bm = bitmap + (es.pos_base >> 6);
-    const uint32_t n = es.n, end = n - 3, K = es.n_seg;
+    const uint32_t n = es.n, end = walk_end(es), K = es.n_seg;
     // ring parse: the rounds of match_long end at the multiples of RING_BLK in [RING_FIRST_END, t_last]; a round that ends
     // with literals older than the new head pushes them as they are and drops the pending match (frontend_ring.rs:250-272)
     const uint32_t ring = es.ring;
@@ -499,6 +508,13 @@ __global__ __launch_bounds__(64 * W) void enc_stitch_kernel(const uint8_t *__res
     x.gstate = gstate ? gstate + es.match_base : nullptr; x.g_marked = 0;
     x.out_count = 0; x.gap_open = 0; x.status = 0;
     x.writer = wv == 0;
+    if (es.n_carry) {
+        // the events of the block the front end had not closed when the block before ended (a repo window, EncStream::n_carry): the
+        // host has put them in front of the stream's gap events, and they lead its match list
+        x.n_gaps = es.n_carry; x.g_marked = es.n_carry;
+        sx_close_gap(x);
+    }
+    uint32_t cross = 0;   // 1 + the position the walk's last match was found at, when that match took the literal index past the end
     uint32_t st_iters = 0, st_syncs = 0, st_fallbacks = 0;
     const uint64_t t_begin = __builtin_amdgcn_s_memtime();
 
@@ -631,7 +647,7 @@ __global__ __launch_bounds__(64 * W) void enc_stitch_kernel(const uint8_t *__res
         const uint32_t rr = r[p];
         uint32_t dist = rec_dist(rr), bw = rec_bwd(rr), fwd = rec_fwd(rr);
         uint32_t midx = p - dist;
-        const uint32_t head = parse_head(ring, n, p);
+        const uint32_t head = parse_head(ring, n, p, es.rel0, midx);
         if (fwd == FCAP) {
             // exact forward part of find_match (frontend_bytes.rs:214-231; ring parse: frontend_ring.rs:453-481) by the whole wave
             uint32_t best_len = 0, best_idx = 0;
@@ -661,7 +677,7 @@ __global__ __launch_bounds__(64 * W) void enc_stitch_kernel(const uint8_t *__res
         if (emitted) {
             sx_gap_event(x, lit_before, e_idx, e_len, e_idx - e_midx);
             T.lit = e_idx + e_len;
-            if (T.lit >= end) { T.index = end; done = true; return; }
+            if (T.lit >= end) { T.index = end; cross = p + 1; done = true; return; }
             T.index = (p + 1 > T.lit) ? p + 1 : T.lit;
         } else {
             T.index = p + 1;
@@ -719,6 +735,18 @@ __global__ __launch_bounds__(64 * W) void enc_stitch_kernel(const uint8_t *__res
         if (!walking) {
             // left the loop while following: cannot happen (the last segment always ends in walking mode)
             x.status = LZFSE_MI_IO;
+        } else if (es.no_flush) {
+            // the input goes on (a block of a slice that is not its last): reposition (frontend_bytes.rs:356-367) -- self.index = the
+            // limit, or the literal index when a match ran past it; literals that lie more than MAX_MATCH_DISTANCE below it have
+            // passed the next block's head: they go as they are and the pending match is dropped. The walk's state leaves with
+            // the stream's result below.
+            const uint32_t idx_end = T.lit > end ? T.lit : end, nb = idx_end - MAX_D_VALUE;
+            if (T.lit < nb) {
+                T.p_len = 0;
+                sx_gap_event(x, T.lit, nb, 0, 1);
+                T.lit = nb;
+            }
+            sx_close_gap(x);
         } else {
             // flush_pending (frontend_bytes.rs:271-285), then flush_literals (:304-317)
             if (T.p_len != 0) {
@@ -736,6 +764,7 @@ __global__ __launch_bounds__(64 * W) void enc_stitch_kernel(const uint8_t *__res
         EncStreamOut o;
         o.n_blocks = 0; o.status = x.status; o.out_len = 0;
         o.n_matches = x.out_count; o.n_ranges = x.n_ranges;
+        o.e_lit = T.lit; o.e_pidx = T.p_len ? T.p_idx : 0; o.e_pmidx = T.p_len ? T.p_midx : 0; o.e_plen = T.p_len; o.e_cross = cross; o.e_pad = 0;
         o.iters = st_iters; o.emits = st_syncs; o.capped = st_fallbacks; o.refills = 0;
         o.cycles = __builtin_amdgcn_s_memtime() - t_begin;
         outs[si] = o;
@@ -926,7 +955,7 @@ __global__ __launch_bounds__(SEGM_THREADS) void enc_segment_kernel(const EncStre
     uint32_t j = 0;             // next unprocessed event
     bool rem = false;           // remainder of a boundary event pending
     uint32_t rem_l = 0, rem_m = 0, rem_d = 0;
-    uint32_t raw_pos = es.start ? es.st_lit + es.st_skip : 0u;   // first raw byte of the current block (a window that continues a stream: where it takes the stream up)
+    uint32_t raw_pos = es.start ? es.st_raw : 0u;   // first raw byte of the current block (a window that continues a stream: where it takes the stream up)
     uint32_t rem_ev = 0, rem_all = 0;   // the event `rem` is what is left of, and its l + m
     bool more = true;
     // A block normally costs ONE memory round trip: the 64 lanes that probe the prefix sums just below the expected end
@@ -1210,7 +1239,7 @@ __global__ __launch_bounds__(64) void enc_segfin_kernel(const EncStream *__restr
     EncBlock *bk = blocks + es.blk_base;
     const int lane = e_lane();
     uint64_t stage_used = 0;
-    uint32_t raw_pos = es.start ? es.st_lit + es.st_skip : 0u;
+    uint32_t raw_pos = es.start ? es.st_raw : 0u;
     for (uint32_t b0 = 0; b0 < nb; b0 += 64) {
         const uint32_t b = b0 + (uint32_t)lane;
         const bool in = b < nb;

@@ -61,6 +61,7 @@ class LaneWorker {
 struct StageTimer {
     lzfse_mi_ctx *ctx;
     int idx = -1;
+    const char *stage;
     StageTimer(lzfse_mi_ctx *c, const char *name);
     ~StageTimer();
 };
@@ -98,6 +99,30 @@ struct EncWindow {
     uint32_t found = 0, index = 0, lit = 0, p_idx = 0, p_midx = 0, p_len = 0, skip_out = 0;
 };
 EncWindow *ctx_window(lzfse_mi_ctx *c);
+// One block of the reference's slice front end beyond what a single call takes (frontend_bytes.rs:160-211,348-375; a slice of more
+// than BLOCK_GUIDE + 3 bytes): what the device call over it is told and what it tells (encode_slice_blocks in api.hip drives the
+// blocks, enc_batch_device fills EncStream from this). Positions are relative to the call's stream, which begins `rel0` bytes before
+// the block: at the first raw byte of the bvx2 block the front end had not closed when the block before ended.
+struct RepoEvent { uint32_t lit_pos, l, m, d; };   // (MatchRec, enc_common.h)
+struct RepoWindow {
+    // in
+    bool first = true;            // the slice's first block: the parse starts at (0, 0, nothing pending)
+    bool final = false;           // its last block: flush_pending, flush_literals, bvx$
+    uint32_t rel0 = 0;            // the block's first byte (self.src of the reference)
+    uint32_t stop = 0;            // the block's limit (not the last block)
+    uint32_t st_lit = 0, st_pidx = 0, st_pmidx = 0, st_plen = 0;   // literal index and pending match at the block's first visited position, rel0 + MAX_MATCH_DISTANCE
+    uint32_t st_skip = 0, st_raw = 0;   // bytes of the first carried event that have left already; first raw byte of the first bvx2 block of this call
+    uint32_t skip_lo = 0, skip_hi = 0;  // positions the reference never pushed into its history
+    const RepoEvent *carry = nullptr;   // events of the unclosed bvx2 block
+    uint32_t n_carry = 0;
+    // out (not the last block)
+    uint32_t e_lit = 0, e_pidx = 0, e_pmidx = 0, e_plen = 0, e_cross = 0;   // EncStreamOut::e_*
+    uint64_t final_bytes = 0;     // bytes of the bvx2 blocks that are complete
+    uint32_t left_skip = 0, left_raw = 0;   // the unclosed block: bytes of its first event that lie before it, its first raw byte
+    std::vector<RepoEvent> left;  // ... and its events
+};
+RepoWindow *ctx_repo(lzfse_mi_ctx *c);
+void ctx_diag_guide(lzfse_mi_ctx *c, uint32_t &guide, uint32_t &slack);   // BLOCK_GUIDE, SLACK (frontend_bytes.rs:19-23); the diagnostic build can set small ones
 // A growable byte buffer in PINNED host memory (hipHostMalloc): what the stream objects (stream.hip) keep their windows in, so
 // that a window travels by plain DMA in both directions -- a transfer from or to pageable memory is pinned page by page by the
 // runtime first, every time (64 MiB windows: stream decode 10.0 -> see profiles/r04_stream_bench.txt).

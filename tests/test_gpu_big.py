@@ -50,6 +50,22 @@ def test_big_zeros_slice(ctx, oracle, n):
     assert st[0] == 0 and dec[0].size == n and not dec[0].any()
 
 
+@pytest.mark.parametrize("n", [0x8000_0003, 0x8000_0004])
+def test_big_zeros_slice_repositions(ctx, oracle, n):
+    """big_mem.rs:92-102 at the first sizes the reference's front end matches in TWO blocks (more than BLOCK_GUIDE + 3 bytes:
+    frontend_bytes.rs:348-375 reposition): LzfseEncoder::encode_bytes == the oracle's bytes (its restated reposition), and back.
+    tests/test_gpu_reposition.py has the many-block cases at a small BLOCK_GUIDE; noise of these sizes: scripts/big_mem.py."""
+    import lzfse_rust_amd as m
+    _need_gib(16)
+    data = np.zeros(n, dtype=np.uint8)
+    want = oracle.encode(data)
+    out = bytearray()
+    got = m.LzfseEncoder(context=ctx).encode_bytes(data, out)
+    assert got == len(want) and bytes(out) == want
+    dec, st = ctx.decode_batch([want], caps=[n])
+    assert st[0] == 0 and dec[0].size == n and not dec[0].any()
+
+
 def test_big_zeros_stream_beyond_u32(ctx, oracle):
     """More than 2^32 zeros through LzfseWriter (lzfse_mi_estream_*: 64 MiB windows with carried state; a window's positions are
     relative) == the restated ring encoder (frontend_ring.rs), which is fed the same pieces."""
