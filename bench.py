@@ -225,6 +225,26 @@ def main():
             assert np.array_equal(np.asarray(lz.decode_chunked(cx, frame)), part)
             for c in cx[1:]:
                 c.close()
+        # ... and what that caller gets on ONE device: the whole 1 GiB through lzfse_mi_encode_chunked / _decode_chunked (host
+        # pointers in and out, the frame assembled in the caller's buffer; best of 2, N = 1 only)
+        chunked_rate = None
+        if rank == 0 and world == 1 and not emu and not args.no_extras:
+            best_e = best_d = 1e9
+            frame = None
+            for _ in range(2):
+                t0 = time.perf_counter()
+                frame = lz.encode_chunked([ctx], data, sharding.CHUNK_BYTES)
+                best_e = min(best_e, time.perf_counter() - t0)
+            for _ in range(2):
+                t0 = time.perf_counter()
+                back = lz.decode_chunked([ctx], frame)
+                best_d = min(best_d, time.perf_counter() - t0)
+            assert np.array_equal(np.asarray(back), data)
+            chunked_rate = {"encode_GBps": round(data.size / best_e / 1e9, 2), "decode_GBps": round(data.size / best_d / 1e9, 2),
+                            "frame_bytes": int(frame.size),
+                            "what": "the whole 1 GiB through lzfse_mi_encode_chunked / lzfse_mi_decode_chunked on one context (host memory in and "
+                                    "out, 256 chunks of 4 MiB framed as LZMC; the Python binding allocates the destination; best of 2)"}
+            del back, frame
         del data
     else:
         t = synth_text(256 << 20, seed=1 + rank)
@@ -347,6 +367,8 @@ def main():
         }
         if args.workload == "chunks1g":
             out["chunked_over_devices"] = chunked_devices   # (> 1: lzfse_mi_encode_chunked ran over that many devices from rank 0, checked)
+            if chunked_rate:
+                out["chunked_one_device"] = chunked_rate
         if kx is not None:
             if dom in kx:   # (an unsplit call may take another LZ path than its sub-batches did)
                 ex_ms = kx[dom][0] / max(kx[dom][1], 1)

@@ -126,7 +126,11 @@ LZFSE_MI_API size_t lzfse_mi_encode_bound(size_t n);
 /* ---- host-pointer entry points: exactly what the Rust shim binds ---------------------- */
 
 /* encode_bytes: writes the complete stream (blocks + bvx$) for src[0..n) at dst, never more
- * than cap bytes; *out_len = bytes written (the u64 the Rust method returns). */
+ * than cap bytes; *out_len = bytes written (the u64 the Rust method returns). Any n: a slice of more than
+ * 0x8000_0002 bytes is matched in several blocks, as the reference's front end does it (frontend_bytes.rs:160-211,
+ * 348-375: match_any / reposition; its test/src/big_mem.rs encodes 0x8000_0003 .. 0x2_0000_0000 bytes), one device
+ * call per block; size cap with lzfse_mi_encode_bound(n). (The batch entry points take streams of up to 0x8000_0002
+ * bytes -- one block of the front end -- and answer LZFSE_MI_UNSUPPORTED for a longer one.) */
 LZFSE_MI_API int lzfse_mi_encode(lzfse_mi_ctx *ctx, const uint8_t *src, size_t n, uint8_t *dst, size_t cap,
                     size_t *out_len);
 

@@ -254,3 +254,67 @@ def test_normalize_m1_invariants(oracle):
             oracle.lib.lzo_normalize_m1(w.ctypes.data, n_sym, int(w.sum()), states)
             assert int(w.sum()) == states
             assert ((w != 0) == nz).all()
+
+
+# ---- reposition (frontend_bytes.rs:348-375): slices that the front end matches in several blocks ----
+G_SMALL, S_SMALL = 0x100000, 0x20000     # BLOCK_GUIDE / SLACK of the test hook: 1 MiB / 128 KiB (the limit lies 917 501 into a block)
+
+
+def test_reposition_one_block_below_the_guide(oracle, snappy_raw):
+    """A slice of up to BLOCK_GUIDE + 3 bytes is ONE block whatever the guide (:169-178): lzo_encode_guide == lzo_encode there, and
+    lzo_encode itself is the guide of the reference (0x7FFF_FFFF / 0x1000_0000)."""
+    text = snappy_raw["lcet10.txt"] + snappy_raw["html"]
+    for n in (4097, 100000, len(text)):
+        assert oracle.encode_guide(text[:n], G_SMALL, S_SMALL) == oracle.encode(text[:n])
+    big = text * 9                                    # 4.8 MB: five blocks at the small guide, one at the reference's
+    assert oracle.encode_guide(big, 0x7FFFFFFF, 0x10000000) == oracle.encode(big)
+    assert oracle.encode_guide(big[:G_SMALL + 3], G_SMALL, S_SMALL) == oracle.encode(big[:G_SMALL + 3])
+
+
+def test_reposition_zeros_by_hand(oracle):
+    """Zeros of BLOCK_GUIDE + 4 bytes, the first size that repositions: position 1 matches position 0 to the END OF THE BLOCK
+    (BLOCK_GUIDE - 1 bytes, :253), the walk stands at BLOCK_GUIDE, the slice moves up to MAX_MATCH_DISTANCE below it, and the
+    second block -- short: 4 + 262 139 bytes -- visits ONE position, whose match of 4 bytes is flushed as pending (:271-285).
+    One block of G + 4 zeros would be one match of G + 3 bytes: the LMD streams differ in their last two entries."""
+    n = G_SMALL + 4
+    got = oracle.decode_lmds(oracle.encode_guide(bytes(n), G_SMALL, S_SMALL))[1]
+    one = oracle.decode_lmds(oracle.encode(bytes(n)))[1]
+    total = lambda lmds: sum(int(l) + int(m) for l, m, _ in lmds)
+    assert total(got) == n and total(one) == n
+    flat = lambda lmds: [(int(l), int(m), int(d)) for l, m, d in lmds]
+    g, o1 = flat(got), flat(one)
+    k = (G_SMALL - 1) // 2359
+    assert g[0] == (1, 2359, 1) and g[:k] == o1[:k]
+    assert g[k:] == [(0, (G_SMALL - 1) - 2359 * k, 1), (0, 4, 1)]           # the rest of the first block's match, then the 4-byte match
+    assert o1[k:] == [(0, (G_SMALL + 3) - 2359 * k, 1)]
+
+
+@pytest.mark.parametrize("kind", ["text", "zeros", "noise", "masked", "desert", "period", "runs"])
+def test_reposition_round_trips(oracle, snappy_raw, kind):
+    """Five blocks and more at the small guide: the stream decodes back (the decoder is pinned by the reference's fixtures), for
+    matches that run past a block's limit or to its end (zeros, periods, runs), literal deserts that pass the next block's
+    head -- pushed as they are, the pending match dropped (:361-367) -- and plain text."""
+    from oracle_py import rng_gen_vec, seq_masked
+    rng = np.random.default_rng(5)
+    text = (snappy_raw["lcet10.txt"] + snappy_raw["alice29.txt"] + snappy_raw["urls.10K"]) * 4
+    data = {
+        "text": text,
+        "zeros": bytes(3_500_000),
+        "noise": rng_gen_vec(3, 3_000_000),
+        "masked": seq_masked(2, 0x03030303, 3_000_000),
+        "desert": rng_gen_vec(4, 1_500_000) + text[:2_000_000] + rng_gen_vec(5, 900_000) + bytes(700_000),
+        "period": rng_gen_vec(6, 70_000) * 60,
+        "runs": b"".join(bytes([int(rng.integers(0, 256))]) * int(rng.integers(2000, 90000)) for _ in range(80)),
+    }[kind]
+    enc = oracle.encode_guide(data, G_SMALL, S_SMALL)
+    assert oracle.decode(enc) == data
+    if kind in ("zeros", "period", "noise", "desert"):
+        assert enc != oracle.encode(data)      # (a match across a block's limit, or a literal desert: not what one block makes)
+
+
+def test_reposition_guide_conditions(oracle):
+    """The reference's own assertions on the two constants (:166-168,359): lzo_encode_guide refuses what they forbid."""
+    from oracle_py import OracleError
+    for g, s in ((0x100000, 255), (0x100000, 0x80001), (0x40000, 0x100), (0x80000000, 0x10000000)):
+        with pytest.raises(OracleError):
+            oracle.encode_guide(bytes(5000), g, s)
