@@ -283,7 +283,7 @@ void launch_enc_cand(const uint8_t *src, const EncStream *streams, const EncTile
 
 // encode_parse.hip
 void launch_enc_spec(const uint8_t *src, const EncStream *streams, const uint2 *segs, uint32_t n_segs, uint32_t seg, const uint32_t *prev,
-                     const uint32_t *rec, const uint64_t *bitmap, SpecEvent *logs, SpecHeader *hdrs, hipStream_t st);
+                     const uint32_t *rec, const uint64_t *bitmap, SpecEvent *logs, SpecHeader *hdrs, bool repo, hipStream_t st);
 void launch_enc_stitch(const uint8_t *src, const EncStream *streams, uint32_t ns, const uint2 *segs, uint32_t n_segs, uint32_t seg, const uint32_t *prev,
                        const uint32_t *rec, const uint64_t *bitmap, const SpecEvent *logs, const SpecHeader *hdrs, uint4 *sync,
                        RangeRec *ranges, MatchRec *gaps, uint4 *gstate /* may be null */, EncStreamOut *outs, hipStream_t st);

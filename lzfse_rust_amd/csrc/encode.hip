@@ -936,7 +936,7 @@ int enc_batch_device(lzfse_mi_ctx *c, uint32_t count, const uint8_t *d_src, cons
         E_TRY(hipMemcpyAsync(d_rslots, prslots.data(), (size_t)range_total * 4, hipMemcpyHostToDevice, stq));
         {
             StageTimer t(c, "enc_spec");
-            launch_enc_spec(d_src, d_streams, d_segs, nseg, seg, d_prev, d_rec, d_bitmap, d_logs, d_hdrs, stq);
+            launch_enc_spec(d_src, d_streams, d_segs, nseg, seg, d_prev, d_rec, d_bitmap, d_logs, d_hdrs, repo && !repo->final, stq);
         }
         uint4 *d_gstate = nullptr;
         if (win && !win->final) {

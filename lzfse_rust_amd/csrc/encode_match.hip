@@ -193,8 +193,11 @@ __global__ __launch_bounds__(64) void enc_chain_ballot_kernel(const uint8_t *__r
                                                               uint32_t *__restrict__ flist, uint32_t *__restrict__ fcount,
                                                               const uint32_t *__restrict__ redo) {
     __shared__ uint32_t last[1u << HASH_BITS];  // offset in tile + 1, 0 = none
-    const uint32_t t = blockIdx.x;
-    if (t >= n_tiles || !redo[t]) return;
+    // (a few workgroups look through all the tiles' flags: the kernel is queued behind every enc_chain_kernel and finds nothing to
+    // do -- one workgroup per tile made that 55 us of an 11 500-tile launch, profiles/r04_bench_kernel_stats.csv)
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    if (!redo[t]) continue;
+    __syncthreads();
     const EncTile tl = tiles[t];
     const int lane = e_lane();
     for (uint32_t k = lane; k < (1u << HASH_BITS); k += 64) last[k] = 0;
@@ -241,6 +244,7 @@ __global__ __launch_bounds__(64) void enc_chain_ballot_kernel(const uint8_t *__r
     for (uint32_t k = lane; k < (1u << HASH_BITS); k += 64) {
         const uint32_t o = last[k];
         sm[k] = o ? seen_make(o, ld_u32(s + tl.start + o - 1)) : 0u;
+    }
     }
 }
 
@@ -772,7 +776,7 @@ void launch_enc_chain(const uint8_t *src, const EncTile *tiles, uint32_t n_tiles
     if (!n_tiles) return;
     hipLaunchKernelGGL(enc_chain_kernel, dim3(n_tiles), dim3(64 * CH_WAVES), 0, st, src, tiles, n_tiles, tile_pos, prev, summary, flist, fcount, redo,
                        force_redo ? 1u : 0u);
-    hipLaunchKernelGGL(enc_chain_ballot_kernel, dim3(n_tiles), dim3(64), 0, st, src, tiles, n_tiles, tile_pos, prev, summary, flist, fcount, redo);
+    hipLaunchKernelGGL(enc_chain_ballot_kernel, dim3(n_tiles < 512u ? n_tiles : 512u), dim3(64), 0, st, src, tiles, n_tiles, tile_pos, prev, summary, flist, fcount, redo);
 }
 
 void launch_enc_link(const EncTile *tiles, uint32_t n_tiles, uint32_t tile_pos, uint32_t *prev, const uint32_t *summary,

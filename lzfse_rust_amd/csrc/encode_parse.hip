@@ -181,7 +181,9 @@ __device__ void st_ring_find(const uint8_t *s, const uint32_t *pv, uint32_t ring
 
 // All 64 lanes stay in the loop until every segment of the wave is finished, so that a lane whose
 // record is capped can have its exact lengths computed by the whole wave (one request at a time).
-template <bool STAGED>
+// (REPO: the call holds a block of a long slice that is not the last, EncStream::stop -- its walkers leave the match that crosses the
+// block's limit to the stitcher; a kernel of its own, so that every other call's walkers carry nothing of it)
+template <bool STAGED, bool REPO>
 __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
                                                       const uint2 *__restrict__ segs, uint32_t n_segs, uint32_t seg,
                                                       const uint32_t *__restrict__ prev, const uint32_t *__restrict__ rec,
@@ -191,7 +193,9 @@ __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict_
     const bool exists = g < n_segs;
     const uint2 sg = exists ? segs[g] : make_uint2(0, 0);
     const EncStream &es = streams[sg.x];
-    const uint32_t end = walk_end(es);
+    const uint32_t end = REPO ? walk_end(es) : es.n - 3;
+    const uint32_t rel0 = REPO ? es.rel0 : 0u;   // (read once: the loop below stores events, and the compiler would fetch it again at every step)
+    const bool to_limit = REPO && es.stop != 0;
     const uint32_t ring = exists ? es.ring : 0u, n_own = es.n;
     const uint32_t S = sg.y * seg, ev_cap = seg_ev_cap(seg);
     const uint32_t stop = exists ? ((S + seg + OVER < end) ? S + seg + OVER : end) : 0;
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict_
                 }
                 d = link_dist(pv[c]);
             }
-            const uint32_t q_hr = best_idx - parse_head(qs.ring, qs.n, q_p, qs.rel0, best_idx);
+            const uint32_t q_hr = best_idx - parse_head(qs.ring, qs.n, q_p, REPO ? qs.rel0 : 0u, best_idx);
             const uint32_t bl = st_wave_lcs_bwd(s, q_p, best_idx, q_hr < BCAP ? q_hr : BCAP);
             if (lane == L) {
                 if (over) { status = 1; running = false; have = false; }  // longer than XCAP: left to the stitcher
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict_
         // ---- exact backward length when the capped one may be too short (frontend_bytes.rs:259-268) ----
         // backward room: the literals before p, and the bytes between the candidate and the start of the input -- or, for
         // the ring parse, the ring's head (frontend_ring.rs:482)
-        const uint32_t hroom = midx - parse_head(ring, n_own, p, es.rel0, midx);
+        const uint32_t hroom = midx - parse_head(ring, n_own, p, rel0, midx);
         const uint32_t room = (p - st.lit) < hroom ? p - st.lit : hroom;
         uint32_t b = bw < room ? bw : room;
         uint64_t reqb = __ballot(have && bw == BCAP && room > BCAP);
@@ -307,15 +311,15 @@ __global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict_
             {
                 uint32_t e_idx = 0, e_midx = 0, e_len = 0;
                 const uint32_t lit_before = st.lit;
-                WState st_was = st;
-                if (select40(st, p - b, midx - b, fwd + b, e_idx, e_midx, e_len)) {
-                    if (es.stop && e_idx + e_len >= end) {
-                        // a block of a slice that is not the last (EncStream::stop): the match that carries the literal index past the
-                        // block's limit is the stitcher's to make -- the position it is found at decides which positions the
-                        // reference never pushed (EncTile::skip_lo), and an event does not say it
-                        st = st_was; st.index = p;
-                        status = 1; running = false;
-                    } else {
+                // a block of a slice that is not the last (EncStream::stop): the match that carries the literal index past the
+                // block's limit is the stitcher's to make -- the position it is found at decides which positions the reference
+                // never pushed (EncTile::skip_lo), and an event does not say it. Whatever this step could emit that reaches the
+                // limit -- the incoming match or the pending one -- ends the walker here, before its state changes.
+                if (to_limit && (p + fwd >= end || (st.p_len && st.p_idx + st.p_len >= end))) {
+                    st.index = p;
+                    status = 1; running = false;
+                } else if (select40(st, p - b, midx - b, fwd + b, e_idx, e_midx, e_len)) {
+                    {
                     st.lit = e_idx + e_len;
                     st.index = (p + 1 > st.lit) ? p + 1 : st.lit;
                     if (nev < ev_cap) {
@@ -1377,11 +1381,14 @@ __global__ __launch_bounds__(64) void enc_cut_kernel(const EncStream *__restrict
 // ------------------------------------------------------------------------------------ launchers
 
 void launch_enc_spec(const uint8_t *src, const EncStream *streams, const uint2 *segs, uint32_t n_segs, uint32_t seg, const uint32_t *prev,
-                     const uint32_t *rec, const uint64_t *bitmap, SpecEvent *logs, SpecHeader *hdrs, hipStream_t st) {
+                     const uint32_t *rec, const uint64_t *bitmap, SpecEvent *logs, SpecHeader *hdrs, bool repo, hipStream_t st) {
     if (!n_segs) return;
-    if (n_segs > 98304) hipLaunchKernelGGL(enc_spec_kernel<true>, dim3((n_segs + 63) / 64), dim3(64), 0, st, src, streams, segs, n_segs, seg, prev, rec, bitmap,
-                                           logs, hdrs);
-    else hipLaunchKernelGGL(enc_spec_kernel<false>, dim3((n_segs + 63) / 64), dim3(64), 0, st, src, streams, segs, n_segs, seg, prev, rec, bitmap, logs, hdrs);
+    const dim3 grid((n_segs + 63) / 64);
+    if (repo) {
+        if (n_segs > 98304) hipLaunchKernelGGL((enc_spec_kernel<true, true>), grid, dim3(64), 0, st, src, streams, segs, n_segs, seg, prev, rec, bitmap, logs, hdrs);
+        else hipLaunchKernelGGL((enc_spec_kernel<false, true>), grid, dim3(64), 0, st, src, streams, segs, n_segs, seg, prev, rec, bitmap, logs, hdrs);
+    } else if (n_segs > 98304) hipLaunchKernelGGL((enc_spec_kernel<true, false>), grid, dim3(64), 0, st, src, streams, segs, n_segs, seg, prev, rec, bitmap, logs, hdrs);
+    else hipLaunchKernelGGL((enc_spec_kernel<false, false>), grid, dim3(64), 0, st, src, streams, segs, n_segs, seg, prev, rec, bitmap, logs, hdrs);
 }
 void launch_enc_stitch(const uint8_t *src, const EncStream *streams, uint32_t ns, const uint2 *segs, uint32_t n_segs, uint32_t seg, const uint32_t *prev,
                        const uint32_t *rec, const uint64_t *bitmap, const SpecEvent *logs, const SpecHeader *hdrs, uint4 *sync,
