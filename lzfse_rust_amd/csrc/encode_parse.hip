@@ -183,8 +183,15 @@ __device__ void st_ring_find(const uint8_t *s, const uint32_t *pv, uint32_t ring
 // record is capped can have its exact lengths computed by the whole wave (one request at a time).
 // (REPO: the call holds a block of a long slice that is not the last, EncStream::stop -- its walkers leave the match that crosses the
 // block's limit to the stitcher; a kernel of its own, so that every other call's walkers carry nothing of it)
+// At most three walker waves per SIMD (round 5): a large launch is bound by the rate of its record misses, not by how many walkers
+// are resident -- 2.53 ms exclusive at 3 as at 8 waves per SIMD, 2.9 at 2, 4.75 at 1 (profiles/r05_ab_spec_occ.txt) -- and the slots it
+// leaves are what another lane's candidate kernel runs in: encode 35.0 -> 35.5 GB/s in the three-lane schedule of the default batch.
+#ifndef LZMI_SPEC_OCC
+#define LZMI_SPEC_OCC 3
+#endif
+#define LZMI_SPEC_ATTR __attribute__((amdgpu_waves_per_eu(1, LZMI_SPEC_OCC)))
 template <bool STAGED, bool REPO>
-__global__ __launch_bounds__(64) void enc_spec_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
+__global__ __launch_bounds__(64) LZMI_SPEC_ATTR void enc_spec_kernel(const uint8_t *__restrict__ src, const EncStream *__restrict__ streams,
                                                       const uint2 *__restrict__ segs, uint32_t n_segs, uint32_t seg,
                                                       const uint32_t *__restrict__ prev, const uint32_t *__restrict__ rec,
                                                       const uint64_t *__restrict__ bitmap, SpecEvent *__restrict__ logs,

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Everything the round's profiles/ files come from, on one GPU box (about 15 minutes); then scripts/collect_profiles.sh TAG here.
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd "$(dirname "$0")/.."
 export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 bash scripts/profile_all.sh $TAG || exit 1
