@@ -972,6 +972,11 @@ int lzfse_mi_encode_batch_device(lzfse_mi_ctx *c, size_t count, const void *d_sr
         uint64_t total = 0;
         for (size_t i = 0; src_len && i < count; i++) total += src_len[i];
         lanes = total >= (700ull << 20) ? 3 : total >= (448ull << 20) ? 2 : 1;
+        // ... except a call of many small streams, 24 .. 100 MiB in 128 streams and more: every stage of such a call is one round of
+        // resident workgroups, and two halves run their rounds side by side (each Snappy file x 256: 26 .. 47 MB, encode 19.1 / 17.3 /
+        // 21.9 / 22.8 GB/s as one pass against 22.7 / 21.6 / 25.3 / 26.0 in two lanes; Snappy x 16 / x 32: 17.8 / 22.5 against 18.1 / 22.7;
+        // 64 streams are better off as one pass up to 26 MB: profiles/r05_per_file_lanes.txt, r05_lanes_small.txt)
+        if (lanes == 1 && count >= 128 && total >= (24ull << 20) && total < (100ull << 20)) lanes = 2;
     }
     return split_batch(c, encode_batch_device_one, lanes, c->opt_stagger != 0, count, d_src, src_off, src_len, d_dst, dst_off, dst_cap,
                        out_lens, statuses);
