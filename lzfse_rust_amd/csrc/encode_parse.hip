@@ -810,6 +810,7 @@ __global__ __launch_bounds__(64) void enc_compact_kernel(const EncStream *__rest
     const int lane = e_lane();
     const SpecEvent *ev = logs + rg.begin;
     const MatchRec *g = gaps + es.match_base + rg.begin;
+    const uint32_t st_skip = es.st_skip;   // (read once: the loop stores, and the compiler would fetch the descriptor again every time round)
     uint32_t carry_c = 0, carry_l = 0;
     for (uint32_t q0 = 0; q0 < rg.count; q0 += 64) {
         const uint32_t q = q0 + lane;
@@ -822,9 +823,9 @@ __global__ __launch_bounds__(64) void enc_compact_kernel(const EncStream *__rest
             } else {
                 m = g[q];
             }
-            if (es.st_skip && rg.out_off + q == 0) {
+            if (st_skip && rg.out_off + q == 0) {
                 // a window that continues a stream: the front of its first event left with the window before
-                const uint32_t sk = es.st_skip, sl = sk < m.l ? sk : m.l;
+                const uint32_t sk = st_skip, sl = sk < m.l ? sk : m.l;
                 m.lit_pos += sk; m.l -= sl; m.m -= sk - sl;
             }
             out[q] = m;
