@@ -11,7 +11,8 @@ for D in "${VARS[@]}"; do
   OBJS=$(ls $P/build/prod_*.o)
   for S in $SRCS; do
     hipcc $FLAGS $D -c $P/csrc/$S.hip -o /tmp/abd_$S.o || { cp /tmp/lib_keep.so $P/liblzfse_mi.so; exit 1; }
-    OBJS=$(echo "$OBJS" | grep -v "prod_$S.o"); OBJS="$OBJS /tmp/abd_$S.o"
+    OBJS=$(echo "$OBJS" | grep -v "prod_$S\.o"); OBJS="$OBJS
+/tmp/abd_$S.o"
   done
   hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $P/liblzfse_mi.so
   for REP in 1 2; do
